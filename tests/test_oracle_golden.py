@@ -1,0 +1,164 @@
+"""Pins oracle/flowdec_oracle.py against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden, rel_err
+from oracle import flowdec_oracle as O
+
+
+def test_window_and_stft():
+    g = load_golden("g1_stft.npz")
+    assert np.allclose(O.hann_sym(1534, np.float32), g["window"], atol=1e-7)
+    S = O.stft(g["y"])
+    assert S.shape == g["stft"].shape == (2, 1, 768, 13)
+    assert rel_err(S, g["stft"]) < 2e-6
+    assert O.num_frames(4800) == 13 and O.num_frames(96000) == 251 and O.num_frames(48000) == 126
+
+
+def test_frame_indexing_exact():
+    # frame j covers padded samples [384 j, 384 j + 1534) with reflect padding 767 (integer exact)
+    y = np.arange(5000, dtype=np.float64)[None, :]
+    fr = O.frame_signal(y)
+    assert fr.shape == (1, 14, 1534)
+    assert fr[0, 0, 767] == 0 and fr[0, 0, 0] == 767 and fr[0, 0, 766] == 1
+    assert fr[0, 3, 0] == 3 * 384 - 767
+    assert fr[0, 13, 1533] == 2 * 4999 - (13 * 384 + 1533 - 767)
+
+
+def test_compress_and_invert():
+    g = load_golden("g1_stft.npz")
+    C = O.compress(g["stft"])
+    assert rel_err(C, g["compressed"]) < 2e-6
+    D = O.decompress(g["compressed"])
+    assert rel_err(D, g["decompressed"]) < 5e-6
+
+
+def test_istft():
+    g = load_golden("g1_stft.npz")
+    rt = O.istft(g["decompressed"], 4800)
+    assert rel_err(rt, g["roundtrip"]) < 5e-6
+    assert rel_err(rt, g["y"]) < 1e-4  # invertibility claim (feature_extractors.py:21-22)
+    a = O.istft(O.decompress(g["Z"]), 3000)
+    b = O.istft(O.decompress(g["Z"]), 3072)
+    assert a.shape == (2, 1, 3000) and b.shape == (2, 1, 3072)
+    assert rel_err(a, g["istft_len3000"]) < 5e-6
+    assert rel_err(b, g["istft_len3072"]) < 5e-6
+
+
+def test_pad_and_normalize():
+    g = load_golden("g3_pad_norm.npz")
+    yn, nf = O.normalize_noisy(g["y"])
+    assert np.array_equal(nf, g["normfac"])       # silent clip -> normfac 1 (other.py:77)
+    assert nf[1, 0, 0] == 1.0
+    assert np.array_equal(yn, g["y_norm"])
+    P, T = O.pad_spec(g["spec"])
+    assert P.shape[-1] == int(g["padded_T"]) == 64 and T == int(g["orig_T"]) == 13
+    assert np.array_equal(P[..., :T], g["spec"]) and not P[..., T:].any()
+    assert [O.padded_frames(t) for t in (1, 64, 65, 126, 251, 501)] == [64, 64, 128, 128, 256, 512]
+
+
+def test_upfirdn2d():
+    g = load_golden("g4_upfirdn2d.npz")
+    for nm in ("a", "b"):
+        x = g["x" + nm]
+        assert rel_err(O.upsample_2d(x), g["up_" + nm]) < 1e-6
+        assert rel_err(O.downsample_2d(x), g["down_" + nm]) < 1e-6
+        # polyphase closed forms (what the HIP kernels implement)
+        assert rel_err(O.fir_up2_polyphase(x), g["up_" + nm]) < 1e-6
+        assert rel_err(O.fir_down2_polyphase(x), g["down_" + nm]) < 1e-6
+    # generic call: up (2,3) down (1,2) pad x(1,2) y(0,1): oracle's upfirdn2d is symmetric in x/y,
+    # so emulate the asymmetric reference call with two separable passes is not possible ->
+    # check the symmetric special case against a direct evaluation instead.
+    k = O.setup_fir_kernel((1, 3, 3, 1))
+    x = g["xa"]
+    ref = O.upfirdn2d(x, k * 4, up=2, pad=(2, 1))
+    assert rel_err(ref, g["up_a"]) < 1e-6
+
+
+def test_groupnorm_silu():
+    g = load_golden("g5_groupnorm_silu.npz")
+    for C in (64, 256, 320, 384, 512):
+        o = O.silu(O.group_norm(g[f"x{C}"], O.gn_groups(C), g[f"gamma{C}"], g[f"beta{C}"]))
+        assert rel_err(o, g[f"out{C}"]) < 2e-6, C
+    assert [O.gn_groups(c) for c in (64, 128, 256, 320, 384, 512)] == [16, 32, 32, 32, 32, 32]
+
+
+@pytest.mark.parametrize("name", list(O.RESBLOCK_CASES))
+def test_resblock(name):
+    g = load_golden("g6_resblock.npz")
+    seed, ci, co, up, down = O.RESBLOCK_CASES[name]
+    p = O.random_resblock_params(seed, ci, co, has_conv2=(ci != co or up or down))
+    net = O.NCSNppOracle({f"all_modules.0.{k}": v for k, v in p.items()}, prefix="")
+    o = net.resblock(0, dict(cin=ci, cout=co, up=up, down=down), g[f"{name}_x"], g[f"{name}_temb"])
+    assert o.shape == g[f"{name}_out"].shape
+    assert rel_err(o, g[f"{name}_out"]) < 5e-6
+
+
+def test_time_embedding_and_ncsnpp_nf8():
+    g = load_golden("g8_ncsnpp_nf8.npz")
+    net = O.NCSNppOracle(O.random_state_dict(seed=int(g["seed"]), nf=8), nf=8)
+    assert rel_err(net.time_embedding(g["t"]), g["temb"]) < 2e-5
+    o = net.forward(g["x"], g["y"], np.array([0.25], np.float32))
+    assert o.shape == (2, 1, 768, 64)
+    assert rel_err(o, g["out_t025"]) < 2e-5
+    o2 = net.forward(g["x"], g["y"], np.array([0.1, 0.9], np.float32))
+    assert rel_err(o2, g["out_t01_09"]) < 2e-5
+
+
+def test_ncsnpp_full_width():
+    g = load_golden("g10_ncsnpp_nf64.npz")
+    net = O.NCSNppOracle(O.random_state_dict(seed=int(g["seed"]), nf=64), nf=64)
+    o = net.forward(g["x"], g["y"], np.array([0.5], np.float32))
+    assert rel_err(o, g["out"]) < 5e-5
+
+
+def test_state_dict_manifest():
+    with open(os.path.join(GOLDEN, "state_dict_manifest.json")) as f:
+        ref = json.load(f)
+    ours = {k: list(v) for k, v in O.state_dict_manifest(nf=64).items()}
+    bb = {k: v for k, v in ref.items() if k.startswith("backbone.")}
+    assert ours == bb
+    assert ref["feature_extractor.complex_stft.window"] == [1534]
+    assert ref["sigma_y"] == [768, 1] and ref["sigma_x"] == []
+    n_params = sum(int(np.prod(v)) for v in bb.values())
+    assert n_params == 23703704
+
+
+def test_sigma_y_curve():
+    g = load_golden("g12_sigma_y.npz")
+    for nm in ("75m", "25s"):
+        c = O.sigma_y_curve(g[nm + "_raw"], 1.0, 3.0)
+        assert c.shape == (768, 1) and c.dtype == np.float64
+        assert np.allclose(c, g[nm], rtol=1e-12, atol=0)
+
+
+def test_t_span_matches_torch_linspace():
+    import torch
+    for N in (1, 2, 3, 5, 6, 7, 25, 32, 50):
+        assert np.array_equal(O.t_span_linspace(N), torch.linspace(0, 1, N + 1).numpy()), N
+
+
+@pytest.mark.parametrize("solver,N", [("euler", 6), ("midpoint", 3), ("heun2", 3), ("heun2_eulerlast", 3)])
+def test_enhance_nf8(solver, N):
+    g = load_golden("g9_enhance_nf8.npz")
+    net = O.NCSNppOracle(O.random_state_dict(seed=int(g["seed"]), nf=8), nf=8)
+    x = O.enhance(net, g["y"], g["noise"], g["sigma_y"], N=N, solver=solver)
+    ref = g[f"{solver}_N{N}"]
+    assert x.shape == ref.shape == (2, 1, 24000)
+    assert rel_err(x, ref) < 1e-4
+    assert O.solver_nfe(solver, N) == {"euler": 6, "midpoint": 6, "heun2": 6, "heun2_eulerlast": 5}[solver]
+
+
+def test_enhance_traj_and_1d():
+    g = load_golden("g9_enhance_nf8.npz")
+    net = O.NCSNppOracle(O.random_state_dict(seed=int(g["seed"]), nf=8), nf=8)
+    traj, waves = O.enhance(net, g["y"], g["noise"], g["sigma_y"], N=2, solver="euler", return_traj=True)
+    norms = np.array([np.sqrt((np.abs(X.astype(np.complex128)) ** 2).sum()) for X in traj])
+    assert np.allclose(norms, g["traj_feat_norms"], rtol=1e-4)
+    assert rel_err(waves[-1], g["traj_last_wave"]) < 1e-4
+    x1 = O.enhance(net, g["y"][0:1], g["noise"][0:1], g["sigma_y"], N=2, solver="euler")
+    assert rel_err(x1[0, 0], g["euler_N2_1d"]) < 1e-4
