@@ -1,0 +1,116 @@
+"""ctypes binding of libflowdec_hip.so (the C ABI in include/flowdec_hip.h).
+
+The HIP library is the ONLY compute path of this package: if it is missing, importing the ops
+raises -- there is no CPU / eager-PyTorch fallback.  PyTorch is used for device memory, streams
+and torch.distributed only.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflowdec_hip.so")
+
+FD_F32, FD_BF16 = 0, 1
+SOLVERS = {"euler": 0, "midpoint": 1, "heun2": 2, "heun2_eulerlast": 3}
+
+c_void_p, c_int, c_float, c_ll, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
+
+
+class FdModelConfig(C.Structure):
+    _fields_ = [("nf", c_int), ("ch_mult", c_int * 8), ("num_levels", c_int), ("num_res_blocks", c_int),
+                ("n_fft", c_int), ("hop", c_int), ("alpha", c_float), ("beta", c_float), ("act_dtype", c_int)]
+
+
+# name -> (restype, [argtypes]); must list every function declared in include/flowdec_hip.h
+_P = c_void_p
+SIGNATURES = {
+    "fd_last_error": (C.c_char_p, []),
+    "fd_version": (c_int, []),
+    "fd_device_info": (c_int, [C.POINTER(c_int)]),
+    "fd_upfirdn2d": (c_int, [_P, _P, _P] + [c_int] * 15 + [_P]),
+    "fd_upfirdn2d_out_size": (c_int, [c_int] * 6),
+    "fd_fused_bias_act": (c_int, [_P, _P, _P, c_ll, c_int, c_int, c_int, c_float, c_float, _P]),
+    "fd_fir_resample": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "fd_channel_sums": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "fd_gn_finalize": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_ll, c_float, _P]),
+    "fd_conv_packed_bytes": (c_ll, [c_int] * 5),
+    "fd_conv_pack_weights": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "fd_conv2d": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, _P, c_float, _P, c_int, c_int, c_int, c_int, c_int,
+                          c_int, c_int, _P]),
+    "fd_time_embedding": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, _P]),
+    "fd_temb_bias": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
+    "fd_stft_workspace_bytes": (c_size_t, [c_int] * 4),
+    "fd_stft_compress": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, _P, _P, c_int, _P, c_size_t, _P]),
+    "fd_decompress_istft": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, c_int, _P, c_size_t, _P]),
+    "fd_num_frames": (c_int, [c_int, c_int]),
+    "fd_padded_frames": (c_int, [c_int]),
+    "fd_model_create": (c_int, [C.POINTER(FdModelConfig), C.POINTER(_P)]),
+    "fd_model_destroy": (None, [_P]),
+    "fd_model_num_params": (c_int, [_P]),
+    "fd_model_param_info": (c_int, [_P, c_int, C.POINTER(C.c_char_p), C.POINTER(c_int), C.POINTER(c_int * 4)]),
+    "fd_model_set_param": (c_int, [_P, C.c_char_p, _P, c_ll]),
+    "fd_model_set_sigma_y": (c_int, [_P, _P, c_int]),
+    "fd_model_finalize": (c_int, [_P, _P]),
+    "fd_model_workspace_bytes": (c_size_t, [_P, c_int, c_int]),
+    "fd_ncsnpp_forward": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, _P, c_size_t, _P]),
+    "fd_ode_solve": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
+    "fd_enhance_workspace_bytes": (c_size_t, [_P, c_int, c_int]),
+    "fd_enhance": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
+    "fd_profile_enable": (c_int, [_P, c_int]),
+    "fd_profile_read": (c_int, [_P, C.POINTER(C.c_double), C.POINTER(c_ll), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libflowdec_hip.so; raises if it has not been built (`python -m flowdec_amd.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is the only compute path of flowdec_amd. "
+            "Build it with `python -m flowdec_amd.build` (needs hipcc, targets gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    """Non-zero return -> RuntimeError, like the reference's TORCH_CHECK (op/upfirdn2d.cpp:34-42)."""
+    if rc != 0:
+        msg = load().fd_last_error()
+        raise RuntimeError("flowdec_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device (or host) pointer of a tensor, None -> NULL."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    """Raw hipStream_t of torch's current stream (the launch stream of every op)."""
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_id(dt):
+    if dt == torch.float32:
+        return FD_F32
+    if dt == torch.bfloat16:
+        return FD_BF16
+    raise RuntimeError(f"flowdec_amd: unsupported activation dtype {dt} (float32 / bfloat16 only)")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("flowdec_amd: tensor must live on the GPU (HIP is the only compute path)")

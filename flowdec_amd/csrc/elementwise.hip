@@ -1,0 +1,585 @@
+// elementwise.hip -- the HBM-bound kernels of the NCSN++ vector field (NHWC activations):
+// GroupNorm statistics, FIR x2 resampling (+ fused GroupNorm/SiLU), generic upfirdn2d,
+// fused bias+act, time embedding, the 4-channel convs at the edges of the U-Net, and the
+// ODE state updates fused with the final 1x1 output layer.
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+// =====================================================================================================
+// GroupNorm statistics: per-(b, c) sum and sum of squares (nn.GroupNorm, layerspp.py:229,241)
+// =====================================================================================================
+// grid (blocks_per_image, B), 256 threads = (C/8 channel vectors) x (2048/C pixel lanes).
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sums_kernel(const T* __restrict__ x, double* __restrict__ sums, int HW,
+                                                           int C, int px_per_block) {
+  const int cv = C >> 3;            // channel vectors (power of two, <= 32)
+  const int lanes = 256 / cv;       // pixel lanes
+  const int t = threadIdx.x;
+  const int c8 = (t % cv) * 8, pl = t / cv;
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * px_per_block;
+  const int p1 = min(p0 + px_per_block, HW);
+  float s[8], ss[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = ss[i] = 0.f;
+  const T* base = x + (size_t)b * HW * C + c8;
+  for (int p = p0 + pl; p < p1; p += lanes) {
+    float v[8];
+    fd_load_vec<T, 8>(base + (size_t)p * C, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] += v[i]; ss[i] = fmaf(v[i], v[i], ss[i]); }
+  }
+  __shared__ float red[256][17];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { red[t][i] = s[i]; red[t][8 + i] = ss[i]; }
+  __syncthreads();
+  // thread j < 2*C... reduce over pixel lanes in double: C*2 outputs, C <= 256 -> up to 512 outputs, 2 per thread
+  for (int o = t; o < 2 * C; o += 256) {
+    const int c = o >> 1, which = o & 1;
+    const int tv = c >> 3, e = (c & 7) + 8 * which;
+    double acc = 0.0;
+    for (int l = 0; l < lanes; ++l) acc += (double)red[l * cv + tv][e];
+    atomicAdd(&sums[((size_t)b * C + c) * 2 + which], acc);
+  }
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ s0, int C0, const double* __restrict__ s1, int C1,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ affine, int B, int groups, double inv_n, float eps) {
+  const int C = C0 + C1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  const int cpg = C / groups;
+  const int g0 = (c / cpg) * cpg;
+  double s = 0.0, ss = 0.0;
+  for (int k = g0; k < g0 + cpg; ++k) {
+    const double* p = (k < C0) ? s0 + ((size_t)b * C0 + k) * 2 : s1 + ((size_t)b * C1 + (k - C0)) * 2;
+    s += p[0]; ss += p[1];
+  }
+  const double mean = s * inv_n;
+  double var = ss * inv_n - mean * mean;
+  var = var < 0.0 ? 0.0 : var;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  const float a = (float)rstd * gamma[c];
+  affine[2 * (size_t)i] = a;
+  affine[2 * (size_t)i + 1] = beta[c] - (float)(mean * rstd) * gamma[c];
+}
+
+// =====================================================================================================
+// FIR [1,3,3,1] x2 resampling, polyphase form (up_or_down_sampling.py:220-282 via op/upfirdn2d.py)
+//   down: out[n]   = (x[2n-1] + 3 x[2n] + 3 x[2n+1] + x[2n+2]) / 8     per axis, zeros outside
+//   up  : out[2i]  = (x[i-1] + 3 x[i]) / 4 ; out[2i+1] = (3 x[i] + x[i+1]) / 4
+// One thread = one VEC-channel vector of one pixel (output pixel for down, input pixel for up).
+// With `affine`, the second output is the resample of silu(a*x+d) computed from the same loads.
+// =====================================================================================================
+template <typename T, int VEC, bool ACT>
+__global__ __launch_bounds__(256) void fir_down_kernel(const T* __restrict__ x, const float* __restrict__ affine,
+                                                       T* __restrict__ out_raw, T* __restrict__ out_act, int B, int H,
+                                                       int W, int C) {
+  const int cvn = C / VEC;
+  const int OH = H >> 1, OW = W >> 1;
+  const long long total = (long long)B * OH * OW * cvn;
+  const long long idx = blockIdx.x * 256ll + threadIdx.x;
+  if (idx >= total) return;
+  const int cv = (int)(idx % cvn);
+  long long r = idx / cvn;
+  const int ox = (int)(r % OW); r /= OW;
+  const int oy = (int)(r % OH);
+  const int b = (int)(r / OH);
+  const int c = cv * VEC;
+  float a[VEC], d[VEC];
+  if (ACT) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { a[i] = affine[((size_t)b * C + c + i) * 2]; d[i] = affine[((size_t)b * C + c + i) * 2 + 1]; }
+  }
+  float accr[VEC], acca[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) accr[i] = acca[i] = 0.f;
+  const float wt[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky) {
+    const int iy = 2 * oy - 1 + ky;
+    if (iy < 0 || iy >= H) continue;
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) {
+      const int ix = 2 * ox - 1 + kx;
+      if (ix < 0 || ix >= W) continue;
+      float v[VEC];
+      fd_load_vec<T, VEC>(x + (((size_t)b * H + iy) * W + ix) * C + c, v);
+      const float w = wt[ky] * wt[kx];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        accr[i] = fmaf(w, v[i], accr[i]);
+        if (ACT) acca[i] = fmaf(w, fd_silu(fmaf(v[i], a[i], d[i])), acca[i]);
+      }
+    }
+  }
+  const size_t o = (((size_t)b * OH + oy) * OW + ox) * C + c;
+  if (out_raw) fd_store_vec<T, VEC>(out_raw + o, accr);
+  if (ACT && out_act) fd_store_vec<T, VEC>(out_act + o, acca);
+}
+
+template <typename T, int VEC, bool ACT>
+__global__ __launch_bounds__(256) void fir_up_kernel(const T* __restrict__ x, const float* __restrict__ affine,
+                                                     T* __restrict__ out_raw, T* __restrict__ out_act, int B, int H,
+                                                     int W, int C) {
+  const int cvn = C / VEC;
+  const long long total = (long long)B * H * W * cvn;
+  const long long idx = blockIdx.x * 256ll + threadIdx.x;
+  if (idx >= total) return;
+  const int cv = (int)(idx % cvn);
+  long long r = idx / cvn;
+  const int ix = (int)(r % W); r /= W;
+  const int iy = (int)(r % H);
+  const int b = (int)(r / H);
+  const int c = cv * VEC;
+  float a[VEC], d[VEC];
+  if (ACT) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { a[i] = affine[((size_t)b * C + c + i) * 2]; d[i] = affine[((size_t)b * C + c + i) * 2 + 1]; }
+  }
+  // 3x3 neighbourhood (zeros outside)
+  float nr[3][3][VEC], na[3][3][VEC];
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int yy = iy + dy - 1, xx = ix + dx - 1;
+      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      if (ok) {
+        fd_load_vec<T, VEC>(x + (((size_t)b * H + yy) * W + xx) * C + c, nr[dy][dx]);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) na[dy][dx][i] = ACT ? fd_silu(fmaf(nr[dy][dx][i], a[i], d[i])) : 0.f;
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { nr[dy][dx][i] = 0.f; na[dy][dx][i] = 0.f; }
+      }
+    }
+  const int OW = 2 * W, OH = 2 * H;
+  // output (2iy+py, 2ix+px): rows {iy-1+py (1/4 if py==0 else 3/4 on centre...)}
+#pragma unroll
+  for (int py = 0; py < 2; ++py)
+#pragma unroll
+    for (int px = 0; px < 2; ++px) {
+      // py == 0: 0.25*row(-1) + 0.75*row(0); py == 1: 0.75*row(0) + 0.25*row(+1)
+      const int y0 = py == 0 ? 0 : 1, y1 = y0 + 1;
+      const float wy0 = py == 0 ? 0.25f : 0.75f, wy1 = py == 0 ? 0.75f : 0.25f;
+      const int x0 = px == 0 ? 0 : 1, x1 = x0 + 1;
+      const float wx0 = px == 0 ? 0.25f : 0.75f, wx1 = px == 0 ? 0.75f : 0.25f;
+      float vr[VEC], va[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        vr[i] = wy0 * (wx0 * nr[y0][x0][i] + wx1 * nr[y0][x1][i]) + wy1 * (wx0 * nr[y1][x0][i] + wx1 * nr[y1][x1][i]);
+        if (ACT) va[i] = wy0 * (wx0 * na[y0][x0][i] + wx1 * na[y0][x1][i]) + wy1 * (wx0 * na[y1][x0][i] + wx1 * na[y1][x1][i]);
+      }
+      const size_t o = (((size_t)b * OH + 2 * iy + py) * OW + 2 * ix + px) * C + c;
+      if (out_raw) fd_store_vec<T, VEC>(out_raw + o, vr);
+      if (ACT && out_act) fd_store_vec<T, VEC>(out_act + o, va);
+    }
+}
+
+// =====================================================================================================
+// Generic upfirdn2d (op/upfirdn2d.py:183-224 semantics; CUDA twin upfirdn2d_kernel.cu:60-218)
+// =====================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void upfirdn2d_kernel(const T* __restrict__ in, const float* __restrict__ kernel,
+                                                        T* __restrict__ out, int major, int in_h, int in_w, int minor,
+                                                        int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                                                        int pad_x0, int pad_y0, int out_h, int out_w) {
+  const long long total = (long long)major * out_h * out_w * minor;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int mi = (int)(idx % minor);
+    long long r = idx / minor;
+    const int ox = (int)(r % out_w); r /= out_w;
+    const int oy = (int)(r % out_h);
+    const int mj = (int)(r / out_h);
+    float acc = 0.f;
+    // out[oy,ox] = sum_{i,j} kernel[kh-1-i][kw-1-j] * U[oy*down_y + i - pad_y0][ox*down_x + j - pad_x0],
+    // U = zero-inserted input (U[u][v] = in[u/up_y][v/up_x] when both divisible and in range)
+    for (int i = 0; i < kh; ++i) {
+      const int u = oy * down_y + i - pad_y0;
+      if (u < 0 || u % up_y != 0) continue;
+      const int iy = u / up_y;
+      if (iy >= in_h) continue;
+      for (int j = 0; j < kw; ++j) {
+        const int v = ox * down_x + j - pad_x0;
+        if (v < 0 || v % up_x != 0) continue;
+        const int ix = v / up_x;
+        if (ix >= in_w) continue;
+        acc = fmaf(kernel[(kh - 1 - i) * kw + (kw - 1 - j)], Elem<T>::ld(in + (((size_t)mj * in_h + iy) * in_w + ix) * minor + mi), acc);
+      }
+    }
+    Elem<T>::st(out + idx, acc);
+  }
+}
+
+// fused_bias_act_kernel.cu:30-61, grad == 0
+__global__ void fused_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ out,
+                                      long long n, int step_b, int size_b, int act, float alpha, float scale) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float v = x[i];
+    if (bias) v += bias[(i / step_b) % size_b];
+    if (act == 3) v = v > 0.f ? v : v * alpha;
+    out[i] = v * scale;
+  }
+}
+
+// =====================================================================================================
+// Time embedding (ncsnpp.py:263-274, layerspp.py:42-51) -- one block per t row.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void time_embedding_kernel(const float* __restrict__ t, float t_imm, const float* __restrict__ W,
+                                                             int nf, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                             const float* __restrict__ w2, const float* __restrict__ b2,
+                                                             float* __restrict__ temb) {
+  extern __shared__ float sm[];
+  float* emb = sm;            // [2nf]
+  float* hid = sm + 2 * nf;   // [4nf]
+  const int r = blockIdx.x;
+  const float tv = t ? t[r] : t_imm;
+  for (int j = threadIdx.x; j < nf; j += blockDim.x) {
+    const float xp = ((tv * W[j]) * 2.0f) * 3.14159274101257324f;  // x[:,None]*W[None,:]*2*np.pi in float32
+    emb[j] = sinf(xp);
+    emb[nf + j] = cosf(xp);
+  }
+  __syncthreads();
+  const int E = 2 * nf, D = 4 * nf;
+  for (int o = threadIdx.x; o < D; o += blockDim.x) {
+    float acc = b1[o];
+    for (int k = 0; k < E; ++k) acc = fmaf(w1[(size_t)o * E + k], emb[k], acc);
+    hid[o] = fd_silu(acc);
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < D; o += blockDim.x) {
+    float acc = b2[o];
+    for (int k = 0; k < D; ++k) acc = fmaf(w2[(size_t)o * D + k], hid[k], acc);
+    temb[(size_t)r * D + o] = acc;
+  }
+}
+
+// out[r][o] = cb[o] + db[o] + sum_k dw[o][k] * silu(temb[r][k]); one job per ResnetBlock (layerspp.py:272-273)
+__global__ __launch_bounds__(256) void temb_bias_kernel(const fd_temb_job* __restrict__ jobs, const float* __restrict__ temb,
+                                                        int temb_dim) {
+  extern __shared__ float st[];  // silu(temb[r])
+  const fd_temb_job job = jobs[blockIdx.x];
+  const int r = blockIdx.y;
+  for (int k = threadIdx.x; k < temb_dim; k += blockDim.x) st[k] = fd_silu(temb[(size_t)r * temb_dim + k]);
+  __syncthreads();
+  for (int o = threadIdx.x; o < job.Cout; o += blockDim.x) {
+    float acc = job.dense_b[o];
+    for (int k = 0; k < temb_dim; ++k) acc = fmaf(job.dense_w[(size_t)o * temb_dim + k], st[k], acc);
+    job.out[(size_t)r * job.Cout + o] = acc + job.conv_b[o];
+  }
+}
+
+__global__ __launch_bounds__(256) void temb_bias_single_kernel(fd_temb_job job, const float* __restrict__ temb, int temb_dim) {
+  extern __shared__ float st[];
+  const int r = blockIdx.x;
+  for (int k = threadIdx.x; k < temb_dim; k += blockDim.x) st[k] = fd_silu(temb[(size_t)r * temb_dim + k]);
+  __syncthreads();
+  for (int o = threadIdx.x; o < job.Cout; o += blockDim.x) {
+    float acc = job.dense_b[o];
+    for (int k = 0; k < temb_dim; ++k) acc = fmaf(job.dense_w[(size_t)o * temb_dim + k], st[k], acc);
+    job.out[(size_t)r * job.Cout + o] = acc + (job.conv_b ? job.conv_b[o] : 0.f);
+  }
+}
+
+// =====================================================================================================
+// Edge-of-network kernels on the 4-channel tensors
+// =====================================================================================================
+// cat(x.re, x.im, y.re, y.im) (ncsnpp.py:401-404) -> NHWC [B][F][T][4]
+template <typename T>
+__global__ void pack_input_kernel(const float2* __restrict__ x, const float2* __restrict__ y, T* __restrict__ out, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float2 a = x[i], b = y[i];
+    const float v[4] = {a.x, a.y, b.x, b.y};
+    fd_store_vec<T, 4>(out + 4 * i, v);
+  }
+}
+
+// 3x3 conv 4 -> Cout (all_modules.3).  Weights [Cout][4][3][3] f32 staged in LDS as [36][Cout].
+// One thread = one pixel x 8 couts.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_in_kernel(const T* __restrict__ in4, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      T* __restrict__ out, int B, int H, int W, int Cout) {
+  extern __shared__ float wl[];  // [36][Cout]
+  for (int i = threadIdx.x; i < 36 * Cout; i += 256) {
+    const int co = i % Cout, k = i / Cout;  // k = ci*9 + tap in the source -> reorder to tap*4+ci
+    const int tap = k / 4, ci = k % 4;
+    wl[i] = w[((size_t)co * 4 + ci) * 9 + tap];
+  }
+  __syncthreads();
+  const int tpp = Cout >> 3;  // threads per pixel
+  const long long total = (long long)B * H * W * tpp;
+  const long long idx = blockIdx.x * 256ll + threadIdx.x;
+  if (idx >= total) return;
+  const int cg = (int)(idx % tpp);
+  long long r = idx / tpp;
+  const int xw = (int)(r % W); r /= W;
+  const int yh = (int)(r % H);
+  const int b = (int)(r / H);
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = bias[cg * 8 + i];
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int yy = yh + dy - 1;
+    if (yy < 0 || yy >= H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int xx = xw + dx - 1;
+      if (xx < 0 || xx >= W) continue;
+      float v[4];
+      fd_load_vec<T, 4>(in4 + (((size_t)b * H + yy) * W + xx) * 4, v);
+      const float* wp = wl + ((dy * 3 + dx) * 4) * Cout + cg * 8;
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fmaf(wp[ci * Cout + i], v[ci], acc[i]);
+    }
+  }
+  fd_store_vec<T, 8>(out + (((size_t)b * H + yh) * W + xw) * Cout + cg * 8, acc);
+}
+
+// Combine 'sum' (layerspp.py:54-69): out = conv1x1(p4) + bias + h.  One thread = pixel x 8 couts.
+template <typename T>
+__global__ __launch_bounds__(256) void combine_kernel(const T* __restrict__ p4, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      const T* __restrict__ h, T* __restrict__ out, long long npix, int Cout) {
+  const int tpp = Cout >> 3;
+  const long long idx = blockIdx.x * 256ll + threadIdx.x;
+  if (idx >= npix * tpp) return;
+  const int cg = (int)(idx % tpp);
+  const long long pix = idx / tpp;
+  float v[4], hv[8], o[8];
+  fd_load_vec<T, 4>(p4 + pix * 4, v);
+  fd_load_vec<T, 8>(h + pix * Cout + cg * 8, hv);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float* wp = w + (size_t)(cg * 8 + i) * 4;
+    float acc = bias[cg * 8 + i];
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) acc = fmaf(wp[ci], v[ci], acc);
+    o[i] = acc + hv[i];
+  }
+  fd_store_vec<T, 8>(out + pix * Cout + cg * 8, o);
+}
+
+// output_layer (1x1, 4 -> 2, no bias; ncsnpp.py:100,398) + view_as_complex (:407-411) fused with the
+// solver's state update:  dst = base + coef * (v + k_old);  optionally k_save = v.
+template <typename T>
+__global__ void output_update_kernel(const T* __restrict__ pyr, const float* __restrict__ wo, const float2* __restrict__ base,
+                                     const float2* __restrict__ kold, float coef, float2* __restrict__ dst,
+                                     float2* __restrict__ ksave, long long n) {
+  const float w0 = wo[0], w1 = wo[1], w2 = wo[2], w3 = wo[3], w4 = wo[4], w5 = wo[5], w6 = wo[6], w7 = wo[7];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float p[4];
+    fd_load_vec<T, 4>(pyr + 4 * i, p);
+    float2 v;
+    v.x = fmaf(w3, p[3], fmaf(w2, p[2], fmaf(w1, p[1], w0 * p[0])));
+    v.y = fmaf(w7, p[3], fmaf(w6, p[2], fmaf(w5, p[1], w4 * p[0])));
+    if (ksave) ksave[i] = v;
+    float2 s = v;
+    if (kold) { const float2 k = kold[i]; s.x += k.x; s.y += k.y; }
+    float2 o = {coef * s.x, coef * s.y};
+    if (base) { const float2 bb = base[i]; o.x += bb.x; o.y += bb.y; }
+    dst[i] = o;
+  }
+}
+
+// x0 = Y + sigma_fac * (sigma_y[f] * noise).type(complex64)   (model.py:512, :530-536); sigma is float64
+__global__ void init_state_kernel(const float2* __restrict__ Y, const float2* __restrict__ noise, const double* __restrict__ sigma,
+                                  int sigma_n, float sigma_fac, float2* __restrict__ x0, int F, int T, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int f = (int)((i / T) % F);
+    const double s = sigma[sigma_n == 1 ? 0 : f];
+    const float2 nz = noise[i], yv = Y[i];
+    const float nx = (float)(s * (double)nz.x), ny = (float)(s * (double)nz.y);
+    float2 o = {yv.x + sigma_fac * nx, yv.y + sigma_fac * ny};
+    x0[i] = o;
+  }
+}
+
+inline int grid_for(long long n, int per_block = 256, int cap = 1 << 20) {
+  long long g = (n + per_block - 1) / per_block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// C ABI + internal launchers
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int fd_channel_sums(const void* x, double* sums, int B, int H, int W, int C, int dtype, void* stream) {
+  FD_REQUIRE(x && sums, "fd_channel_sums: null pointer");
+  FD_REQUIRE(C >= 8 && C <= 256 && (C & (C - 1)) == 0, "fd_channel_sums: C must be a power of two in [8,256] (got %d)", C);
+  FD_REQUIRE(dtype == FD_F32 || dtype == FD_BF16, "fd_channel_sums: bad dtype");
+  hipStream_t st = fd_stream(stream);
+  FD_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)B * C, st));
+  const int HW = H * W;
+  const int ppb = 2048;  // pixels per block
+  dim3 grid(fd_cdiv(HW, ppb), B);
+  if (dtype == FD_BF16)
+    hipLaunchKernelGGL(channel_sums_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, sums, HW, C, ppb);
+  else
+    hipLaunchKernelGGL(channel_sums_kernel<float>, grid, dim3(256), 0, st, (const float*)x, sums, HW, C, ppb);
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}
+
+extern "C" int fd_gn_finalize(const double* sums0, int C0, const double* sums1, int C1, const float* gamma,
+                              const float* beta, float* affine, int B, int groups, long long hw, float eps, void* stream) {
+  FD_REQUIRE(sums0 && gamma && beta && affine, "fd_gn_finalize: null pointer");
+  FD_REQUIRE((C1 == 0) == (sums1 == nullptr), "fd_gn_finalize: sums1 / C1 mismatch");
+  const int C = C0 + C1;
+  FD_REQUIRE(groups > 0 && C % groups == 0, "fd_gn_finalize: C=%d not divisible by groups=%d", C, groups);
+  const double inv_n = 1.0 / ((double)hw * (C / groups));
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(fd_cdiv((long long)B * C, 256)), dim3(256), 0, fd_stream(stream), sums0, C0,
+                     sums1, C1, gamma, beta, affine, B, groups, inv_n, eps);
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}
+
+template <typename T, int VEC>
+static int launch_fir(const void* x, const float* affine, void* out_raw, void* out_act, int B, int H, int W, int C,
+                      int direction, hipStream_t st) {
+  const long long n = (long long)B * (direction > 0 ? H * W : (H / 2) * (W / 2)) * (C / VEC);
+  dim3 grid(fd_cdiv(n, 256));
+  if (direction > 0) {
+    if (affine) hipLaunchKernelGGL((fir_up_kernel<T, VEC, true>), grid, dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C);
+    else hipLaunchKernelGGL((fir_up_kernel<T, VEC, false>), grid, dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C);
+  } else {
+    if (affine) hipLaunchKernelGGL((fir_down_kernel<T, VEC, true>), grid, dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C);
+    else hipLaunchKernelGGL((fir_down_kernel<T, VEC, false>), grid, dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C);
+  }
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}
+
+extern "C" int fd_fir_resample(const void* x, const float* affine, void* out_raw, void* out_act, int B, int H, int W,
+                               int C, int direction, int dtype, void* stream) {
+  FD_REQUIRE(x && (out_raw || out_act), "fd_fir_resample: null pointer");
+  FD_REQUIRE(direction == 1 || direction == -1, "fd_fir_resample: direction must be +1 (up) or -1 (down)");
+  FD_REQUIRE(C % 4 == 0, "fd_fir_resample: C must be a multiple of 4");
+  FD_REQUIRE(direction > 0 || (H % 2 == 0 && W % 2 == 0), "fd_fir_resample: down needs even H, W");
+  FD_REQUIRE(out_act == nullptr || affine != nullptr, "fd_fir_resample: out_act needs affine");
+  hipStream_t st = fd_stream(stream);
+  if (dtype == FD_BF16) {
+    if (C % 8 == 0) return launch_fir<bf16, 8>(x, affine, out_raw, out_act, B, H, W, C, direction, st);
+    return launch_fir<bf16, 4>(x, affine, out_raw, out_act, B, H, W, C, direction, st);
+  } else if (dtype == FD_F32) {
+    return launch_fir<float, 4>(x, affine, out_raw, out_act, B, H, W, C, direction, st);
+  }
+  return fd_set_error(FD_EINVAL, "fd_fir_resample: bad dtype %d", dtype);
+}
+
+extern "C" int fd_upfirdn2d_out_size(int in_size, int up, int down, int pad0, int pad1, int ksize) {
+  return (in_size * up + pad0 + pad1 - ksize + down) / down;  // upfirdn2d_kernel.cu:248-251
+}
+
+extern "C" int fd_upfirdn2d(const void* input, const float* kernel, void* out, int major, int in_h, int in_w, int minor,
+                            int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
+                            int pad_y0, int pad_y1, int dtype, void* stream) {
+  FD_REQUIRE(input && kernel && out, "fd_upfirdn2d: null pointer");
+  FD_REQUIRE(up_x >= 1 && up_y >= 1 && down_x >= 1 && down_y >= 1, "fd_upfirdn2d: up/down factors must be >= 1");
+  FD_REQUIRE(major > 0 && in_h > 0 && in_w > 0 && minor > 0 && kernel_h > 0 && kernel_w > 0, "fd_upfirdn2d: bad shape");
+  const int out_h = fd_upfirdn2d_out_size(in_h, up_y, down_y, pad_y0, pad_y1, kernel_h);
+  const int out_w = fd_upfirdn2d_out_size(in_w, up_x, down_x, pad_x0, pad_x1, kernel_w);
+  FD_REQUIRE(out_h > 0 && out_w > 0, "fd_upfirdn2d: empty output (%d x %d)", out_h, out_w);
+  const long long n = (long long)major * out_h * out_w * minor;
+  dim3 grid(grid_for(n, 256, 65536));
+  if (dtype == FD_F32)
+    hipLaunchKernelGGL(upfirdn2d_kernel<float>, grid, dim3(256), 0, fd_stream(stream), (const float*)input, kernel, (float*)out, major,
+                       in_h, in_w, minor, kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_y0, out_h, out_w);
+  else if (dtype == FD_BF16)
+    hipLaunchKernelGGL(upfirdn2d_kernel<bf16>, grid, dim3(256), 0, fd_stream(stream), (const bf16*)input, kernel, (bf16*)out, major,
+                       in_h, in_w, minor, kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_y0, out_h, out_w);
+  else
+    return fd_set_error(FD_EINVAL, "fd_upfirdn2d: bad dtype %d", dtype);
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}
+
+extern "C" int fd_fused_bias_act(const float* x, const float* bias, float* out, long long n, int step_b, int size_b,
+                                 int act, float alpha, float scale, void* stream) {
+  FD_REQUIRE(x && out && n >= 0, "fd_fused_bias_act: bad arguments");
+  FD_REQUIRE(act == 1 || act == 3, "fd_fused_bias_act: act must be 1 (linear) or 3 (lrelu)");
+  FD_REQUIRE(bias == nullptr || (step_b > 0 && size_b > 0), "fd_fused_bias_act: bad bias geometry");
+  if (n == 0) return FD_OK;
+  hipLaunchKernelGGL(fused_bias_act_kernel, dim3(grid_for(n, 256, 65536)), dim3(256), 0, fd_stream(stream), x, bias, out, n,
+                     step_b, size_b, act, alpha, scale);
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}
+
+int fd_time_embedding_impl(const float* t, float t_imm, int nt, const float* gfp_w, int nf, const float* w1, const float* b1,
+                           const float* w2, const float* b2, float* temb, hipStream_t st) {
+  hipLaunchKernelGGL(time_embedding_kernel, dim3(nt), dim3(256), sizeof(float) * 6 * nf, st, t, t_imm, gfp_w, nf, w1, b1, w2, b2, temb);
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}
+
+extern "C" int fd_time_embedding(const float* t, int nt, const float* gfp_w, int nf, const float* w1, const float* b1,
+                                 const float* w2, const float* b2, float* temb, void* stream) {
+  FD_REQUIRE(t && gfp_w && w1 && b1 && w2 && b2 && temb && nt > 0 && nf > 0, "fd_time_embedding: bad arguments");
+  return fd_time_embedding_impl(t, 0.f, nt, gfp_w, nf, w1, b1, w2, b2, temb, fd_stream(stream));
+}
+
+int fd_temb_bias_batched(const fd_temb_job* jobs_dev, int njobs, const float* temb, int nt, int temb_dim, hipStream_t st) {
+  hipLaunchKernelGGL(temb_bias_kernel, dim3(njobs, nt), dim3(256), sizeof(float) * temb_dim, st, jobs_dev, temb, temb_dim);
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}
+
+extern "C" int fd_temb_bias(const float* temb, int nt, int temb_dim, const float* dense_w, const float* dense_b,
+                            const float* conv_bias, int Cout, float* out, void* stream) {
+  FD_REQUIRE(temb && dense_w && dense_b && out && nt > 0 && temb_dim > 0 && Cout > 0, "fd_temb_bias: bad arguments");
+  fd_temb_job j{dense_w, dense_b, conv_bias, out, Cout};
+  hipLaunchKernelGGL(temb_bias_single_kernel, dim3(nt), dim3(256), sizeof(float) * temb_dim, fd_stream(stream), j, temb, temb_dim);
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}
+
+template <typename T>
+static int edge_launch(int which, const fd_edge_args& a, hipStream_t st) {
+  switch (which) {
+    case 0: {  // pack input
+      const long long n = (long long)a.B * a.H * a.W;
+      hipLaunchKernelGGL(pack_input_kernel<T>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, (const float2*)a.x, (const float2*)a.y, (T*)a.out, n);
+      break;
+    }
+    case 1: {  // conv_in
+      const long long n = (long long)a.B * a.H * a.W * (a.Cout / 8);
+      hipLaunchKernelGGL(conv_in_kernel<T>, dim3(fd_cdiv(n, 256)), dim3(256), sizeof(float) * 36 * a.Cout, st, (const T*)a.x, a.w, a.bias, (T*)a.out, a.B, a.H, a.W, a.Cout);
+      break;
+    }
+    case 2: {  // combine
+      const long long npix = (long long)a.B * a.H * a.W;
+      hipLaunchKernelGGL(combine_kernel<T>, dim3(fd_cdiv(npix * (a.Cout / 8), 256)), dim3(256), 0, st, (const T*)a.x, a.w, a.bias, (const T*)a.y, (T*)a.out, npix, a.Cout);
+      break;
+    }
+    case 3: {  // output + update
+      const long long n = (long long)a.B * a.H * a.W;
+      hipLaunchKernelGGL(output_update_kernel<T>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, (const T*)a.x, a.w, (const float2*)a.base, (const float2*)a.kold, a.coef, (float2*)a.out, (float2*)a.ksave, n);
+      break;
+    }
+    default: return fd_set_error(FD_EINVAL, "edge_launch: bad op");
+  }
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}
+
+int fd_edge_op(int which, const fd_edge_args& a, int dtype, hipStream_t st) {
+  if (which == 1 || which == 2) FD_REQUIRE(a.Cout % 8 == 0, "edge op: Cout must be a multiple of 8");
+  return dtype == FD_BF16 ? edge_launch<bf16>(which, a, st) : edge_launch<float>(which, a, st);
+}
+
+int fd_init_state(const float* Y, const float* noise, const double* sigma_dev, int sigma_n, float sigma_fac, float* x0, int B,
+                  int F, int T, hipStream_t st) {
+  const long long n = (long long)B * F * T;
+  hipLaunchKernelGGL(init_state_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, (const float2*)Y, (const float2*)noise, sigma_dev, sigma_n,
+                     sigma_fac, (float2*)x0, F, T, n);
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}

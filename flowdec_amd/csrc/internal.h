@@ -1,0 +1,44 @@
+// internal.h -- cross-file (non-ABI) declarations of libflowdec_hip.so.
+#pragma once
+#include "common.h"
+
+struct fd_temb_job {
+  const float* dense_w;  // [Cout][temb_dim]
+  const float* dense_b;  // [Cout]
+  const float* conv_b;   // [Cout]
+  float* out;            // [nt][Cout]
+  int Cout;
+};
+
+struct fd_edge_args {
+  const void* x = nullptr;   // main input (4-channel NHWC tensor, or complex x for pack)
+  const void* y = nullptr;   // second input (complex y for pack; h for combine)
+  const float* w = nullptr;
+  const float* bias = nullptr;
+  void* out = nullptr;
+  const void* base = nullptr;  // output_update
+  const void* kold = nullptr;
+  void* ksave = nullptr;
+  float coef = 1.f;
+  int B = 0, H = 0, W = 0, Cout = 0;
+};
+
+// elementwise.hip
+int fd_time_embedding_impl(const float* t, float t_imm, int nt, const float* gfp_w, int nf, const float* w1, const float* b1,
+                           const float* w2, const float* b2, float* temb, hipStream_t st);
+int fd_temb_bias_batched(const fd_temb_job* jobs_dev, int njobs, const float* temb, int nt, int temb_dim, hipStream_t st);
+// which: 0 = pack_input, 1 = conv_in (3x3, 4->Cout), 2 = combine (1x1 4->Cout + h), 3 = output layer + state update
+int fd_edge_op(int which, const fd_edge_args& a, int dtype, hipStream_t st);
+int fd_init_state(const float* Y, const float* noise, const double* sigma_dev, int sigma_n, float sigma_fac, float* x0, int B,
+                  int F, int T, hipStream_t st);
+// conv_mfma.hip
+int fd_conv_init_attributes();
+// stft.hip
+struct fd_stft_plan;  // device-resident DFT matrices, window envelope
+int fd_stft_plan_create(int n_fft, int hop, fd_stft_plan** out);
+void fd_stft_plan_destroy(fd_stft_plan* p);
+int fd_stft_forward(fd_stft_plan* p, const float* y, int B, int L, float alpha, float beta, int normalize, float* normfac,
+                    float* Y, int T_pad, void* ws, size_t ws_bytes, hipStream_t st);
+int fd_stft_inverse(fd_stft_plan* p, const float* X, int B, int T, int T_pad, float alpha, float beta, const float* normfac,
+                    float* y, int L, void* ws, size_t ws_bytes, hipStream_t st);
+size_t fd_stft_ws_bytes(int B, int L, int n_fft, int hop);

@@ -1,0 +1,751 @@
+// model.hip -- host side of the whole-model entry points: NCSN++ structure (ncsnpp.py:102-251),
+// parameter store + MFMA weight packing, workspace planner, the forward pass (ncsnpp.py:254-399), the
+// fixed-step ODE loop (model.py:503-515; torchdyn fixed-step semantics restated) with hipGraph capture, and
+// FlowModel.enhance (model.py:476-528).
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+enum ModKind { M_GFP, M_LINEAR, M_CONV_IN, M_RB, M_COMBINE, M_GN, M_CONV_HEAD };
+
+struct Mod {
+  ModKind kind;
+  int idx;              // index in all_modules
+  int cin = 0, cout = 0;
+  int c0 = 0, c1 = 0;   // virtual-concat split of cin (RB)
+  bool up = false, down = false, has_c2 = false;
+  // device pointers (filled by finalize)
+  void* w0 = nullptr; void* w1 = nullptr; void* w2 = nullptr;   // packed conv weights
+  float *gn0_g = nullptr, *gn0_b = nullptr, *gn1_g = nullptr, *gn1_b = nullptr;
+  float *b1 = nullptr, *b2 = nullptr;      // Conv_1 / Conv_2 bias
+  float* bias0_eff = nullptr;              // [nt][cout] Conv_0 bias + Dense_0(silu(temb)), model-owned scratch
+  float *w_f32 = nullptr, *b_f32 = nullptr;  // small f32 weights (conv_in, combine, head bias, gn affine)
+};
+
+struct ParamInfo {
+  std::string name;
+  std::vector<int> shape;
+  long long numel() const { long long n = 1; for (int s : shape) n *= s; return n; }
+};
+
+// first-fit offset allocator over the caller's workspace; kernels run in stream order so a block may be
+// reused as soon as it is released in program order
+class Arena {
+  struct Blk { size_t off, size; bool free; };
+  std::vector<Blk> blks_;
+  size_t end_ = 0, peak_ = 0;
+ public:
+  size_t alloc(size_t bytes) {
+    bytes = fd_align(bytes ? bytes : 1);
+    for (size_t i = 0; i < blks_.size(); ++i)
+      if (blks_[i].free && blks_[i].size >= bytes) {
+        const size_t rest = blks_[i].size - bytes;
+        blks_[i].free = false; blks_[i].size = bytes;
+        if (rest) blks_.insert(blks_.begin() + i + 1, Blk{blks_[i].off + bytes, rest, true});
+        return blks_[i].off;
+      }
+    if (!blks_.empty() && blks_.back().free) {  // grow the trailing free block
+      blks_.back().free = false; blks_.back().size = bytes;
+      end_ = blks_.back().off + bytes;
+    } else {
+      blks_.push_back(Blk{end_, bytes, false});
+      end_ += bytes;
+    }
+    if (end_ > peak_) peak_ = end_;
+    return blks_.back().off;
+  }
+  void release(size_t off) {
+    for (size_t i = 0; i < blks_.size(); ++i)
+      if (blks_[i].off == off && !blks_[i].free) {
+        blks_[i].free = true;
+        if (i + 1 < blks_.size() && blks_[i + 1].free) { blks_[i].size += blks_[i + 1].size; blks_.erase(blks_.begin() + i + 1); }
+        if (i > 0 && blks_[i - 1].free) { blks_[i - 1].size += blks_[i].size; blks_.erase(blks_.begin() + i); }
+        if (!blks_.empty() && blks_.back().free) { end_ = blks_.back().off; blks_.pop_back(); }
+        return;
+      }
+  }
+  size_t peak() const { return peak_; }
+};
+
+struct Tens {
+  size_t off = (size_t)-1;
+  int C = 0, H = 0, W = 0;
+  size_t sums = (size_t)-1;  // offset of the per-(b,c) (sum, sumsq) doubles, if computed
+};
+
+struct GraphKey {
+  const void *Y, *noise, *X, *traj, *ws, *y, *xhat;
+  int B, T, N, solver, L, kind;
+  float sigma_fac;
+  bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
+};
+
+}  // namespace
+
+struct fd_model {
+  fd_model_config cfg;
+  int n_freq = 0, temb_dim = 0;
+  std::vector<Mod> mods;
+  std::vector<ParamInfo> params;
+  std::map<std::string, std::vector<float>> host;   // staged parameters
+  std::map<std::string, float*> dev_f32;            // uploaded f32 copies
+  std::vector<void*> dev_allocs;
+  std::vector<double> sigma_host;
+  double* sigma_dev = nullptr;
+  int sigma_n = 0;
+  bool finalized = false;
+  float* temb = nullptr;            // [MAX_NT][temb_dim]
+  fd_temb_job* jobs_dev = nullptr;
+  int njobs = 0;
+  float* wo = nullptr;              // output_layer weight [2][4]
+  fd_stft_plan* stft = nullptr;
+  std::map<GraphKey, hipGraphExec_t> graphs;
+  // profiling of the dominant kernel (conv MFMA)
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  size_t ev_used = 0;
+  double prof_flops = 0.0;
+  static constexpr int MAX_NT = 256;
+};
+
+namespace {
+
+int gn_groups(int C) { return (C / 4 < 32) ? C / 4 : 32; }
+
+// mirrors NCSNpp.__init__ (ncsnpp.py:102-251) for progressive='output_skip', progressive_input='input_skip',
+// combine 'sum', biggan blocks, no attention
+void build_structure(fd_model* m) {
+  const fd_model_config& c = m->cfg;
+  const int nf = c.nf, R = c.num_levels, nrb = c.num_res_blocks, nch = 4;
+  auto& mods = m->mods;
+  auto& P = m->params;
+  mods.clear(); P.clear();
+  auto add_param = [&](const std::string& n, std::vector<int> s) { P.push_back(ParamInfo{n, s}); };
+  auto pref = [](int i) { return "backbone.all_modules." + std::to_string(i) + "."; };
+  add_param("backbone.output_layer.weight", {2, nch, 1, 1});
+  int idx = 0;
+  auto push = [&](Mod md) { md.idx = idx++; mods.push_back(md); return (int)mods.size() - 1; };
+  auto add_rb = [&](int c0, int c1, int cout, bool up, bool down) {
+    Mod md{}; md.kind = M_RB; md.c0 = c0; md.c1 = c1; md.cin = c0 + c1; md.cout = cout; md.up = up; md.down = down;
+    md.has_c2 = (md.cin != cout) || up || down;
+    const int i = mods[push(md)].idx;
+    add_param(pref(i) + "GroupNorm_0.weight", {md.cin}); add_param(pref(i) + "GroupNorm_0.bias", {md.cin});
+    add_param(pref(i) + "Conv_0.weight", {cout, md.cin, 3, 3}); add_param(pref(i) + "Conv_0.bias", {cout});
+    add_param(pref(i) + "Dense_0.weight", {cout, 4 * nf}); add_param(pref(i) + "Dense_0.bias", {cout});
+    add_param(pref(i) + "GroupNorm_1.weight", {cout}); add_param(pref(i) + "GroupNorm_1.bias", {cout});
+    add_param(pref(i) + "Conv_1.weight", {cout, cout, 3, 3}); add_param(pref(i) + "Conv_1.bias", {cout});
+    if (md.has_c2) { add_param(pref(i) + "Conv_2.weight", {cout, md.cin, 1, 1}); add_param(pref(i) + "Conv_2.bias", {cout}); }
+  };
+  { Mod md{}; md.kind = M_GFP; push(md); add_param(pref(0) + "W", {nf}); }
+  { Mod md{}; md.kind = M_LINEAR; md.cin = 2 * nf; md.cout = 4 * nf; push(md); add_param(pref(1) + "weight", {4 * nf, 2 * nf}); add_param(pref(1) + "bias", {4 * nf}); }
+  { Mod md{}; md.kind = M_LINEAR; md.cin = 4 * nf; md.cout = 4 * nf; push(md); add_param(pref(2) + "weight", {4 * nf, 4 * nf}); add_param(pref(2) + "bias", {4 * nf}); }
+  { Mod md{}; md.kind = M_CONV_IN; md.cin = nch; md.cout = nf; push(md); add_param(pref(3) + "weight", {nf, nch, 3, 3}); add_param(pref(3) + "bias", {nf}); }
+  std::vector<int> hs_c{nf};
+  int in_ch = nf;
+  for (int lvl = 0; lvl < R; ++lvl) {
+    for (int b = 0; b < nrb; ++b) {
+      const int out_ch = nf * c.ch_mult[lvl];
+      add_rb(in_ch, 0, out_ch, false, false);
+      in_ch = out_ch;
+      hs_c.push_back(in_ch);
+    }
+    if (lvl != R - 1) {
+      add_rb(in_ch, 0, in_ch, false, true);
+      Mod md{}; md.kind = M_COMBINE; md.cin = nch; md.cout = in_ch;
+      const int i = mods[push(md)].idx;
+      add_param(pref(i) + "Conv_0.weight", {in_ch, nch, 1, 1}); add_param(pref(i) + "Conv_0.bias", {in_ch});
+      hs_c.push_back(in_ch);
+    }
+  }
+  in_ch = hs_c.back();
+  add_rb(in_ch, 0, in_ch, false, false);
+  add_rb(in_ch, 0, in_ch, false, false);
+  for (int lvl = R - 1; lvl >= 0; --lvl) {
+    for (int b = 0; b < nrb + 1; ++b) {
+      const int out_ch = nf * c.ch_mult[lvl];
+      const int sk = hs_c.back(); hs_c.pop_back();
+      add_rb(in_ch, sk, out_ch, false, false);
+      in_ch = out_ch;
+    }
+    { Mod md{}; md.kind = M_GN; md.cin = in_ch; const int i = mods[push(md)].idx;
+      add_param(pref(i) + "weight", {in_ch}); add_param(pref(i) + "bias", {in_ch}); }
+    { Mod md{}; md.kind = M_CONV_HEAD; md.cin = in_ch; md.cout = nch; const int i = mods[push(md)].idx;
+      add_param(pref(i) + "weight", {nch, in_ch, 3, 3}); add_param(pref(i) + "bias", {nch}); }
+    if (lvl != 0) add_rb(in_ch, 0, in_ch, true, false);
+  }
+}
+
+int upload_f32(fd_model* m, const std::string& name, float** out) {
+  auto it = m->host.find(name);
+  if (it == m->host.end()) return fd_set_error(FD_ESTATE, "parameter '%s' was never set", name.c_str());
+  float* d = nullptr;
+  FD_HIP(hipMalloc(&d, sizeof(float) * it->second.size()));
+  FD_HIP(hipMemcpy(d, it->second.data(), sizeof(float) * it->second.size(), hipMemcpyHostToDevice));
+  m->dev_allocs.push_back(d);
+  m->dev_f32[name] = d;
+  *out = d;
+  return FD_OK;
+}
+
+int pack_conv(fd_model* m, const std::string& name, int Cout, int C0, int C1, int ks, void** out, hipStream_t st) {
+  float* src = nullptr;
+  FD_TRY(upload_f32(m, name, &src));
+  void* dst = nullptr;
+  const long long bytes = fd_conv_packed_bytes(Cout, C0, C1, ks, m->cfg.act_dtype);
+  FD_HIP(hipMalloc(&dst, (size_t)bytes));
+  m->dev_allocs.push_back(dst);
+  FD_TRY(fd_conv_pack_weights(src, dst, Cout, C0, C1, ks, m->cfg.act_dtype, st));
+  *out = dst;
+  return FD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward pass
+// ---------------------------------------------------------------------------------------------------------------
+struct OutSpec {           // what to do with v = NCSNpp(x, y, t):  dst = base + coef * (v + kold); ksave = v
+  const float* base = nullptr;
+  const float* kold = nullptr;
+  float coef = 1.f;
+  float* dst = nullptr;
+  float* ksave = nullptr;
+};
+
+struct Fwd {
+  fd_model* m;
+  bool dry;            // plan only (no launches, no pointers)
+  char* base;
+  Arena arena;
+  hipStream_t st;
+  int B, F, T, dt, esz;
+
+  void* ptr(size_t off) const { return dry ? nullptr : base + off; }
+  Tens talloc(int C, int H, int W) { Tens t; t.C = C; t.H = H; t.W = W; t.off = arena.alloc((size_t)B * H * W * C * esz); return t; }
+  void tfree(Tens& t) {
+    if (t.off != (size_t)-1) arena.release(t.off);
+    if (t.sums != (size_t)-1) arena.release(t.sums);
+    t.off = t.sums = (size_t)-1;
+  }
+  int ensure_sums(Tens& t) {
+    if (t.sums != (size_t)-1) return FD_OK;
+    t.sums = arena.alloc(sizeof(double) * 2 * (size_t)B * t.C);
+    if (dry) return FD_OK;
+    return fd_channel_sums(ptr(t.off), (double*)ptr(t.sums), B, t.H, t.W, t.C, dt, st);
+  }
+  // GroupNorm over the virtual concat [a | b] -> affine pairs
+  int gn_affine(Tens& a, Tens* b, const float* gamma, const float* beta, size_t* aff_off) {
+    FD_TRY(ensure_sums(a));
+    if (b) FD_TRY(ensure_sums(*b));
+    const int C = a.C + (b ? b->C : 0);
+    *aff_off = arena.alloc(sizeof(float) * 2 * (size_t)B * C);
+    if (dry) return FD_OK;
+    return fd_gn_finalize((const double*)ptr(a.sums), a.C, b ? (const double*)ptr(b->sums) : nullptr, b ? b->C : 0, gamma, beta,
+                          (float*)ptr(*aff_off), B, gn_groups(C), (long long)a.H * a.W, 1e-6f, st);
+  }
+  int conv(const Tens& a, const Tens* b, size_t aff, const void* w, const float* bias, int bias_rows, const Tens* skip, float scale,
+           Tens& out, int ks) {
+    if (dry) return FD_OK;
+    if (m->profiling) {
+      if (m->ev_used == m->ev.size()) {
+        hipEvent_t e0, e1;
+        FD_HIP(hipEventCreate(&e0)); FD_HIP(hipEventCreate(&e1));
+        m->ev.emplace_back(e0, e1);
+      }
+      FD_HIP(hipEventRecord(m->ev[m->ev_used].first, st));
+    }
+    const int rc = fd_conv2d(ptr(a.off), a.C, b ? ptr(b->off) : nullptr, b ? b->C : 0, aff == (size_t)-1 ? nullptr : (const float*)ptr(aff), w,
+                             bias, bias_rows, skip ? ptr(skip->off) : nullptr, scale, ptr(out.off), out.C, B, out.H, out.W, ks, dt, dt, st);
+    if (m->profiling) {
+      FD_HIP(hipEventRecord(m->ev[m->ev_used].second, st));
+      ++m->ev_used;
+      m->prof_flops += 2.0 * B * out.H * out.W * (double)out.C * (a.C + (b ? b->C : 0)) * ks * ks;
+    }
+    return rc;
+  }
+
+  int resblock(const Mod& md, Tens& x0, Tens* x1, int nt, Tens& out) {
+    const float rs2 = 0.70710678118654752440f;
+    size_t aff0;
+    FD_TRY(gn_affine(x0, x1, md.gn0_g, md.gn0_b, &aff0));
+    const int H = x0.H, W = x0.W;
+    const int OH = md.up ? 2 * H : (md.down ? H / 2 : H), OW = md.up ? 2 * W : (md.down ? W / 2 : W);
+    Tens h1 = talloc(md.cout, OH, OW);
+    Tens xr, hr;
+    if (md.up || md.down) {
+      xr = talloc(md.cin, OH, OW); hr = talloc(md.cin, OH, OW);
+      if (!dry) FD_TRY(fd_fir_resample(ptr(x0.off), (const float*)ptr(aff0), ptr(xr.off), ptr(hr.off), B, H, W, md.cin, md.up ? 1 : -1, dt, st));
+      FD_TRY(conv(hr, nullptr, (size_t)-1, md.w0, md.bias0_eff, nt, nullptr, 1.f, h1, 3));
+      tfree(hr);
+    } else {
+      FD_TRY(conv(x0, x1, aff0, md.w0, md.bias0_eff, nt, nullptr, 1.f, h1, 3));
+    }
+    arena.release(aff0);
+    size_t aff1;
+    FD_TRY(gn_affine(h1, nullptr, md.gn1_g, md.gn1_b, &aff1));
+    out = talloc(md.cout, OH, OW);
+    if (md.has_c2) {
+      Tens sk = talloc(md.cout, OH, OW);
+      if (md.up || md.down) FD_TRY(conv(xr, nullptr, (size_t)-1, md.w2, md.b2, 1, nullptr, 1.f, sk, 1));
+      else FD_TRY(conv(x0, x1, (size_t)-1, md.w2, md.b2, 1, nullptr, 1.f, sk, 1));
+      FD_TRY(conv(h1, nullptr, aff1, md.w1, md.b1, 1, &sk, rs2, out, 3));
+      tfree(sk);
+    } else {
+      FD_TRY(conv(h1, nullptr, aff1, md.w1, md.b1, 1, &x0, rs2, out, 3));
+    }
+    if (md.up || md.down) tfree(xr);
+    arena.release(aff1);
+    tfree(h1);
+    return FD_OK;
+  }
+
+  // ncsnpp.py:254-399
+  int run(const float* x, const float* y, const float* t, float t_imm, int nt, const OutSpec& os) {
+    const fd_model_config& c = m->cfg;
+    const int R = c.num_levels, nrb = c.num_res_blocks;
+    const auto& mods = m->mods;
+    if (!dry) {
+      FD_TRY(fd_time_embedding_impl(t, t_imm, nt, m->dev_f32["backbone.all_modules.0.W"], c.nf, m->dev_f32["backbone.all_modules.1.weight"],
+                                    m->dev_f32["backbone.all_modules.1.bias"], m->dev_f32["backbone.all_modules.2.weight"],
+                                    m->dev_f32["backbone.all_modules.2.bias"], m->temb, st));
+      FD_TRY(fd_temb_bias_batched(m->jobs_dev, m->njobs, m->temb, nt, m->temb_dim, st));
+    }
+    size_t mi = 3;
+    Tens in4 = talloc(4, F, T);
+    if (!dry) { fd_edge_args a; a.x = x; a.y = y; a.out = ptr(in4.off); a.B = B; a.H = F; a.W = T; FD_TRY(fd_edge_op(0, a, dt, st)); }
+    std::vector<Tens> hs;
+    {
+      const Mod& md = mods[mi++];
+      Tens h0 = talloc(md.cout, F, T);
+      if (!dry) { fd_edge_args a; a.x = ptr(in4.off); a.w = md.w_f32; a.bias = md.b_f32; a.out = ptr(h0.off); a.B = B; a.H = F; a.W = T; a.Cout = md.cout;
+                  FD_TRY(fd_edge_op(1, a, dt, st)); }
+      hs.push_back(h0);
+    }
+    Tens pyr_in = in4;  // input pyramid (owned here)
+    Tens h;
+    for (int lvl = 0; lvl < R; ++lvl) {
+      for (int b = 0; b < nrb; ++b) {
+        FD_TRY(resblock(mods[mi++], hs.back(), nullptr, nt, h));
+        hs.push_back(h);
+      }
+      if (lvl != R - 1) {
+        Tens hd;
+        FD_TRY(resblock(mods[mi++], hs.back(), nullptr, nt, hd));
+        Tens p2 = talloc(4, pyr_in.H / 2, pyr_in.W / 2);
+        if (!dry) FD_TRY(fd_fir_resample(ptr(pyr_in.off), nullptr, ptr(p2.off), nullptr, B, pyr_in.H, pyr_in.W, 4, -1, dt, st));
+        tfree(pyr_in);
+        pyr_in = p2;
+        const Mod& md = mods[mi++];
+        Tens hc = talloc(md.cout, hd.H, hd.W);
+        if (!dry) { fd_edge_args a; a.x = ptr(pyr_in.off); a.y = ptr(hd.off); a.w = md.w_f32; a.bias = md.b_f32; a.out = ptr(hc.off);
+                    a.B = B; a.H = hd.H; a.W = hd.W; a.Cout = md.cout; FD_TRY(fd_edge_op(2, a, dt, st)); }
+        tfree(hd);
+        hs.push_back(hc);
+      }
+    }
+    tfree(pyr_in);
+    {
+      Tens a1, a2;
+      FD_TRY(resblock(mods[mi++], hs.back(), nullptr, nt, a1));
+      FD_TRY(resblock(mods[mi++], a1, nullptr, nt, a2));
+      tfree(a1);
+      h = a2;
+    }
+    Tens pyramid; bool have_pyr = false;
+    for (int lvl = R - 1; lvl >= 0; --lvl) {
+      for (int b = 0; b < nrb + 1; ++b) {
+        Tens sk = hs.back(); hs.pop_back();
+        Tens o;
+        FD_TRY(resblock(mods[mi++], h, &sk, nt, o));
+        tfree(h); tfree(sk);
+        h = o;
+      }
+      const Mod& gn = mods[mi++];
+      const Mod& head = mods[mi++];
+      size_t aff;
+      FD_TRY(gn_affine(h, nullptr, gn.gn0_g, gn.gn0_b, &aff));
+      Tens pnew = talloc(4, h.H, h.W);
+      if (have_pyr) {
+        Tens pu = talloc(4, h.H, h.W);
+        if (!dry) FD_TRY(fd_fir_resample(ptr(pyramid.off), nullptr, ptr(pu.off), nullptr, B, pyramid.H, pyramid.W, 4, +1, dt, st));
+        FD_TRY(conv(h, nullptr, aff, head.w0, head.b_f32, 1, &pu, 1.f, pnew, 3));
+        tfree(pu); tfree(pyramid);
+      } else {
+        FD_TRY(conv(h, nullptr, aff, head.w0, head.b_f32, 1, nullptr, 1.f, pnew, 3));
+      }
+      arena.release(aff);
+      pyramid = pnew; have_pyr = true;
+      if (lvl != 0) {
+        Tens o;
+        FD_TRY(resblock(mods[mi++], h, nullptr, nt, o));
+        tfree(h);
+        h = o;
+      }
+    }
+    tfree(h);
+    if (!hs.empty() || mi != mods.size()) return fd_set_error(FD_ESTATE, "internal: module walk mismatch");
+    if (!dry) {
+      fd_edge_args a; a.x = ptr(pyramid.off); a.w = m->wo; a.base = os.base; a.kold = os.kold; a.coef = os.coef; a.out = os.dst; a.ksave = os.ksave;
+      a.B = B; a.H = F; a.W = T;
+      FD_TRY(fd_edge_op(3, a, dt, st));
+    }
+    tfree(pyramid);
+    return FD_OK;
+  }
+};
+
+int check_ready(const fd_model* m) {
+  if (!m) return fd_set_error(FD_EINVAL, "null model");
+  if (!m->finalized) return fd_set_error(FD_ESTATE, "model not finalised (call fd_model_finalize)");
+  return FD_OK;
+}
+
+size_t forward_ws_bytes(const fd_model* m, int B, int T) {
+  Fwd f{const_cast<fd_model*>(m), true, nullptr, Arena(), nullptr, B, m->n_freq, T, m->cfg.act_dtype, (int)fd_dtype_size(m->cfg.act_dtype)};
+  OutSpec os;
+  if (f.run(nullptr, nullptr, nullptr, 0.f, 1, os) != FD_OK) return 0;
+  return f.arena.peak() + 256;
+}
+
+int check_shape(const fd_model* m, int B, int T) {
+  const int div = 1 << (m->cfg.num_levels - 1);
+  FD_REQUIRE(B > 0 && T > 0 && T % div == 0, "T_pad=%d must be a positive multiple of %d (B=%d)", T, div, B);
+  FD_REQUIRE(m->n_freq % div == 0, "n_freq=%d not divisible by %d", m->n_freq, div);
+  return FD_OK;
+}
+
+int forward_call(fd_model* m, const float* x, const float* y, const float* t, float t_imm, int nt, const OutSpec& os, int B, int T, void* ws,
+                 size_t ws_bytes, hipStream_t st) {
+  Fwd f{m, false, (char*)ws, Arena(), st, B, m->n_freq, T, m->cfg.act_dtype, (int)fd_dtype_size(m->cfg.act_dtype)};
+  (void)ws_bytes;
+  return f.run(x, y, t, t_imm, nt, os);
+}
+
+// torch.linspace(0, 1, N+1) in float32 with ATen's fused multiply-add evaluation (see oracle t_span_linspace)
+std::vector<float> t_span_linspace(int N) {
+  const int steps = N + 1;
+  std::vector<float> out(steps);
+  const float step = 1.0f / (float)(steps - 1);
+  const int half = steps / 2;
+  for (int i = 0; i < steps; ++i) out[i] = i < half ? fmaf(step, (float)i, 0.0f) : fmaf(-step, (float)(steps - 1 - i), 1.0f);
+  return out;
+}
+
+int solver_nfe(int solver, int N) {
+  switch (solver) {
+    case FD_SOLVER_EULER: return N;
+    case FD_SOLVER_MIDPOINT: case FD_SOLVER_HEUN2: return 2 * N;
+    case FD_SOLVER_HEUN2_EULERLAST: return 2 * N - 1;
+  }
+  return -1;
+}
+
+size_t ode_ws_bytes(const fd_model* m, int B, int T) {
+  const size_t state = fd_align(sizeof(float) * 2 * (size_t)B * m->n_freq * T);
+  return 2 * state + forward_ws_bytes(m, B, T);
+}
+
+// the solver loop; everything is enqueued on `st` (eagerly or inside a capture)
+int ode_enqueue(fd_model* m, const float* Y, const float* noise, float sigma_fac, int N, int solver, float* X, float* traj, int B, int T, void* ws,
+                size_t ws_bytes, hipStream_t st) {
+  const size_t nstate = (size_t)B * m->n_freq * T;
+  const size_t state = fd_align(sizeof(float) * 2 * nstate);
+  float* xtmp = (float*)ws;
+  float* k1 = (float*)((char*)ws + state);
+  void* fws = (char*)ws + 2 * state;
+  const size_t fws_bytes = ws_bytes - 2 * state;
+  FD_TRY(fd_init_state(Y, noise, m->sigma_dev, m->sigma_n, sigma_fac, X, B, m->n_freq, T, st));
+  if (traj) FD_HIP(hipMemcpyAsync(traj, X, sizeof(float) * 2 * nstate, hipMemcpyDeviceToDevice, st));
+  const std::vector<float> ts = t_span_linspace(N);
+  float t = ts[0];
+  float dt = ts[1] - ts[0];
+  for (int i = 1; i <= N; ++i) {
+    OutSpec os;
+    if (solver == FD_SOLVER_EULER) {
+      os.base = X; os.coef = dt; os.dst = X;
+      FD_TRY(forward_call(m, X, Y, nullptr, t, 1, os, B, T, fws, fws_bytes, st));
+    } else if (solver == FD_SOLVER_MIDPOINT) {
+      const float half = 0.5f * dt;
+      os.base = X; os.coef = half; os.dst = xtmp;
+      FD_TRY(forward_call(m, X, Y, nullptr, t, 1, os, B, T, fws, fws_bytes, st));
+      OutSpec o2; o2.base = X; o2.coef = dt; o2.dst = X;
+      FD_TRY(forward_call(m, xtmp, Y, nullptr, t + half, 1, o2, B, T, fws, fws_bytes, st));
+    } else {  // heun2 / heun2_eulerlast (sampling/solvers.py:15-57)
+      const bool last = solver == FD_SOLVER_HEUN2_EULERLAST && fabsf((t + dt) - 1.0f) <= 1e-8f + 1e-5f;
+      if (last) {
+        os.base = X; os.coef = dt; os.dst = X;
+        FD_TRY(forward_call(m, X, Y, nullptr, t, 1, os, B, T, fws, fws_bytes, st));
+      } else {
+        os.base = X; os.coef = dt; os.dst = xtmp; os.ksave = k1;
+        FD_TRY(forward_call(m, X, Y, nullptr, t, 1, os, B, T, fws, fws_bytes, st));
+        OutSpec o2; o2.base = X; o2.kold = k1; o2.coef = dt * 0.5f; o2.dst = X;
+        FD_TRY(forward_call(m, xtmp, Y, nullptr, t + dt, 1, o2, B, T, fws, fws_bytes, st));
+      }
+    }
+    if (traj) FD_HIP(hipMemcpyAsync(traj + 2 * nstate * i, X, sizeof(float) * 2 * nstate, hipMemcpyDeviceToDevice, st));
+    t = t + dt;
+    if (i < N) dt = ts[i + 1] - t;
+  }
+  return FD_OK;
+}
+
+template <typename Fn>
+int run_maybe_graph(fd_model* m, const GraphKey& key, bool use_graph, hipStream_t st, Fn&& enqueue) {
+  if (!use_graph || m->profiling) return enqueue();
+  auto it = m->graphs.find(key);
+  if (it == m->graphs.end()) {
+    hipGraph_t graph = nullptr;
+    FD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue();
+    const hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc != FD_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fd_set_error(FD_ERUNTIME, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    hipGraphExec_t exec = nullptr;
+    FD_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    it = m->graphs.emplace(key, exec).first;
+  }
+  FD_HIP(hipGraphLaunch(it->second, st));
+  return FD_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int fd_model_create(const fd_model_config* cfg, fd_model** out) {
+  FD_REQUIRE(cfg && out, "fd_model_create: null pointer");
+  FD_REQUIRE(cfg->nf >= 8 && cfg->nf % 8 == 0 && cfg->nf <= 64, "fd_model_create: nf must be a multiple of 8 in [8, 64] (got %d)", cfg->nf);
+  FD_REQUIRE(cfg->num_levels >= 1 && cfg->num_levels <= 8 && cfg->num_res_blocks >= 1, "fd_model_create: bad level / block counts");
+  FD_REQUIRE(cfg->act_dtype == FD_BF16 || cfg->act_dtype == FD_F32, "fd_model_create: act_dtype must be FD_BF16 or FD_F32");
+  FD_REQUIRE(cfg->n_fft > 0 && cfg->n_fft % 2 == 0 && cfg->hop > 0, "fd_model_create: bad STFT geometry");
+  for (int i = 0; i < cfg->num_levels; ++i) {
+    const int ch = cfg->nf * cfg->ch_mult[i];
+    FD_REQUIRE(ch >= 8 && ch <= 256 && (ch & (ch - 1)) == 0, "fd_model_create: level width nf*ch_mult=%d must be a power of two in [8, 256]", ch);
+  }
+  fd_model* m = new fd_model();
+  m->cfg = *cfg;
+  m->n_freq = cfg->n_fft / 2 + 1;
+  m->temb_dim = 4 * cfg->nf;
+  build_structure(m);
+  *out = m;
+  return FD_OK;
+}
+
+extern "C" void fd_model_destroy(fd_model* m) {
+  if (!m) return;
+  for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
+  for (void* p : m->dev_allocs) (void)hipFree(p);
+  for (auto& e : m->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  fd_stft_plan_destroy(m->stft);
+  delete m;
+}
+
+extern "C" int fd_model_num_params(const fd_model* m) { return m ? (int)m->params.size() : 0; }
+
+extern "C" int fd_model_param_info(const fd_model* m, int i, const char** name, int* ndim, int shape[4]) {
+  FD_REQUIRE(m && i >= 0 && i < (int)m->params.size(), "fd_model_param_info: index out of range");
+  const ParamInfo& p = m->params[i];
+  if (name) *name = p.name.c_str();
+  if (ndim) *ndim = (int)p.shape.size();
+  if (shape) for (size_t k = 0; k < 4; ++k) shape[k] = k < p.shape.size() ? p.shape[k] : 1;
+  return FD_OK;
+}
+
+extern "C" int fd_model_set_param(fd_model* m, const char* name, const float* host_data, long long numel) {
+  FD_REQUIRE(m && name && host_data, "fd_model_set_param: null pointer");
+  if (m->finalized) return fd_set_error(FD_ESTATE, "fd_model_set_param: model already finalised");
+  for (const ParamInfo& p : m->params)
+    if (p.name == name) {
+      FD_REQUIRE(p.numel() == numel, "fd_model_set_param: '%s' expects %lld elements, got %lld", name, p.numel(), numel);
+      m->host[name].assign(host_data, host_data + numel);
+      return FD_OK;
+    }
+  return fd_set_error(FD_EINVAL, "fd_model_set_param: unknown parameter '%s'", name);
+}
+
+extern "C" int fd_model_set_sigma_y(fd_model* m, const double* host_sigma, int n) {
+  FD_REQUIRE(m && host_sigma, "fd_model_set_sigma_y: null pointer");
+  FD_REQUIRE(n == 1 || n == m->n_freq, "fd_model_set_sigma_y: expected 1 or %d values, got %d", m->n_freq, n);
+  m->sigma_host.assign(host_sigma, host_sigma + n);
+  m->sigma_n = n;
+  if (m->sigma_dev) FD_HIP(hipMemcpy(m->sigma_dev, m->sigma_host.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  return FD_OK;
+}
+
+extern "C" int fd_model_finalize(fd_model* m, void* stream) {
+  FD_REQUIRE(m, "fd_model_finalize: null model");
+  if (m->finalized) return FD_OK;
+  hipStream_t st = fd_stream(stream);
+  for (const ParamInfo& p : m->params)
+    if (!m->host.count(p.name)) return fd_set_error(FD_ESTATE, "fd_model_finalize: parameter '%s' missing", p.name.c_str());
+  FD_TRY(fd_conv_init_attributes());
+  auto pref = [](int i) { return "backbone.all_modules." + std::to_string(i) + "."; };
+  float* tmp;
+  for (int i = 0; i < 3; ++i) {
+    if (i == 0) FD_TRY(upload_f32(m, pref(0) + "W", &tmp));
+    else { FD_TRY(upload_f32(m, pref(i) + "weight", &tmp)); FD_TRY(upload_f32(m, pref(i) + "bias", &tmp)); }
+  }
+  FD_TRY(upload_f32(m, "backbone.output_layer.weight", &m->wo));
+  std::vector<fd_temb_job> jobs;
+  size_t bias_total = 0;
+  for (Mod& md : m->mods) if (md.kind == M_RB) bias_total += (size_t)fd_model::MAX_NT * md.cout;
+  float* bias_pool = nullptr;
+  FD_HIP(hipMalloc(&bias_pool, sizeof(float) * (bias_total ? bias_total : 1)));
+  m->dev_allocs.push_back(bias_pool);
+  size_t bias_off = 0;
+  for (Mod& md : m->mods) {
+    const std::string p = pref(md.idx);
+    switch (md.kind) {
+      case M_CONV_IN:
+      case M_COMBINE: {
+        const std::string q = md.kind == M_COMBINE ? p + "Conv_0." : p;
+        FD_TRY(upload_f32(m, q + "weight", &md.w_f32));
+        FD_TRY(upload_f32(m, q + "bias", &md.b_f32));
+        break;
+      }
+      case M_GN:
+        FD_TRY(upload_f32(m, p + "weight", &md.gn0_g));
+        FD_TRY(upload_f32(m, p + "bias", &md.gn0_b));
+        break;
+      case M_CONV_HEAD:
+        FD_TRY(pack_conv(m, p + "weight", md.cout, md.cin, 0, 3, &md.w0, st));
+        FD_TRY(upload_f32(m, p + "bias", &md.b_f32));
+        break;
+      case M_RB: {
+        FD_TRY(upload_f32(m, p + "GroupNorm_0.weight", &md.gn0_g)); FD_TRY(upload_f32(m, p + "GroupNorm_0.bias", &md.gn0_b));
+        FD_TRY(upload_f32(m, p + "GroupNorm_1.weight", &md.gn1_g)); FD_TRY(upload_f32(m, p + "GroupNorm_1.bias", &md.gn1_b));
+        // up/down blocks resample the (single) input first, so Conv_0 / Conv_2 see one tensor of cin channels
+        FD_TRY(pack_conv(m, p + "Conv_0.weight", md.cout, md.c0, md.c1, 3, &md.w0, st));
+        FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, &md.w1, st));
+        FD_TRY(upload_f32(m, p + "Conv_1.bias", &md.b1));
+        if (md.has_c2) { FD_TRY(pack_conv(m, p + "Conv_2.weight", md.cout, md.c0, md.c1, 1, &md.w2, st)); FD_TRY(upload_f32(m, p + "Conv_2.bias", &md.b2)); }
+        fd_temb_job j{};
+        FD_TRY(upload_f32(m, p + "Dense_0.weight", &tmp)); j.dense_w = tmp;
+        FD_TRY(upload_f32(m, p + "Dense_0.bias", &tmp)); j.dense_b = tmp;
+        FD_TRY(upload_f32(m, p + "Conv_0.bias", &tmp)); j.conv_b = tmp;
+        md.bias0_eff = bias_pool + bias_off; bias_off += (size_t)fd_model::MAX_NT * md.cout;
+        j.out = md.bias0_eff; j.Cout = md.cout;
+        jobs.push_back(j);
+        break;
+      }
+      default: break;
+    }
+  }
+  m->njobs = (int)jobs.size();
+  FD_HIP(hipMalloc(&m->jobs_dev, sizeof(fd_temb_job) * jobs.size()));
+  m->dev_allocs.push_back(m->jobs_dev);
+  FD_HIP(hipMemcpy(m->jobs_dev, jobs.data(), sizeof(fd_temb_job) * jobs.size(), hipMemcpyHostToDevice));
+  FD_HIP(hipMalloc(&m->temb, sizeof(float) * fd_model::MAX_NT * m->temb_dim));
+  m->dev_allocs.push_back(m->temb);
+  if (m->sigma_host.empty()) { m->sigma_host.assign(1, 0.0); m->sigma_n = 1; }
+  FD_HIP(hipMalloc(&m->sigma_dev, sizeof(double) * m->n_freq));
+  m->dev_allocs.push_back(m->sigma_dev);
+  FD_HIP(hipMemcpy(m->sigma_dev, m->sigma_host.data(), sizeof(double) * m->sigma_n, hipMemcpyHostToDevice));
+  FD_TRY(fd_stft_plan_create(m->cfg.n_fft, m->cfg.hop, &m->stft));
+  FD_HIP(hipStreamSynchronize(st));
+  m->host.clear();
+  m->finalized = true;
+  return FD_OK;
+}
+
+extern "C" size_t fd_model_workspace_bytes(const fd_model* m, int B, int T_pad) {
+  if (!m || check_shape(m, B, T_pad) != FD_OK) return 0;
+  return ode_ws_bytes(m, B, T_pad);
+}
+
+extern "C" int fd_ncsnpp_forward(fd_model* m, const float* x, const float* y, const float* t, int nt, float* v, int B, int T_pad, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  FD_TRY(check_ready(m));
+  FD_REQUIRE(x && y && t && v && ws, "fd_ncsnpp_forward: null pointer");
+  FD_TRY(check_shape(m, B, T_pad));
+  FD_REQUIRE(nt == 1 || nt == B, "fd_ncsnpp_forward: t must have 1 or B entries (got %d)", nt);
+  FD_REQUIRE(nt <= fd_model::MAX_NT, "fd_ncsnpp_forward: per-sample t supports at most %d clips", fd_model::MAX_NT);
+  const size_t need = forward_ws_bytes(m, B, T_pad);
+  if (ws_bytes < need) return fd_set_error(FD_ENOMEM, "fd_ncsnpp_forward: workspace %zu < required %zu bytes", ws_bytes, need);
+  OutSpec os; os.dst = v; os.coef = 1.f;
+  return forward_call(m, x, y, t, 0.f, nt, os, B, T_pad, ws, ws_bytes, fd_stream(stream));
+}
+
+extern "C" int fd_ode_solve(fd_model* m, const float* Y, const float* noise, float sigma_fac, int N, int solver, float* X_out, float* traj, int B,
+                            int T_pad, void* ws, size_t ws_bytes, int use_graph, void* stream) {
+  FD_TRY(check_ready(m));
+  FD_REQUIRE(Y && noise && X_out && ws, "fd_ode_solve: null pointer");
+  FD_REQUIRE(N >= 1, "fd_ode_solve: N must be >= 1");
+  FD_REQUIRE(solver_nfe(solver, N) > 0, "fd_ode_solve: unknown solver id %d", solver);
+  FD_TRY(check_shape(m, B, T_pad));
+  const size_t need = ode_ws_bytes(m, B, T_pad);
+  if (ws_bytes < need) return fd_set_error(FD_ENOMEM, "fd_ode_solve: workspace %zu < required %zu bytes", ws_bytes, need);
+  hipStream_t st = fd_stream(stream);
+  GraphKey key{}; key.Y = Y; key.noise = noise; key.X = X_out; key.traj = traj; key.ws = ws; key.B = B; key.T = T_pad; key.N = N; key.solver = solver;
+  key.kind = 1; key.sigma_fac = sigma_fac;
+  return run_maybe_graph(m, key, use_graph != 0, st, [&]() { return ode_enqueue(m, Y, noise, sigma_fac, N, solver, X_out, traj, B, T_pad, ws, ws_bytes, st); });
+}
+
+extern "C" size_t fd_enhance_workspace_bytes(const fd_model* m, int B, int L) {
+  if (!m || B <= 0 || L <= 0) return 0;
+  const int T = 1 + L / m->cfg.hop, Tp = fd_padded_frames(T);
+  if (check_shape(m, B, Tp) != FD_OK) return 0;
+  const size_t state = fd_align(sizeof(float) * 2 * (size_t)B * m->n_freq * Tp);
+  const size_t a = fd_stft_ws_bytes(B, L, m->cfg.n_fft, m->cfg.hop), b = ode_ws_bytes(m, B, Tp);
+  return 2 * state + fd_align(sizeof(float) * B) + (a > b ? a : b) + 256;
+}
+
+extern "C" int fd_enhance(fd_model* m, const float* y, const float* noise, float sigma_fac, int N, int solver, float* x_hat, int B, int L, void* ws,
+                          size_t ws_bytes, int use_graph, void* stream) {
+  FD_TRY(check_ready(m));
+  FD_REQUIRE(y && noise && x_hat && ws, "fd_enhance: null pointer");
+  FD_REQUIRE(N >= 1 && solver_nfe(solver, N) > 0, "fd_enhance: bad N / solver");
+  FD_REQUIRE(B > 0 && L > m->cfg.n_fft / 2, "fd_enhance: clips must be longer than %d samples", m->cfg.n_fft / 2);
+  const int T = 1 + L / m->cfg.hop, Tp = fd_padded_frames(T);
+  FD_TRY(check_shape(m, B, Tp));
+  const size_t need = fd_enhance_workspace_bytes(m, B, L);
+  if (ws_bytes < need) return fd_set_error(FD_ENOMEM, "fd_enhance: workspace %zu < required %zu bytes", ws_bytes, need);
+  hipStream_t st = fd_stream(stream);
+  const size_t state = fd_align(sizeof(float) * 2 * (size_t)B * m->n_freq * Tp);
+  float* Y = (float*)ws;
+  float* X = (float*)((char*)ws + state);
+  float* normfac = (float*)((char*)ws + 2 * state);
+  char* rest = (char*)ws + 2 * state + fd_align(sizeof(float) * B);
+  const size_t rest_bytes = ws_bytes - (2 * state + fd_align(sizeof(float) * B));
+  GraphKey key{}; key.y = y; key.noise = noise; key.xhat = x_hat; key.ws = ws; key.B = B; key.L = L; key.N = N; key.solver = solver; key.kind = 2;
+  key.sigma_fac = sigma_fac;
+  return run_maybe_graph(m, key, use_graph != 0, st, [&]() {
+    FD_TRY(fd_stft_forward(m->stft, y, B, L, m->cfg.alpha, m->cfg.beta, 1, normfac, Y, Tp, rest, rest_bytes, st));
+    FD_TRY(ode_enqueue(m, Y, noise, sigma_fac, N, solver, X, nullptr, B, Tp, rest, rest_bytes, st));
+    FD_TRY(fd_stft_inverse(m->stft, X, B, T, Tp, m->cfg.alpha, m->cfg.beta, normfac, x_hat, L, rest, rest_bytes, st));
+    return FD_OK;
+  });
+}
+
+extern "C" int fd_profile_enable(fd_model* m, int enable) {
+  FD_REQUIRE(m, "fd_profile_enable: null model");
+  m->profiling = enable != 0;
+  m->ev_used = 0;
+  m->prof_flops = 0.0;
+  return FD_OK;
+}
+
+extern "C" int fd_profile_read(fd_model* m, double* conv_ms_total, long long* conv_launches, double* conv_flops_total) {
+  FD_REQUIRE(m, "fd_profile_read: null model");
+  double ms = 0.0;
+  for (size_t i = 0; i < m->ev_used; ++i) {
+    FD_HIP(hipEventSynchronize(m->ev[i].second));
+    float e = 0.f;
+    FD_HIP(hipEventElapsedTime(&e, m->ev[i].first, m->ev[i].second));
+    ms += e;
+  }
+  if (conv_ms_total) *conv_ms_total = ms;
+  if (conv_launches) *conv_launches = (long long)m->ev_used;
+  if (conv_flops_total) *conv_flops_total = m->prof_flops;
+  m->ev_used = 0;
+  m->prof_flops = 0.0;
+  return FD_OK;
+}

@@ -1,0 +1,479 @@
+"""Host-side mirror of the reference's Python API for the inference hot path.
+
+Same names, argument meaning, defaults, return conventions and state_dict key layout as
+
+* ``flowdec.model.FlowModel``            (flowdec/model.py:391-536)  -> :class:`FlowModel`
+* ``flowdec.backbones.ncsnpp.NCSNpp``    (flowdec/backbones/ncsnpp.py:49-411) -> :class:`NCSNpp`
+* ``flowdec.data.feature_extractors.AmplitudeCompressedComplexSTFT`` (:29-59) -> same name here
+
+but every FLOP runs in libflowdec_hip.so (hand-written HIP for gfx950).  The ``nn.Module`` tree only
+holds parameters (so ``load_state_dict(ckpt['_pl_ema_state_dict'])`` works unchanged); there is no
+Lightning / Hydra / torchdyn dependency and no PyTorch compute fallback.
+"""
+import ctypes as C
+import math
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers (names/shapes identical to the reference modules)
+# ------------------------------------------------------------------------------------------------
+class GaussianFourierProjection(nn.Module):
+    """layerspp.py:42-51 (parameter container; W is frozen)."""
+
+    def __init__(self, embedding_size=256, scale=1.0):
+        super().__init__()
+        self.W = nn.Parameter(torch.randn(embedding_size) * scale, requires_grad=False)
+
+
+class ResnetBlockBigGANpp(nn.Module):
+    """layerspp.py:222-284 (parameter container)."""
+
+    def __init__(self, in_ch, out_ch=None, temb_dim=None, up=False, down=False):
+        super().__init__()
+        out_ch = out_ch if out_ch else in_ch
+        self.GroupNorm_0 = nn.GroupNorm(min(in_ch // 4, 32), in_ch, eps=1e-6)
+        self.Conv_0 = nn.Conv2d(in_ch, out_ch, 3, padding=1)
+        self.Dense_0 = nn.Linear(temb_dim, out_ch)
+        self.GroupNorm_1 = nn.GroupNorm(min(out_ch // 4, 32), out_ch, eps=1e-6)
+        self.Conv_1 = nn.Conv2d(out_ch, out_ch, 3, padding=1)
+        if in_ch != out_ch or up or down:
+            self.Conv_2 = nn.Conv2d(in_ch, out_ch, 1)
+        self.up, self.down, self.in_ch, self.out_ch = up, down, in_ch, out_ch
+
+
+class Combine(nn.Module):
+    """layerspp.py:54-69 (parameter container, method 'sum')."""
+
+    def __init__(self, dim1, dim2):
+        super().__init__()
+        self.Conv_0 = nn.Conv2d(dim1, dim2, 1)
+
+
+DEFAULT_OUTPUTLAYER_KWARGS = dict(kernel_size=3, bias=False, padding="same", padding_mode="zeros")
+
+
+class NCSNpp(nn.Module):
+    """NCSN++ vector field v(x_t, y, t) -- constructor signature of ncsnpp.py:52-75.
+
+    Supported (= every shipped FlowDec config, config/model/backbone/ncsnpp_final_no_attn.yaml):
+    swish, BigGAN blocks, FIR [1,3,3,1], skip_rescale, progressive 'output_skip', progressive_input
+    'input_skip' combined by 'sum', Fourier embedding, no attention, 1x1 bias-free output layer.
+    Anything else raises NotImplementedError.
+    """
+
+    def __init__(self, nonlinearity="swish", nf=128, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2,
+                 attn_resolutions=(64, 32, 16, 8), resamp_with_conv=True, conditional=True, fir=True,
+                 fir_kernel=(1, 3, 3, 1), skip_rescale=True, resblock_type="biggan", progressive="output_skip",
+                 progressive_input="input_skip", progressive_combine="sum", init_scale=0.0, fourier_scale=16,
+                 image_size=256, embedding_type="fourier", dropout=0.0, num_channels=4,
+                 output_layer_kwargs: dict = DEFAULT_OUTPUTLAYER_KWARGS, bottleneck_attn: bool = True,
+                 precision: str = "bf16"):
+        super().__init__()
+        ch_mult = tuple(ch_mult)
+        all_res = [image_size // (2 ** i) for i in range(len(ch_mult))]
+        unsupported = []
+        if nonlinearity != "swish": unsupported.append("nonlinearity != swish")
+        if any(r in tuple(attn_resolutions) for r in all_res) or bottleneck_attn: unsupported.append("attention blocks")
+        if not (conditional and fir and skip_rescale and resamp_with_conv): unsupported.append("conditional/fir/skip_rescale/resamp_with_conv must be True")
+        if tuple(fir_kernel) != (1, 3, 3, 1): unsupported.append("fir_kernel != [1,3,3,1]")
+        if resblock_type.lower() != "biggan": unsupported.append("resblock_type != biggan")
+        if progressive.lower() != "output_skip" or progressive_input.lower() != "input_skip" or progressive_combine.lower() != "sum":
+            unsupported.append("progressive modes other than output_skip/input_skip/sum")
+        if embedding_type.lower() != "fourier": unsupported.append("embedding_type != fourier")
+        if dropout != 0.0: unsupported.append("dropout != 0 (inference only)")
+        if num_channels != 4: unsupported.append("num_channels != 4")
+        if dict(output_layer_kwargs).get("kernel_size", 3) != 1 or dict(output_layer_kwargs).get("bias", False):
+            unsupported.append("output layer other than 1x1 without bias")
+        if unsupported:
+            raise NotImplementedError("flowdec_amd.NCSNpp: unsupported configuration: " + "; ".join(unsupported))
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.nf, self.ch_mult, self.num_res_blocks, self.precision = nf, ch_mult, num_res_blocks, precision
+        self.num_resolutions = len(ch_mult)
+        self.output_layer = nn.Conv2d(num_channels, 2, kernel_size=1, bias=False)
+        temb_dim = nf * 4
+        mods = [GaussianFourierProjection(embedding_size=nf, scale=fourier_scale), nn.Linear(2 * nf, temb_dim),
+                nn.Linear(temb_dim, temb_dim), nn.Conv2d(num_channels, nf, 3, padding=1)]
+        hs_c, in_ch = [nf], nf
+        R = self.num_resolutions
+        for lvl in range(R):
+            for _ in range(num_res_blocks):
+                out_ch = nf * ch_mult[lvl]
+                mods.append(ResnetBlockBigGANpp(in_ch, out_ch, temb_dim)); in_ch = out_ch; hs_c.append(in_ch)
+            if lvl != R - 1:
+                mods.append(ResnetBlockBigGANpp(in_ch, temb_dim=temb_dim, down=True))
+                mods.append(Combine(num_channels, in_ch)); hs_c.append(in_ch)
+        in_ch = hs_c[-1]
+        mods += [ResnetBlockBigGANpp(in_ch, temb_dim=temb_dim), ResnetBlockBigGANpp(in_ch, temb_dim=temb_dim)]
+        for lvl in reversed(range(R)):
+            for _ in range(num_res_blocks + 1):
+                out_ch = nf * ch_mult[lvl]
+                mods.append(ResnetBlockBigGANpp(in_ch + hs_c.pop(), out_ch, temb_dim)); in_ch = out_ch
+            mods.append(nn.GroupNorm(min(in_ch // 4, 32), in_ch, eps=1e-6))
+            mods.append(nn.Conv2d(in_ch, num_channels, 3, padding=1))
+            if lvl != 0:
+                mods.append(ResnetBlockBigGANpp(in_ch, temb_dim=temb_dim, up=True))
+        assert not hs_c
+        self.all_modules = nn.ModuleList(mods)
+        for p in self.parameters():
+            p.requires_grad_(False)
+        # ---- native state ----
+        self._handle = None
+        self._handle_sig = None
+        self._ws = {}
+        self._sigma_y = None
+        self._stft_cfg = dict(n_fft=1534, hop=384, alpha=0.3, beta=0.33)
+
+    # -- native handle management ----------------------------------------------------------------
+    def _config_struct(self):
+        cfg = L.FdModelConfig()
+        cfg.nf = self.nf
+        for i, c in enumerate(self.ch_mult):
+            cfg.ch_mult[i] = int(c)
+        cfg.num_levels = len(self.ch_mult)
+        cfg.num_res_blocks = self.num_res_blocks
+        cfg.n_fft, cfg.hop = self._stft_cfg["n_fft"], self._stft_cfg["hop"]
+        cfg.alpha, cfg.beta = self._stft_cfg["alpha"], self._stft_cfg["beta"]
+        cfg.act_dtype = L.FD_BF16 if self.precision == "bf16" else L.FD_F32
+        return cfg
+
+    def invalidate(self):
+        """Drop the packed device copy (called after parameters change)."""
+        if self._handle is not None:
+            L.load().fd_model_destroy(self._handle)
+        self._handle, self._ws = None, {}
+
+    def __del__(self):
+        try:
+            self.invalidate()
+        except Exception:
+            pass
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self._handle_sig = None  # parameters changed -> repack lazily
+
+    def _sig(self):
+        p = next(self.parameters())
+        sig_sigma = None if self._sigma_y is None else (self._sigma_y.data_ptr(), self._sigma_y._version)
+        return (p.device, self.precision, tuple(sorted(self._stft_cfg.items())), sig_sigma,
+                tuple(q._version for q in self.parameters()))
+
+    def handle(self):
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("flowdec_amd: the model must be on the GPU (`model.cuda()`); there is no CPU path")
+        sig = self._sig()
+        if self._handle is not None and sig == self._handle_sig:
+            return self._handle
+        self.invalidate()
+        lib = L.load()
+        with torch.cuda.device(dev):
+            h = C.c_void_p()
+            cfg = self._config_struct()
+            L.check(lib.fd_model_create(C.byref(cfg), C.byref(h)))
+            sd = {"backbone." + k: v for k, v in self.state_dict().items()}
+            n = lib.fd_model_num_params(h)
+            for i in range(n):
+                name, ndim, shape = C.c_char_p(), C.c_int(), (C.c_int * 4)()
+                L.check(lib.fd_model_param_info(h, i, C.byref(name), C.byref(ndim), C.byref(shape)))
+                key = name.value.decode()
+                if key not in sd:
+                    lib.fd_model_destroy(h)
+                    raise RuntimeError(f"flowdec_amd: parameter {key} missing from the module state")
+                t = sd[key].detach().to("cpu", torch.float32).contiguous()
+                if list(t.shape) != [shape[j] for j in range(ndim.value)]:
+                    lib.fd_model_destroy(h)
+                    raise RuntimeError(f"flowdec_amd: parameter {key} has shape {list(t.shape)}")
+                L.check(lib.fd_model_set_param(h, name.value, C.c_void_p(t.data_ptr()), t.numel()))
+            if self._sigma_y is not None:
+                s = self._sigma_y.detach().to("cpu", torch.float64).contiguous().reshape(-1)
+                L.check(lib.fd_model_set_sigma_y(h, C.c_void_p(s.data_ptr()), s.numel()))
+            L.check(lib.fd_model_finalize(h, L.stream()))
+        self._handle, self._handle_sig = h, sig
+        return h
+
+    def workspace(self, key, nbytes, device):
+        buf = self._ws.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self._ws[key] = buf
+        return buf
+
+    # -- reference API -----------------------------------------------------------------------------
+    def forward(self, x, y, t):
+        """x, y: complex64 [B, 1, F, T]; t: [1] or [B]  ->  complex64 [B, 1, F, T] (ncsnpp.py:254-399)."""
+        L.require_cuda(x, y, t)
+        if x.shape != y.shape or x.ndim != 4 or x.shape[1] != 1:
+            raise RuntimeError(f"NCSNpp.forward expects x, y of shape [B, 1, F, T] (got {tuple(x.shape)}, {tuple(y.shape)})")
+        h = self.handle()
+        lib = L.load()
+        B, _, F, T = x.shape
+        x = x.to(torch.complex64).contiguous(); y = y.to(torch.complex64).contiguous()
+        t = t.to(torch.float32).reshape(-1).contiguous()
+        out = torch.empty_like(x)
+        need = lib.fd_model_workspace_bytes(h, B, T)
+        if need == 0:
+            raise RuntimeError("flowdec_hip: " + lib.fd_last_error().decode())
+        ws = self.workspace(("fwd", B, T), need, x.device)
+        L.check(lib.fd_ncsnpp_forward(h, L.ptr(torch.view_as_real(x)), L.ptr(torch.view_as_real(y)), L.ptr(t), t.numel(),
+                                      L.ptr(torch.view_as_real(out)), B, T, L.ptr(ws), ws.numel(), L.stream()))
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# feature extractor mirror
+# ------------------------------------------------------------------------------------------------
+class ComplexSTFT(nn.Module):
+    """feature_extractors.py:62-109 -- torch.stft/istft replaced by the HIP DFT-GEMM kernels."""
+
+    def __init__(self, window_fn, n_fft, sampling_rate, hop_length=None, n_hops=None, learnable_window=False):
+        super().__init__()
+        assert (hop_length is not None) ^ (n_hops is not None), "Exactly one of {hop_length, n_hops} must be specified!"
+        if hop_length is None:
+            hop_length = int(math.ceil(n_fft / n_hops))
+        if window_fn != "hann" or learnable_window:
+            raise NotImplementedError("flowdec_amd.ComplexSTFT: only the fixed symmetric Hann window is implemented")
+        self.window = nn.Parameter(torch.signal.windows.hann(n_fft), requires_grad=False)
+        self.n_fft, self.hop_length, self.sampling_rate, self.center = n_fft, hop_length, sampling_rate, True
+
+
+class CompressAmplitudesAndScale(nn.Module):
+    """feature_extractors.py:112-139 (parameters only; arithmetic is fused into the STFT kernels)."""
+
+    def __init__(self, compression_exponent: float, scale_factor: float):
+        super().__init__()
+        self.compression_exponent, self.scale_factor = compression_exponent, scale_factor
+
+
+class AmplitudeCompressedComplexSTFT(nn.Module):
+    """feature_extractors.py:29-59."""
+
+    def __init__(self, window_fn, n_fft, sampling_rate, alpha, beta, hop_length=None, n_hops=None, learnable_window=False):
+        super().__init__()
+        self.complex_stft = ComplexSTFT(window_fn, n_fft, sampling_rate, hop_length=hop_length, n_hops=n_hops,
+                                        learnable_window=learnable_window)
+        self.compress = CompressAmplitudesAndScale(alpha, beta)
+
+    def _cfg(self):
+        return dict(n_fft=self.complex_stft.n_fft, hop=self.complex_stft.hop_length,
+                    alpha=float(self.compress.compression_exponent), beta=float(self.compress.scale_factor))
+
+    def forward(self, x, **kwargs):
+        """x: [B, C, T] or [B, T] real (GPU) -> complex STFT, compressed (no normalisation, no padding)."""
+        from . import ops
+        shp = x.shape
+        Y, _, T = ops.stft_compress(x.reshape(-1, shp[-1]).float().contiguous(), normalize=False, **self._cfg())
+        return Y[:, 0, :, :T].reshape(*shp[:-1], Y.shape[2], T)
+
+    def invert(self, X, orig_length: Optional[int] = None, **kwargs):
+        from . import ops
+        shp = X.shape
+        T = shp[-1]
+        if orig_length is None:
+            orig_length = self.complex_stft.hop_length * (T - 1)
+        Xp = X.reshape(-1, 1, shp[-2], T).to(torch.complex64).contiguous()
+        y = ops.decompress_istft(Xp, T, orig_length, None, **self._cfg())
+        return y.reshape(*shp[:-2], orig_length)
+
+
+# ------------------------------------------------------------------------------------------------
+# FlowModel
+# ------------------------------------------------------------------------------------------------
+def sigma_y_from_file(filename: str, factor: float = 1.0, kernel_bandwidth: Optional[float] = None) -> torch.Tensor:
+    """flowdec/data/sigma_models/__init__.py:21-47 (gaussian_filter(mode='nearest') restated in NumPy)."""
+    if not os.path.isabs(filename):
+        filename = os.path.join(_DATA, os.path.basename(filename))
+    curve = np.load(filename).astype(np.float64)
+    if kernel_bandwidth is not None:
+        radius = int(4.0 * float(kernel_bandwidth) + 0.5)
+        k = np.arange(-radius, radius + 1, dtype=np.float64)
+        w = np.exp(-0.5 * (k / kernel_bandwidth) ** 2); w /= w.sum()
+        xp = np.concatenate([np.full(radius, curve[0]), curve, np.full(radius, curve[-1])])
+        curve = np.correlate(xp, w, mode="valid")
+    return factor * torch.from_numpy(curve).unsqueeze(-1)
+
+
+class FlowModel(nn.Module):
+    """Drop-in for flowdec.model.FlowModel on the inference path (model.py:391-536).
+
+    Extensions over the reference signature: ``enhance(..., noise=None, generator=None)`` to inject /
+    seed the initial Gaussian noise (the reference draws it from the global device RNG, model.py:512),
+    and ``use_graph`` (hipGraph replay of the whole solve).  ``with_grad=True`` is not supported.
+    """
+    strict_loading = False
+
+    def __init__(self, backbone: NCSNpp, feature_extractor: AmplitudeCompressedComplexSTFT, sampling_rate: int,
+                 sigma_x=0.0, sigma_y=0.66, flow_matcher=None, lr: float = 1e-4, normalize_mode: str = "noisy", **kwargs):
+        super().__init__()
+        assert normalize_mode in ("noisy", "none")
+        if normalize_mode != "noisy":
+            raise NotImplementedError("flowdec_amd.FlowModel: normalize_mode='none' is not wired to the HIP front-end")
+        self.sampling_rate, self.normalize_mode, self.lr, self.flow_matcher = sampling_rate, normalize_mode, lr, flow_matcher
+        self.backbone, self.feature_extractor = backbone, feature_extractor
+        self.sigma_x = nn.Parameter(sigma_x if isinstance(sigma_x, torch.Tensor) else torch.tensor(float(sigma_x)), requires_grad=False)
+        self.sigma_y = nn.Parameter(sigma_y if isinstance(sigma_y, torch.Tensor) else torch.tensor(float(sigma_y)), requires_grad=False)
+        self._io = {}
+        self._side_stream = None
+
+    # -- helpers ------------------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.sigma_y.device
+
+    def load_state_dict(self, state_dict, strict: bool = False, **kw):
+        # the reference sets strict_loading = False (model.py:397)
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def _sync_native(self):
+        self.backbone._sigma_y = self.sigma_y
+        self.backbone._stft_cfg = self.feature_extractor._cfg()
+        return self.backbone.handle()
+
+    def _io_buffers(self, B, Lw, Tp, F, dev):
+        key = (B, Lw, str(dev))
+        io = self._io.get(key)
+        if io is None:
+            io = dict(y=torch.empty(B, Lw, dtype=torch.float32, device=dev),
+                      noise=torch.empty(B, 1, F, Tp, dtype=torch.complex64, device=dev),
+                      out=torch.empty(B, Lw, dtype=torch.float32, device=dev))
+            self._io = {key: io}  # keep one shape resident
+        return io
+
+    def forward(self, xt, y, t):
+        if t.ndim == 0:
+            t = t.unsqueeze(0)  # model.py:471-472
+        self._sync_native()
+        return self.backbone(xt, y, t)
+
+    def _get_noise_tensor(self, shape, dev, noise, generator):
+        if noise is not None:
+            return noise.to(dev, torch.complex64).reshape(shape)
+        return torch.randn(shape, dtype=torch.complex64, device=dev, generator=generator)
+
+    @torch.no_grad()
+    def enhance(self, y, return_preprocess_info: bool = False, N: int = 50, solver: str = "euler", with_grad: bool = False,
+                sigma_fac: float = 1.0, return_traj: bool = False, noise=None, generator=None, use_graph: bool = True, **kwargs):
+        """Enhances a coded/noisy waveform y (model.py:476-528).  y: [L], [1, L] or [B, 1, L]."""
+        if with_grad:
+            raise NotImplementedError("flowdec_amd.FlowModel.enhance: with_grad=True (backprop through the solver) is out of scope")
+        if solver not in L.SOLVERS:
+            raise ValueError(f"unknown solver {solver!r}; supported: {sorted(L.SOLVERS)}")
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("flowdec_amd: move the model to the GPU first (`model.cuda()`)")
+        orig_device = y.device
+        squeeze_dims = 0
+        y3 = y
+        while y3.ndim < 3:  # model.py:146-149
+            y3 = y3.unsqueeze(0); squeeze_dims += 1
+        if y3.ndim != 3 or y3.shape[1] != 1:
+            raise RuntimeError(f"enhance expects [L], [1, L] or [B, 1, L] waveforms (got {tuple(y.shape)})")
+        lib = L.load()
+        h = self._sync_native()
+        cfg = self.feature_extractor._cfg()
+        B, Lw = y3.shape[0], y3.shape[-1]
+        F = cfg["n_fft"] // 2 + 1
+        T = lib.fd_num_frames(Lw, cfg["hop"]); Tp = lib.fd_padded_frames(T)
+        with torch.cuda.device(dev):
+            io = self._io_buffers(B, Lw, Tp, F, dev)
+            io["y"].copy_(y3.reshape(B, Lw))
+            io["noise"].copy_(self._get_noise_tensor((B, 1, F, Tp), dev, noise, generator))
+            # stream capture is illegal on the legacy default stream: run the solve on a side stream that is
+            # ordered after / before the caller's current stream
+            cur = torch.cuda.current_stream(dev)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(dev)
+            side = self._side_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                res = self._enhance_native(lib, h, cfg, io, B, Lw, F, T, Tp, N, solver, sigma_fac, return_traj,
+                                           return_preprocess_info, squeeze_dims, use_graph, dev)
+            cur.wait_stream(side)
+        if return_traj:
+            res[0].record_stream(cur)
+            for w in res[1]:
+                w.record_stream(cur)
+            return res
+        x_hat, info = res
+        x_hat.record_stream(cur)
+        for _ in range(squeeze_dims):
+            x_hat = x_hat.squeeze(0)
+        x_hat = x_hat.to(orig_device)
+        return (x_hat, info) if return_preprocess_info else x_hat
+
+    def _enhance_native(self, lib, h, cfg, io, B, Lw, F, T, Tp, N, solver, sigma_fac, return_traj, return_preprocess_info,
+                        squeeze_dims, use_graph, dev):
+        if True:
+            if not return_traj:
+                need = lib.fd_enhance_workspace_bytes(h, B, Lw)
+                if need == 0:
+                    raise RuntimeError("flowdec_hip: " + lib.fd_last_error().decode())
+                ws = self.backbone.workspace(("enh", B, Lw), need, dev)
+                L.check(lib.fd_enhance(h, L.ptr(io["y"]), L.ptr(torch.view_as_real(io["noise"])), float(sigma_fac), int(N),
+                                       L.SOLVERS[solver], L.ptr(io["out"]), B, Lw, L.ptr(ws), ws.numel(), int(use_graph), L.stream()))
+                x_hat = io["out"].reshape(B, 1, Lw).clone()
+                info = None
+                if return_preprocess_info:
+                    # normfac was computed by the HIP front-end; it lives right after the two state buffers of the workspace
+                    state = (8 * B * F * Tp + 255) // 256 * 256
+                    normfac = ws[2 * state:2 * state + 4 * B].view(torch.float32).clone().reshape(B, 1, 1)
+                    info = dict(orig_length=Lw, normfac=normfac, undo_pad_fn=(lambda Y_, T=T: Y_[..., :T]), squeeze_dims=squeeze_dims)
+            else:
+                from . import ops
+                Y, normfac, _ = ops.stft_compress(io["y"], normalize=True, **cfg)
+                traj = torch.empty(N + 1, B, 1, F, Tp, dtype=torch.complex64, device=dev)
+                X = torch.empty_like(Y)
+                need = lib.fd_model_workspace_bytes(h, B, Tp)
+                ws = self.backbone.workspace(("ode", B, Tp), need, dev)
+                L.check(lib.fd_ode_solve(h, L.ptr(torch.view_as_real(Y)), L.ptr(torch.view_as_real(io["noise"])), float(sigma_fac), int(N),
+                                         L.SOLVERS[solver], L.ptr(torch.view_as_real(X)), L.ptr(torch.view_as_real(traj)), B, Tp,
+                                         L.ptr(ws), ws.numel(), 0, L.stream()))
+                x_hats = []
+                for i in range(N + 1):
+                    xh = ops.decompress_istft(traj[i], T, Lw, normfac, **cfg).reshape(B, 1, Lw)
+                    for _ in range(squeeze_dims):
+                        xh = xh.squeeze(0)
+                    x_hats.append(xh)
+                return traj, x_hats
+        return x_hat, info
+
+
+# ------------------------------------------------------------------------------------------------
+# presets (replace hydra.compose('flowdec_75m' | 'flowdec_25s'), config/flowdec_75m.yaml etc.)
+# ------------------------------------------------------------------------------------------------
+BACKBONE_FINAL_NO_ATTN = dict(image_size=768, nonlinearity="swish", nf=64, ch_mult=(4, 4, 4, 2), num_res_blocks=1,
+                              attn_resolutions=(), bottleneck_attn=False, resamp_with_conv=True, conditional=True, fir=True,
+                              fir_kernel=(1, 3, 3, 1), skip_rescale=True, resblock_type="biggan", progressive="output_skip",
+                              progressive_input="input_skip", progressive_combine="sum", init_scale=0.0, embedding_type="fourier",
+                              fourier_scale=16, dropout=0.0, num_channels=4,
+                              output_layer_kwargs=dict(kernel_size=1, bias=False, padding="same", padding_mode="zeros"))
+
+PRESETS = {
+    "flowdec_75m": dict(sigma_file="flowdec_autoparams_75m.npy"),
+    "flowdec_25s": dict(sigma_file="flowdec_autoparams_25s.npy"),
+    "flowdec_75m_globsigy": dict(sigma_file=None),
+    "flowdec_25s_globsigy": dict(sigma_file=None),
+}
+
+
+def from_preset(name: str = "flowdec_75m", precision: str = "bf16", **backbone_overrides) -> FlowModel:
+    """Instantiate the model a reference user gets from `instantiate(compose(config_name=name)['model'])`."""
+    if name not in PRESETS:
+        raise KeyError(f"unknown preset {name!r}; available: {sorted(PRESETS)}")
+    bb = dict(BACKBONE_FINAL_NO_ATTN); bb.update(backbone_overrides)
+    backbone = NCSNpp(precision=precision, **bb)
+    fe = AmplitudeCompressedComplexSTFT(window_fn="hann", n_fft=1534, n_hops=4, sampling_rate=48000, alpha=0.3, beta=0.33)
+    sf = PRESETS[name]["sigma_file"]
+    sigma_y = sigma_y_from_file(sf, factor=1, kernel_bandwidth=3) if sf else 0.66
+    return FlowModel(backbone=backbone, feature_extractor=fe, sampling_rate=48000, sigma_x=0.0, sigma_y=sigma_y).eval()

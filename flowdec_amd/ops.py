@@ -1,0 +1,156 @@
+"""Thin torch-tensor wrappers over the op-level C ABI (include/flowdec_hip.h).
+
+Tensors are NHWC ([B, H, W, C]) float32 or bfloat16 on the GPU unless stated otherwise; every
+wrapper launches on torch's current stream and allocates only its own output.
+"""
+import math
+
+import torch
+
+from . import _lib as L
+
+
+def _nhwc(x):
+    L.require_cuda(x)
+    if x.ndim != 4 or not x.is_contiguous():
+        raise RuntimeError("expected a contiguous NHWC tensor [B, H, W, C]")
+    return x.shape
+
+
+def to_nhwc(x_nchw, dtype=None):
+    return x_nchw.permute(0, 2, 3, 1).contiguous().to(dtype or x_nchw.dtype)
+
+
+def to_nchw(x_nhwc):
+    return x_nhwc.permute(0, 3, 1, 2).contiguous()
+
+
+def channel_sums(x):
+    B, H, W, Cc = _nhwc(x)
+    out = torch.empty(B, Cc, 2, dtype=torch.float64, device=x.device)
+    L.check(L.load().fd_channel_sums(L.ptr(x), L.ptr(out), B, H, W, Cc, L.dtype_id(x.dtype), L.stream()))
+    return out
+
+
+def gn_finalize(sums0, sums1, gamma, beta, groups, hw, eps=1e-6):
+    B, C0 = sums0.shape[0], sums0.shape[1]
+    C1 = 0 if sums1 is None else sums1.shape[1]
+    out = torch.empty(B, C0 + C1, 2, dtype=torch.float32, device=sums0.device)
+    L.check(L.load().fd_gn_finalize(L.ptr(sums0), C0, L.ptr(sums1), C1, L.ptr(gamma), L.ptr(beta), L.ptr(out), B, groups, hw,
+                                    eps, L.stream()))
+    return out
+
+
+def gn_affine(x0, x1, gamma, beta, eps=1e-6):
+    """GroupNorm(min(C//4, 32), C) statistics of the virtual concat [x0 | x1] as per-(b, c) affine pairs."""
+    Cc = x0.shape[3] + (0 if x1 is None else x1.shape[3])
+    s0 = channel_sums(x0)
+    s1 = None if x1 is None else channel_sums(x1)
+    return gn_finalize(s0, s1, gamma, beta, min(Cc // 4, 32), x0.shape[1] * x0.shape[2], eps)
+
+
+def fir_resample(x, direction, affine=None, want_raw=True):
+    """direction +1 / -1; returns (raw, act) -- act is None without `affine`."""
+    B, H, W, Cc = _nhwc(x)
+    oh, ow = (2 * H, 2 * W) if direction > 0 else (H // 2, W // 2)
+    raw = torch.empty(B, oh, ow, Cc, dtype=x.dtype, device=x.device) if want_raw else None
+    act = torch.empty(B, oh, ow, Cc, dtype=x.dtype, device=x.device) if affine is not None else None
+    L.check(L.load().fd_fir_resample(L.ptr(x), L.ptr(affine), L.ptr(raw), L.ptr(act), B, H, W, Cc, direction,
+                                     L.dtype_id(x.dtype), L.stream()))
+    return raw, act
+
+
+def pack_conv_weight(w, C0=None, dtype=torch.bfloat16):
+    """w: [Cout, Cin, k, k] float32 (GPU).  C0 = channels of the first concat segment (default: all)."""
+    L.require_cuda(w)
+    w = w.contiguous().float()
+    Cout, Cin, k, _ = w.shape
+    C0 = Cin if C0 is None else C0
+    nbytes = L.load().fd_conv_packed_bytes(Cout, C0, Cin - C0, k, L.dtype_id(dtype))
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    L.check(L.load().fd_conv_pack_weights(L.ptr(w), L.ptr(packed), Cout, C0, Cin - C0, k, L.dtype_id(dtype), L.stream()))
+    return packed
+
+
+def conv2d(x0, packed_w, Cout, ksize, x1=None, affine=None, bias=None, skip=None, scale=1.0):
+    B, H, W, C0 = _nhwc(x0)
+    C1 = 0 if x1 is None else x1.shape[3]
+    out = torch.empty(B, H, W, Cout, dtype=x0.dtype, device=x0.device)
+    rows = 0 if bias is None else (1 if bias.ndim == 1 else bias.shape[0])
+    dt = L.dtype_id(x0.dtype)
+    L.check(L.load().fd_conv2d(L.ptr(x0), C0, L.ptr(x1), C1, L.ptr(affine), L.ptr(packed_w), L.ptr(bias), rows, L.ptr(skip),
+                               float(scale), L.ptr(out), Cout, B, H, W, ksize, dt, dt, L.stream()))
+    return out
+
+
+def time_embedding(t, gfp_w, w1, b1, w2, b2):
+    nt, nf = t.numel(), gfp_w.numel()
+    out = torch.empty(nt, 4 * nf, dtype=torch.float32, device=t.device)
+    L.check(L.load().fd_time_embedding(L.ptr(t), nt, L.ptr(gfp_w), nf, L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(out),
+                                       L.stream()))
+    return out
+
+
+def temb_bias(temb, dense_w, dense_b, conv_bias):
+    nt, D = temb.shape
+    Cout = dense_w.shape[0]
+    out = torch.empty(nt, Cout, dtype=torch.float32, device=temb.device)
+    L.check(L.load().fd_temb_bias(L.ptr(temb), nt, D, L.ptr(dense_w), L.ptr(dense_b), L.ptr(conv_bias), Cout, L.ptr(out), L.stream()))
+    return out
+
+
+def stft_compress(y, n_fft=1534, hop=384, alpha=0.3, beta=0.33, normalize=True):
+    """y [B, L] float32 -> (Y complex64 [B, 1, F, T_pad], normfac [B], T)."""
+    L.require_cuda(y)
+    lib = L.load()
+    B, Ls = y.shape
+    T = lib.fd_num_frames(Ls, hop)
+    Tp = lib.fd_padded_frames(T)
+    Y = torch.empty(B, 1, n_fft // 2 + 1, Tp, dtype=torch.complex64, device=y.device)
+    nf = torch.empty(B, dtype=torch.float32, device=y.device)
+    nws = lib.fd_stft_workspace_bytes(B, Ls, n_fft, hop)
+    ws = torch.empty(nws, dtype=torch.uint8, device=y.device)
+    L.check(lib.fd_stft_compress(L.ptr(y), B, Ls, n_fft, hop, alpha, beta, int(normalize), L.ptr(nf), L.ptr(Y), Tp, L.ptr(ws), nws, L.stream()))
+    return Y, nf, T
+
+
+def decompress_istft(X, T, length, normfac=None, n_fft=1534, hop=384, alpha=0.3, beta=0.33):
+    """X complex64 [B, 1, F, T_pad] -> y [B, length] float32."""
+    L.require_cuda(X)
+    lib = L.load()
+    B, Tp = X.shape[0], X.shape[-1]
+    y = torch.empty(B, length, dtype=torch.float32, device=X.device)
+    nws = lib.fd_stft_workspace_bytes(B, max(length, hop * T), n_fft, hop)
+    ws = torch.empty(nws, dtype=torch.uint8, device=X.device)
+    L.check(lib.fd_decompress_istft(L.ptr(X), B, T, Tp, n_fft, hop, alpha, beta, L.ptr(normfac), L.ptr(y), length, L.ptr(ws), nws, L.stream()))
+    return y
+
+
+def upfirdn2d_raw(x, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
+    """x: [major, in_h, in_w, minor] (the reference binding's view, op/upfirdn2d.py:123)."""
+    L.require_cuda(x, kernel)
+    lib = L.load()
+    major, in_h, in_w, minor = x.shape
+    kh, kw = kernel.shape
+    oh = lib.fd_upfirdn2d_out_size(in_h, up_y, down_y, pad_y0, pad_y1, kh)
+    ow = lib.fd_upfirdn2d_out_size(in_w, up_x, down_x, pad_x0, pad_x1, kw)
+    if oh <= 0 or ow <= 0:
+        raise RuntimeError("upfirdn2d: empty output")
+    out = torch.empty(major, oh, ow, minor, dtype=x.dtype, device=x.device)
+    L.check(lib.fd_upfirdn2d(L.ptr(x.contiguous()), L.ptr(kernel.contiguous().float()), L.ptr(out), major, in_h, in_w, minor, kh, kw,
+                             up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, L.dtype_id(x.dtype), L.stream()))
+    return out
+
+
+def fused_bias_act(x, bias, act=3, alpha=0.2, scale=math.sqrt(2.0)):
+    """scale * lrelu(x + bias[c]) for NCHW x (fused_act.py:110-121)."""
+    L.require_cuda(x)
+    x = x.contiguous().float()
+    out = torch.empty_like(x)
+    step_b = 1
+    for d in x.shape[2:]:
+        step_b *= d
+    size_b = 0 if bias is None else bias.numel()
+    L.check(L.load().fd_fused_bias_act(L.ptr(x), L.ptr(None if bias is None else bias.contiguous().float()), L.ptr(out), x.numel(),
+                                       step_b, size_b, act, alpha, scale, L.stream()))
+    return out

@@ -1,0 +1,191 @@
+/* flowdec_hip.h -- C ABI of libflowdec_hip.so: the MI355X (gfx950) drop-in for the FlowDec
+ * inference hot path (FlowModel.enhance: STFT -> NCSN++ x NFE inside a fixed-step ODE loop ->
+ * iSTFT).  Everything here is `extern "C"`, plain pointers and sizes; no torch types.
+ *
+ * Conventions
+ *  - Every function returns 0 on success or a negative FD_E* code; fd_last_error() gives the
+ *    message of the last failure on the calling thread.  The reference's native ops raise a C++
+ *    exception -> Python RuntimeError (op/upfirdn2d.cpp:34-42); the Python binding in
+ *    flowdec_amd/_lib.py turns a non-zero return into RuntimeError to keep that behaviour.
+ *  - All data pointers are DEVICE pointers owned by the caller unless stated otherwise; nothing on
+ *    the hot path allocates.  All work is enqueued asynchronously on `stream` (a hipStream_t passed
+ *    as void*; NULL = default stream), no hidden synchronisation, graph-capture safe -- the same
+ *    contract as the reference's launches on at::cuda::getCurrentCUDAStream (upfirdn2d_kernel.cu:224-226).
+ *  - Activation tensors are NHWC ([B][H][W][C], H = frequency bins, W = time frames) in the storage
+ *    type given by `dtype` (FD_F32 or FD_BF16).  Spectrogram / ODE-state tensors at the model boundary
+ *    use the reference layout: complex64 [B][1][F=768][T] (interleaved re,im), float32 waveforms [B][L].
+ */
+#ifndef FLOWDEC_HIP_H
+#define FLOWDEC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FD_OK 0
+#define FD_EINVAL (-1)   /* bad argument / unsupported shape */
+#define FD_ERUNTIME (-2) /* HIP runtime error (message has hipGetErrorString) */
+#define FD_ENOMEM (-3)   /* caller-provided workspace too small */
+#define FD_ESTATE (-4)   /* model not finalised / parameter missing */
+
+#define FD_F32 0
+#define FD_BF16 1
+
+/* solver ids (flowdec/model.py:487 'euler'/'midpoint' via torchdyn; sampling/solvers.py:15-57) */
+#define FD_SOLVER_EULER 0
+#define FD_SOLVER_MIDPOINT 1
+#define FD_SOLVER_HEUN2 2
+#define FD_SOLVER_HEUN2_EULERLAST 3
+
+const char* fd_last_error(void);
+int fd_version(void);
+/* Device properties the bench reports: [0]=CU count, [1]=max clock kHz, [2]=wavefront size, [3]=gfx arch number. */
+int fd_device_info(int* out4);
+
+/* ------------------------------------------------------------------------------------------------
+ * Native-operator parity (the reference's only FFI)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Replaces upfirdn2d_op.upfirdn2d(input[major,in_h,in_w,minor], kernel[kh,kw], up_x,up_y,down_x,down_y,
+ * pad_x0,pad_x1,pad_y0,pad_y1) -> out[major,out_h,out_w,minor]
+ * (op/upfirdn2d.cpp:38-49; kernel upfirdn2d_kernel.cu:118-218; out_h/out_w formula :248-251).
+ * `kernel` is float32 on device.  `out` must hold major*out_h*out_w*minor elements. */
+int fd_upfirdn2d(const void* input, const float* kernel, void* out, int major, int in_h, int in_w, int minor,
+                 int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
+                 int pad_y0, int pad_y1, int dtype, void* stream);
+int fd_upfirdn2d_out_size(int in_size, int up, int down, int pad0, int pad1, int ksize);
+
+/* Replaces fused_bias_act(input, bias, refer, act, grad, alpha, scale) for grad == 0
+ * (op/fused_bias_act.cpp:37-46; kernel fused_bias_act_kernel.cu:30-61):
+ * out[i] = scale * act(x[i] + bias[(i / step_b) % size_b]); act 1 = linear, 3 = leaky-relu(alpha).
+ * bias may be NULL (size_b == 0).  float32 only (dead code on the hot path; kept for API parity). */
+int fd_fused_bias_act(const float* x, const float* bias, float* out, long long n, int step_b, int size_b, int act,
+                      float alpha, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Hot-path building blocks (NHWC activations)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* StyleGAN2 FIR [1,3,3,1] x2 resampling in polyphase form (upsample_2d / downsample_2d,
+ * up_or_down_sampling.py:220-282) on an NHWC tensor.  If `affine` != NULL ([B][C] pairs (a,d)) a second
+ * output out_act = FIR(silu(a*x+d)) is produced from the same read (the resample of
+ * h = act(GroupNorm_0(x)) and of x in ResnetBlockBigGANpp.forward, layerspp.py:255-267).
+ * direction: +1 = up x2, -1 = down x2.  Either output may be NULL. */
+int fd_fir_resample(const void* x, const float* affine, void* out_raw, void* out_act, int B, int H, int W, int C,
+                    int direction, int dtype, void* stream);
+
+/* GroupNorm statistics, split in two so that a stats pass can be shared by consumers that group the
+ * channels differently (nn.GroupNorm(min(C//4,32), C, eps=1e-6), layerspp.py:229,241):
+ *  fd_channel_sums : sums[b][c] = (sum x, sum x^2) over H*W, float64 pairs, for an NHWC tensor.
+ *  fd_gn_finalize  : combine the per-channel sums of one or two tensors (virtual channel concat
+ *                    [C0 | C1], ncsnpp.py:337) into per-(b,c) affine pairs
+ *                    a = rstd*gamma[c], d = beta[c] - mean*rstd*gamma[c]  (biased variance). */
+int fd_channel_sums(const void* x, double* sums, int B, int H, int W, int C, int dtype, void* stream);
+int fd_gn_finalize(const double* sums0, int C0, const double* sums1, int C1, const float* gamma, const float* beta,
+                   float* affine, int B, int groups, long long hw, float eps, void* stream);
+
+/* Packs a PyTorch conv weight [Cout][Cin][k][k] float32 (device) into the MFMA layout
+ * [chunk][tap][CoutPad][32] (bf16 or f32), channels split at `C0` into two 32-padded segments
+ * (virtual concat).  fd_conv_packed_bytes gives the byte size of the destination. */
+long long fd_conv_packed_bytes(int Cout, int C0, int C1, int ksize, int wdtype);
+int fd_conv_pack_weights(const float* w, void* packed, int Cout, int C0, int C1, int ksize, int wdtype, void* stream);
+
+/* Implicit-GEMM convolution, stride 1, 'same' zero padding, ksize 3 or 1 (ddpm_conv3x3 / ddpm_conv1x1,
+ * layers.py:110-134) on MFMA:
+ *   out = scale * ( conv( act([in0 | in1]) ) + bias[b] + skip )
+ * act(x) = silu(a*x+d) per (b,c) if `affine` != NULL (GroupNorm+SiLU folded into the operand load),
+ * identity otherwise; [in0|in1] is a virtual channel concat (in1 may be NULL, C1 = 0);
+ * bias: [bias_rows][Cout] float32 with bias_rows in {1, B} (conv bias + Dense_0(act(temb)), layerspp.py:272-273);
+ * skip: optional NHWC tensor of `Cout` channels ((x+h)/sqrt(2), layerspp.py:281-284; Combine 'sum' :66).
+ * `wdtype` selects the arithmetic: FD_BF16 = bf16 operands / f32 accumulate (v_mfma_f32_32x32x16_bf16),
+ * FD_F32 = exact f32 (v_mfma_f32_32x32x2_f32).  Channel counts must be multiples of 8 (in) / 4 (out). */
+int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const float* affine, const void* packed_w,
+              const float* bias, int bias_rows, const void* skip, float scale, void* out, int Cout, int B, int H, int W,
+              int ksize, int dtype, int wdtype, void* stream);
+
+/* Time embedding: GaussianFourierProjection -> Linear -> SiLU -> Linear (ncsnpp.py:263-274,
+ * layerspp.py:42-51); t [nt] float32 -> temb [nt][4*nf]. */
+int fd_time_embedding(const float* t, int nt, const float* gfp_w, int nf, const float* w1, const float* b1,
+                      const float* w2, const float* b2, float* temb, void* stream);
+/* out[r][o] = conv_bias[o] + dense_b[o] + sum_k dense_w[o][k] * silu(temb[r][k])  (layerspp.py:272-273). */
+int fd_temb_bias(const float* temb, int nt, int temb_dim, const float* dense_w, const float* dense_b,
+                 const float* conv_bias, int Cout, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Front / back end
+ * ---------------------------------------------------------------------------------------------- */
+
+/* normalize_noisy('noisy') + torch.stft(n_fft, hop, sym-Hann, center/reflect, onesided) + amplitude
+ * compression beta*|X|^alpha*e^{j angle X} + zero pad of the frame axis to T_pad
+ * (util/other.py:55-82, feature_extractors.py:86-96,118-128, util/other.py:25-52).
+ * y [B][L] f32 -> Y [B][1][n_fft/2+1][T_pad] complex64, normfac [B] f32.
+ * ws: fd_stft_workspace_bytes(B, L, n_fft, hop) bytes of scratch. */
+size_t fd_stft_workspace_bytes(int B, int L, int n_fft, int hop);
+int fd_stft_compress(const float* y, int B, int L, int n_fft, int hop, float alpha, float beta, int normalize,
+                     float* normfac, float* Y, int T_pad, void* ws, size_t ws_bytes, void* stream);
+/* Inverse: slice [:T] -> X/beta -> |.|^(1/alpha) -> torch.istft(length=L) -> * normfac
+ * (model.py:165-190, feature_extractors.py:98-109,130-139).  normfac may be NULL. */
+int fd_decompress_istft(const float* X, int B, int T, int T_pad, int n_fft, int hop, float alpha, float beta,
+                        const float* normfac, float* y, int L, void* ws, size_t ws_bytes, void* stream);
+int fd_num_frames(int L, int hop);     /* 1 + L / hop */
+int fd_padded_frames(int T);           /* next multiple of 64 */
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-model entry points
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fd_model fd_model;
+
+typedef struct fd_model_config {
+  int nf;                /* 64 */
+  int ch_mult[8];        /* {4,4,4,2} */
+  int num_levels;        /* 4 */
+  int num_res_blocks;    /* 1 */
+  int n_fft;             /* 1534 */
+  int hop;               /* 384 */
+  float alpha, beta;     /* 0.3, 0.33 */
+  int act_dtype;         /* FD_BF16 (bf16 storage + bf16 MFMA) or FD_F32 (f32 storage + exact f32 MFMA) */
+} fd_model_config;
+
+int fd_model_create(const fd_model_config* cfg, fd_model** out);
+void fd_model_destroy(fd_model* m);
+/* Number of parameter tensors the model expects, and the i-th name / shape (reference state_dict
+ * layout `backbone.all_modules.<i>.<...>`). */
+int fd_model_num_params(const fd_model* m);
+int fd_model_param_info(const fd_model* m, int i, const char** name, int* ndim, int shape[4]);
+/* Copy one parameter (float32, HOST pointer, contiguous, reference shape) into the model. */
+int fd_model_set_param(fd_model* m, const char* name, const float* host_data, long long numel);
+/* sigma_y: per-frequency curve [n_freq] (float64 host) or a scalar (n = 1) (model.py:399-419). */
+int fd_model_set_sigma_y(fd_model* m, const double* host_sigma, int n);
+/* Pack weights for MFMA and upload; must be called after all fd_model_set_param and before forward. */
+int fd_model_finalize(fd_model* m, void* stream);
+
+size_t fd_model_workspace_bytes(const fd_model* m, int B, int T_pad);
+/* v = NCSNpp(x, y, t): x, y, v complex64 [B][1][F][T_pad]; t float32 [nt] with nt in {1, B}
+ * (FlowModel.forward, model.py:470-474; ncsnpp.py:254-399). */
+int fd_ncsnpp_forward(fd_model* m, const float* x, const float* y, const float* t, int nt, float* v, int B, int T_pad,
+                      void* ws, size_t ws_bytes, void* stream);
+/* x0 = Y + sigma_fac * (sigma_y * noise) (model.py:512,530-536), then the fixed-step solve over
+ * t_span = linspace(0,1,N+1) (:513-514) -- torchdyn fixed-step semantics restated (oracle/flowdec_oracle.py
+ * odeint_fixed).  X (in: Y; out: final state) complex64 [B][1][F][T_pad]; noise complex64 same shape
+ * (standard complex normal, supplied by the caller so results are reproducible); traj (optional)
+ * receives all N+1 states.  use_graph != 0 captures the whole solve into a hipGraph cached per
+ * (B, T_pad, N, solver) and replays it. */
+int fd_ode_solve(fd_model* m, const float* Y, const float* noise, float sigma_fac, int N, int solver, float* X_out,
+                 float* traj, int B, int T_pad, void* ws, size_t ws_bytes, int use_graph, void* stream);
+size_t fd_enhance_workspace_bytes(const fd_model* m, int B, int L);
+/* FlowModel.enhance (model.py:476-528) end to end on device buffers: y [B][L] f32 -> x_hat [B][L] f32. */
+int fd_enhance(fd_model* m, const float* y, const float* noise, float sigma_fac, int N, int solver, float* x_hat, int B,
+               int L, void* ws, size_t ws_bytes, int use_graph, void* stream);
+
+/* Per-launch timing of the dominant kernel (conv MFMA) measured with HIP events on the launch stream;
+ * used by bench.py for the roofline object.  enable != 0 starts recording (forces eager launches). */
+int fd_profile_enable(fd_model* m, int enable);
+int fd_profile_read(fd_model* m, double* conv_ms_total, long long* conv_launches, double* conv_flops_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOWDEC_HIP_H */

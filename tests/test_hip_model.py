@@ -1,0 +1,152 @@
+"""GPU parity tests of the whole-model entry points (fd_ncsnpp_forward / fd_ode_solve / fd_enhance) through the
+reference-shaped Python API, against golden vectors produced by the reference and against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import flowdec_oracle as O
+from test_hip_ops import check, report
+
+pytestmark = pytest.mark.gpu
+
+# tolerance of the two arithmetic modes against the reference's fp32 results (relative L2):
+#   fp32 mode: exact-f32 MFMA, f32 storage -> differences are summation order / transcendental ulps only
+#   bf16 mode: bf16 operands + bf16 activation storage, f32 accumulate and f32 ODE state
+TOL_FWD = {"fp32": 2e-4, "bf16": 3e-2}
+TOL_WAVE = {"fp32": 5e-4, "bf16": 5e-2}
+
+_cache = {}
+
+
+def make_model(nf, seed, precision):
+    key = (nf, seed, precision)
+    if key not in _cache:
+        import flowdec_amd
+        m = flowdec_amd.from_preset("flowdec_75m", precision=precision, nf=nf)
+        sd = {k: torch.from_numpy(v) for k, v in O.random_state_dict(seed=seed, nf=nf).items()}
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not unexpected and all(not k.startswith("backbone.") for k in missing), (missing, unexpected)
+        _cache[key] = m.cuda()
+    return _cache[key]
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_ncsnpp_nf8_golden(prec):
+    g = load_golden("g8_ncsnpp_nf8.npz")
+    m = make_model(8, int(g["seed"]), prec)
+    out = m(cu(g["x"]), cu(g["y"]), torch.tensor(0.25, device="cuda"))  # 0-dim t like torchdyn passes it
+    assert out.shape == (2, 1, 768, 64) and out.dtype == torch.complex64
+    check(f"ncsnpp_nf8[{prec}]", out.cpu().numpy(), g["out_t025"], TOL_FWD[prec])
+    out2 = m.backbone(cu(g["x"]), cu(g["y"]), torch.tensor([0.1, 0.9], device="cuda"))  # per-sample t
+    check(f"ncsnpp_nf8_per_sample_t[{prec}]", out2.cpu().numpy(), g["out_t01_09"], TOL_FWD[prec])
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_ncsnpp_full_width_golden(prec):
+    g = load_golden("g10_ncsnpp_nf64.npz")
+    m = make_model(64, int(g["seed"]), prec)
+    out = m(cu(g["x"]), cu(g["y"]), torch.tensor([0.5], device="cuda"))
+    check(f"ncsnpp_nf64[{prec}]", out.cpu().numpy(), g["out"], TOL_FWD[prec])
+    # deterministic: same inputs -> bit-identical output
+    out_b = m(cu(g["x"]), cu(g["y"]), torch.tensor([0.5], device="cuda"))
+    assert torch.equal(torch.view_as_real(out), torch.view_as_real(out_b))
+
+
+def test_ncsnpp_batch_independence():
+    """Clips are independent end to end (what the multi-GPU batch split relies on)."""
+    g = load_golden("g8_ncsnpp_nf8.npz")
+    m = make_model(8, int(g["seed"]), "fp32")
+    x, y = cu(g["x"]), cu(g["y"])
+    t = torch.tensor([0.25], device="cuda")
+    both = m(x, y, t)
+    one = m(x[1:2].contiguous(), y[1:2].contiguous(), t)
+    assert rel_err(one.cpu().numpy(), both[1:2].cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("solver,N", [("euler", 6), ("midpoint", 3), ("heun2", 3), ("heun2_eulerlast", 3)])
+def test_enhance_golden(solver, N, prec):
+    g = load_golden("g9_enhance_nf8.npz")
+    m = make_model(8, int(g["seed"]), prec)
+    y = torch.from_numpy(g["y"])                       # CPU input -> output must come back on the CPU (model.py:524)
+    x = m.enhance(y, N=N, solver=solver, noise=torch.from_numpy(g["noise"]))
+    assert x.shape == (2, 1, 24000) and x.device.type == "cpu" and x.dtype == torch.float32
+    check(f"enhance[{solver},N={N},{prec}]", x.numpy(), g[f"{solver}_N{N}"], TOL_WAVE[prec])
+
+
+def test_enhance_graph_equals_eager():
+    g = load_golden("g9_enhance_nf8.npz")
+    m = make_model(8, int(g["seed"]), "bf16")
+    y, nz = torch.from_numpy(g["y"]).cuda(), torch.from_numpy(g["noise"])
+    a = m.enhance(y, N=3, solver="midpoint", noise=nz, use_graph=False)
+    b = m.enhance(y, N=3, solver="midpoint", noise=nz, use_graph=True)    # capture + launch
+    c = m.enhance(y, N=3, solver="midpoint", noise=nz, use_graph=True)    # replay
+    assert a.is_cuda and torch.equal(a, b) and torch.equal(b, c)
+
+
+def test_enhance_shapes_info_and_traj():
+    g = load_golden("g9_enhance_nf8.npz")
+    m = make_model(8, int(g["seed"]), "fp32")
+    nz = torch.from_numpy(g["noise"])
+    x1 = m.enhance(torch.from_numpy(g["y"][0, 0]), N=2, solver="euler", noise=nz[:1])   # 1-D in -> 1-D out
+    assert x1.shape == (24000,)
+    check("enhance_1d", x1.numpy(), g["euler_N2_1d"], TOL_WAVE["fp32"])
+    xh, info = m.enhance(torch.from_numpy(g["y"]), N=2, solver="euler", noise=nz, return_preprocess_info=True)
+    assert set(info) == {"orig_length", "normfac", "undo_pad_fn", "squeeze_dims"}
+    assert info["orig_length"] == 24000 and info["squeeze_dims"] == 0 and info["normfac"].shape == (2, 1, 1)
+    assert np.allclose(info["normfac"].cpu().numpy().ravel(), np.abs(g["y"]).max(axis=(1, 2)), rtol=1e-6)
+    assert info["undo_pad_fn"](torch.zeros(2, 1, 768, 64)).shape[-1] == 63
+    traj, waves = m.enhance(torch.from_numpy(g["y"]), N=2, solver="euler", noise=nz, return_traj=True)
+    assert traj.shape == (3, 2, 1, 768, 64) and len(waves) == 3
+    norms = np.array([float(torch.view_as_real(X).double().pow(2).sum().sqrt()) for X in traj])
+    assert np.allclose(norms, g["traj_feat_norms"], rtol=1e-3)
+    check("enhance_traj_last", waves[-1].cpu().numpy(), g["traj_last_wave"], TOL_WAVE["fp32"])
+
+
+def test_enhance_seeded_noise_reproducible():
+    g = load_golden("g9_enhance_nf8.npz")
+    m = make_model(8, int(g["seed"]), "bf16")
+    y = torch.from_numpy(g["y"]).cuda()
+    a = m.enhance(y, N=1, generator=torch.Generator(device="cuda").manual_seed(5))
+    b = m.enhance(y, N=1, generator=torch.Generator(device="cuda").manual_seed(5))
+    c = m.enhance(y, N=1, generator=torch.Generator(device="cuda").manual_seed(6))
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert torch.isfinite(a).all()
+
+
+def test_errors():
+    import flowdec_amd
+    g = load_golden("g9_enhance_nf8.npz")
+    m = make_model(8, int(g["seed"]), "bf16")
+    with pytest.raises(ValueError):
+        m.enhance(torch.zeros(1, 1, 24000), solver="rk4")
+    with pytest.raises(NotImplementedError):
+        m.enhance(torch.zeros(1, 1, 24000), with_grad=True)
+    with pytest.raises(RuntimeError):
+        m.enhance(torch.zeros(2, 2, 24000))           # two channels
+    with pytest.raises(RuntimeError):
+        m.enhance(torch.zeros(1, 1, 500), N=1)        # shorter than the reflect padding
+    cpu_model = flowdec_amd.from_preset("flowdec_75m", nf=8)
+    with pytest.raises(RuntimeError):
+        cpu_model.enhance(torch.zeros(1, 1, 24000), N=1)   # no CPU path: must fail loudly
+
+
+def test_full_size_properties():
+    """BASELINE config 2 shape (B=8 x 2 s, Euler N=6 is run by bench.py); here one full-width forward at
+    B=2 x 2 s checks size-independent properties: finite output, batch independence, determinism."""
+    m = make_model(64, 64, "bf16")
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(2, 1, 768, 256, dtype=torch.complex64, device="cuda", generator=gen)
+    y = torch.randn(2, 1, 768, 256, dtype=torch.complex64, device="cuda", generator=gen)
+    t = torch.tensor([0.3], device="cuda")
+    v = m(x, y, t)
+    assert torch.isfinite(torch.view_as_real(v)).all()
+    v0 = m(x[:1].contiguous(), y[:1].contiguous(), t)
+    e = rel_err(v0.cpu().numpy(), v[:1].cpu().numpy())
+    report("full_size_batch_independence", e, 1e-6)
+    assert e < 1e-6
