@@ -13,8 +13,11 @@ pytestmark = pytest.mark.gpu
 # tolerance of the two arithmetic modes against the reference's fp32 results (relative L2):
 #   fp32 mode: exact-f32 MFMA, f32 storage -> differences are summation order / transcendental ulps only
 #   bf16 mode: bf16 operands + bf16 activation storage, f32 accumulate and f32 ODE state
+# measured floors on the nf=8 golden model: rounding ONLY the conv operands to bf16 in the oracle (everything else f32)
+# already gives 1.2e-2 on one forward and 6.4e-2 on the final waveform (|X|^(1/0.3) decompression amplifies 3.3x);
+# the HIP bf16 path measures 1.6e-2 / 8-10e-2, the f32 path 2e-6 / 1e-5.
 TOL_FWD = {"fp32": 2e-4, "bf16": 3e-2}
-TOL_WAVE = {"fp32": 5e-4, "bf16": 5e-2}
+TOL_WAVE = {"fp32": 5e-4, "bf16": 1.5e-1}
 
 _cache = {}
 
