@@ -33,12 +33,16 @@ SIGNATURES = {
     "fd_upfirdn2d_out_size": (c_int, [c_int] * 6),
     "fd_fused_bias_act": (c_int, [_P, _P, _P, c_ll, c_int, c_int, c_int, c_float, c_float, _P]),
     "fd_fir_resample": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "fd_channel_sums_tiles": (c_int, [c_int, c_int]),
     "fd_channel_sums": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "fd_gn_finalize": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_ll, c_float, _P]),
-    "fd_conv_packed_bytes": (c_ll, [c_int] * 5),
-    "fd_conv_pack_weights": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "fd_conv2d": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, _P, c_float, _P, c_int, c_int, c_int, c_int, c_int,
-                          c_int, c_int, _P]),
+    "fd_gn_finalize": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_ll, c_float, _P]),
+    "fd_conv_packed_bytes": (c_ll, [c_int] * 7),
+    "fd_conv_pack_weights": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "fd_conv_cout_pad": (c_int, [c_int]),
+    "fd_conv_stats_tiles": (c_int, [c_int, c_int]),
+    "fd_conv2d": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P, c_int, _P, c_float, _P, c_int, _P,
+                          c_int, c_int, c_int, c_int, c_int, _P]),
+    "fd_tuning_set": (c_int, [C.c_char_p, c_int]),
     "fd_time_embedding": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, _P]),
     "fd_temb_bias": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
     "fd_stft_workspace_bytes": (c_size_t, [c_int] * 4),

@@ -42,7 +42,8 @@ static inline int fd_cdiv(long long a, long long b) { return (int)((a + b - 1) /
 static inline size_t fd_dtype_size(int dtype) { return dtype == FD_BF16 ? 2 : 4; }
 
 // ---- device helpers ---------------------------------------------------------------------------
-__device__ __forceinline__ float fd_silu(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division (10 VALU instructions)
+__device__ __forceinline__ float fd_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 template <typename T>
 struct Elem;

@@ -1,22 +1,27 @@
-// conv_mfma.hip -- implicit-GEMM 3x3 / 1x1 convolution on the gfx950 matrix cores.
+// conv_mfma.hip -- implicit-GEMM 3x3 / 1x1 convolution on the gfx950 matrix cores (v2).
 //
 // Replaces the reference's nn.Conv2d calls (ddpm_conv3x3 / ddpm_conv1x1,
-// flowdec/backbones/ncsnpp_utils/layers.py:110-134) together with the GroupNorm+SiLU that
-// precedes them (layerspp.py:253,274), the time-embedding bias (:272-273), the skip add and
-// 1/sqrt(2) rescale (:281-284) and the channel concat of the up path (ncsnpp.py:337).
+// flowdec/backbones/ncsnpp_utils/layers.py:110-134) together with what surrounds them in
+// ResnetBlockBigGANpp.forward (layerspp.py:252-284): the GroupNorm+SiLU in front (:253,:274), the
+// time-embedding bias (:272-273), the 1x1 shortcut conv Conv_2 (:278-279, folded in as extra K steps),
+// the residual add and 1/sqrt(2) (:281-284), the channel concat of the up path (ncsnpp.py:337), and the
+// statistics pass of the NEXT GroupNorm (per-tile partial sums of the output).
 //
-// Mapping (NHWC activations, one workgroup = one 16x16 pixel tile x BN output channels):
-//   D[cout][pixel] += W[cout][k] * X[k][pixel],  k = (tap, cin)      (weights are the MFMA "A"
-//   operand so that each lane ends up with 4 consecutive couts of ONE pixel -> 8/16-byte stores)
-//   * the K loop walks 64-byte channel chunks (32 bf16 / 16 f32 channels); per chunk the (TH+2)x(TW+2)
-//     halo tile is staged ONCE in LDS and re-used by all 9 taps as shifted windows;
-//   * per (chunk, tap) step the BN x 64 B weight slab is staged in LDS; both are double-buffered and
-//     register-prefetched one step ahead so there is a single barrier per step;
-//   * the operand load applies silu(a*x+d) (GroupNorm folded to a per-(b,c) affine) and the zero
-//     padding AFTER it, exactly like conv(pad(act(gn(x))));
-//   * LDS rows are 64 B; the 16-byte slot index is XOR-swizzled with (row>>2)&3 and the halo pitch is
-//     24 (= 8 mod 16), which makes every ds_read_b128 lane group hit 16 distinct slots (conflict-free
-//     for the 4x8-pixel MFMA patches used here).
+// Mapping (NHWC activations; one workgroup = one 16x16 pixel tile x BN output channels):
+//   D[cout][pixel] += W[cout][k] * X[k][pixel],  k = (segment, channel chunk, tap)
+//   * weights are the MFMA "A" operand, so every lane ends up with 4 consecutive couts of one pixel;
+//   * K walks 64-byte channel chunks (32 bf16 / 16 f32 channels).  Per chunk the 18x18 halo tile is staged
+//     once in LDS and reused by the 9 taps as shifted windows (ds_read immediates, taps fully unrolled);
+//   * per (chunk, tap) step a BN x 64 B weight slab is staged; weights/halo are register-prefetched one
+//     step / one chunk ahead through buffer (SRD) loads, one barrier per step;
+//   * the operand load applies silu(a*x+d) (GroupNorm folded to a per-(b,c) affine), zero padding after it;
+//   * LDS rows are padded to 80 B (5 x 16 B, coprime with the 16 slots of a 256 B bank row) and the halo
+//     pitch is 24 pixels (= 8 mod 16): every ds_read_b128 lane group hits 16 distinct slots, no swizzle;
+//   * epilogue: accumulators are transposed through LDS so that global traffic (skip read, output write) is
+//     16 B per lane and fully coalesced; bias / skip / scale are applied there, and per-channel sum / sum of
+//     squares of the f32 result are reduced per tile for the consumer GroupNorm (deterministic, no atomics).
+#include <string.h>
+
 #include "common.h"
 #include "internal.h"
 
@@ -24,20 +29,30 @@ namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int ROWB = 80;   // LDS / packed-weight row pitch in bytes (64 B of data + 16 B pad)
+constexpr int PITCH = 24;  // halo row pitch in pixels
+
+struct Seg {
+  const void* src;
+  int C;         // channels of this tensor
+  int aff_off;   // channel offset into the affine table, or -1 (no activation)
+  int taps;      // 9 or 1
+};
+
 struct ConvArgs {
-  const void* in0; const void* in1;
-  int C0, C1;
-  const float* affine;     // [B][C0+C1][2] or null
-  const void* w;           // packed [chunk][tap][CoutPad][64 bytes]
-  const float* bias;       // [bias_rows][Cout] or null
-  int bias_rows;
-  const void* skip;        // [B,H,W,Cout] or null
+  Seg seg[4];
+  int nseg;
+  const float* affine; int affC;   // [B][affC][2]
+  const void* w;                   // packed [step][CoutPad][ROWB bytes]
+  long long w_bytes;
+  const float* bias; int bias_rows;
+  const void* skip;
   float scale;
   void* out;
   int Cout, CoutPad;
+  float* stats;                    // [B][tiles_h*tiles_w][CoutPad][2] or null
   int B, H, W;
   int tiles_h, tiles_w, tiles_n;
-  int nchunk0, nchunks;    // chunks taken from in0, total chunks
 };
 
 template <typename T>
@@ -45,65 +60,91 @@ struct Math;
 template <>
 struct Math<bf16> {
   static constexpr int EPS = 8;  // elements per 16-byte slot
-  __device__ static void mma(f32x16& acc, const u32x4& wf, const u32x4& pf) {
-    bf16x8 a = __builtin_bit_cast(bf16x8, wf), b = __builtin_bit_cast(bf16x8, pf);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  __device__ static __forceinline__ void mma(f32x16& acc, const u32x4& wf, const u32x4& pf) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, pf), acc, 0, 0, 0);
   }
 };
 template <>
 struct Math<float> {
   static constexpr int EPS = 4;
-  __device__ static void mma(f32x16& acc, const u32x4& wf, const u32x4& pf) {
-    f32x4 a = __builtin_bit_cast(f32x4, wf), b = __builtin_bit_cast(f32x4, pf);
+  __device__ static __forceinline__ void mma(f32x16& acc, const u32x4& wf, const u32x4& pf) {
+    const f32x4 a = __builtin_bit_cast(f32x4, wf), b = __builtin_bit_cast(f32x4, pf);
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
   }
 };
 
-// ad[j] holds the (a, d) pairs of channels 2j and 2j+1 of the slot: {a0, d0, a1, d1}
+// silu(a*x+d) on the EPS channels of one 16-byte slot; the (a,d) pairs are read from the LDS table two channels
+// at a time ({a0,d0,a1,d1} per ds_read_b128) to keep the register footprint small
 template <typename T, int EPS>
-__device__ __forceinline__ u32x4 transform_slot(u32x4 raw, const f32x4 (&ad)[EPS / 2]) {
+__device__ __forceinline__ u32x4 transform_slot(u32x4 raw, const char* ad) {
+  u32x4 out;
   if constexpr (sizeof(T) == 2) {
-    bf16x8 v = __builtin_bit_cast(bf16x8, raw);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (bf16)fd_silu(fmaf((float)v[i], ad[i >> 1][2 * (i & 1)], ad[i >> 1][2 * (i & 1) + 1]));
-    return __builtin_bit_cast(u32x4, v);
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ad + 16 * j);
+      const unsigned u = raw[j];
+      const float x0 = __builtin_bit_cast(float, u << 16), x1 = __builtin_bit_cast(float, u & 0xffff0000u);
+      bf16x2 r = {(bf16)fd_silu(fmaf(x0, a[0], a[1])), (bf16)fd_silu(fmaf(x1, a[2], a[3]))};
+      out[j] = __builtin_bit_cast(unsigned, r);
+    }
   } else {
-    f32x4 v = __builtin_bit_cast(f32x4, raw);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = fd_silu(fmaf(v[i], ad[i >> 1][2 * (i & 1)], ad[i >> 1][2 * (i & 1) + 1]));
-    return __builtin_bit_cast(u32x4, v);
+    for (int j = 0; j < 2; ++j) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ad + 16 * j);
+      // NB: copy the vector element to a scalar first -- __builtin_bit_cast applied directly to an ext-vector element
+      // lvalue reads element 0 for every index (hipcc / ROCm 7.2)
+      const unsigned u0 = raw[2 * j], u1 = raw[2 * j + 1];
+      const float y0 = fd_silu(fmaf(__builtin_bit_cast(float, u0), a[0], a[1]));
+      const float y1 = fd_silu(fmaf(__builtin_bit_cast(float, u1), a[2], a[3]));
+      out[2 * j] = __builtin_bit_cast(unsigned, y0);
+      out[2 * j + 1] = __builtin_bit_cast(unsigned, y1);
+    }
   }
+  return out;
 }
 
-template <int TAPS, int WM, int WN, int MT, int NT>
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+constexpr int AFF_BYTES = 512 * 8;  // per-(b,c) (a,d) pairs of up to 512 activated input channels, staged in LDS
+constexpr int HLAG = 1;             // a halo slot loaded in phase B of tap i is transformed + stored in phase A of tap i + HLAG
+
+template <int WM, int WN, int MT, int NT>
 struct Geo {
   static constexpr int NTH = 64 * WM * WN;
-  static constexpr int HALO = TAPS == 9 ? 1 : 0;
-  static constexpr int NP = WM * MT;       // 4x8-pixel patches per tile
-  static constexpr int TH = 4 * (NP / 2);  // patches arranged (NP/2) x 2
-  static constexpr int TW = 16;
-  static constexpr int HH = TH + 2 * HALO, HW = TW + 2 * HALO;
-  static constexpr int PITCH = 24;         // halo row pitch in pixels, = 8 (mod 16)
+  static constexpr int NP = WM * MT;       // 4x8-pixel patches per tile, arranged (NP/2) x 2
+  static constexpr int TH = 4 * (NP / 2), TW = 16;
+  static constexpr int HH = TH + 2, HW = TW + 2;
   static constexpr int BN = WN * NT * 32;
-  static constexpr int HALO_BYTES = HH * PITCH * 64;
-  static constexpr int W_BYTES = BN * 64;
-  static constexpr int LDS_BYTES = 2 * HALO_BYTES + 2 * W_BYTES;
-  static constexpr int PPP = NTH / 4;      // rows (pixels / couts) covered per loader pass
+  static constexpr int HALO_BYTES = HH * PITCH * ROWB;
+  static constexpr int W_BYTES = BN * ROWB;
+  static constexpr int MAIN_BYTES = 2 * HALO_BYTES + 2 * W_BYTES + AFF_BYTES;
+  // epilogue staging: one M-tile row of the block (WM * 32 pixels) x BN floats (+16 B pad per pixel)
+  static constexpr int EP_PIX = WM * 32;
+  static constexpr int EP_ROWB = BN * 4 + 16;
+  static constexpr int EP_BYTES = EP_PIX * EP_ROWB;
+  static constexpr int OCT = BN / 8;             // 8-channel groups per pixel
+  static constexpr int PPASS = NTH / OCT;        // pixels per epilogue pass
+  static constexpr int NPASS = EP_PIX / PPASS;
+  static constexpr int ST_BYTES = PPASS * BN * 2 * 4;
+  static constexpr int LDS_BYTES = cmax(MAIN_BYTES, cmax(EP_BYTES, ST_BYTES));
+  static constexpr int PPP = NTH / 4;            // rows covered per loader pass (4 slots per row)
   static constexpr int HITER = (HH * HW + PPP - 1) / PPP;
-  static constexpr int WITER = (BN + PPP - 1) / PPP;
+  static_assert(EP_PIX % PPASS == 0, "epilogue pass geometry");
+  static_assert(HITER + HLAG <= 9, "halo slots must fit the 9-tap schedule");
 };
 
-template <typename T, int TAPS, int WM, int WN, int MT, int NT>
+template <typename T, int WM, int WN, int MT, int NT>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) {
-  using G = Geo<TAPS, WM, WN, MT, NT>;
+  using G = Geo<WM, WN, MT, NT>;
   constexpr int EPS = Math<T>::EPS;
   constexpr int CK = 4 * EPS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const hbuf = smem;
   char* const wbuf = smem + 2 * G::HALO_BYTES;
+  char* const afftab = wbuf + 2 * G::W_BYTES;
 
-  // ---- tile decode with XCD-aware remap: consecutive logical tiles share an XCD's L2 ------------
+  // ---- tile decode with XCD-aware remap: consecutive logical tiles share an XCD's L2 ------------------------
   const int bid = blockIdx.x, nblk = gridDim.x;
   int lid;
   {
@@ -122,93 +163,79 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const int q = t & 3;        // 16-byte slot inside the 64-byte chunk row
   const int prow = t >> 2;
 
-  // ---- loader bookkeeping (independent of the chunk).  Loads are UNCONDITIONAL (addresses clamped to a
-  // valid pixel / row) and validity is applied when the registers are written to LDS: conditional loads
-  // make hipcc keep the staging registers in scratch and wait vmcnt(0) right after each load. -----------
-  int pix[G::HITER];   // clamped global pixel index
-  int hlds[G::HITER];  // LDS byte offset of the slot
+  // ---- loader bookkeeping.  Loads are unconditional (clamped addresses); validity is applied when the
+  // registers are written to LDS. ----------------------------------------------------------------------------
+  int pixl[G::HITER];   // clamped pixel index inside image b
+  int hlds[G::HITER];   // LDS byte offset of the slot
   unsigned pvalid = 0, hexist = 0;
 #pragma unroll
   for (int i = 0; i < G::HITER; ++i) {
     const int hp = prow + i * G::PPP;
     const int hpc = hp < G::HH * G::HW ? hp : 0;
     const int hr = hpc / G::HW, hc = hpc - hr * G::HW;
-    const int gh = h0 - G::HALO + hr, gw = w0 - G::HALO + hc;
+    const int gh = h0 - 1 + hr, gw = w0 - 1 + hc;
     const bool ok = gh >= 0 && gh < H && gw >= 0 && gw < W;
-    pix[i] = ok ? ((b * H + gh) * W + gw) : (b * H * W);
-    const int hpl = hr * G::PITCH + hc;
-    hlds[i] = hpl * 64 + ((q ^ ((hpl >> 2) & 3)) << 4);
+    pixl[i] = ok ? gh * W + gw : 0;
+    hlds[i] = (hr * PITCH + hc) * ROWB + q * 16;
     if (hp < G::HH * G::HW) { hexist |= 1u << i; if (ok) pvalid |= 1u << i; }
   }
+  const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+  const size_t img_elems = (size_t)H * W;
 
   u32x4 hreg[G::HITER];
-  u32x4 wreg[G::WITER];
-  f32x4 af[EPS / 2];
-  bool chan_ok = false;
 
-  auto load_halo = [&](int chunk) {
-    const bool second = chunk >= p.nchunk0;
-    const T* src = reinterpret_cast<const T*>(second ? p.in1 : p.in0);
-    const int Cs = second ? p.C1 : p.C0;
-    int c = (second ? chunk - p.nchunk0 : chunk) * CK + q * EPS;
-    chan_ok = c < Cs;
-    c = chan_ok ? c : 0;
-#pragma unroll
-    for (int i = 0; i < G::HITER; ++i) hreg[i] = *reinterpret_cast<const u32x4*>(src + (size_t)pix[i] * Cs + c);
-    if (p.affine != nullptr) {
-      const float* ap = p.affine + ((size_t)b * (p.C0 + p.C1) + (second ? p.C0 : 0) + c) * 2;
-#pragma unroll
-      for (int e = 0; e < EPS / 2; ++e) af[e] = *reinterpret_cast<const f32x4*>(ap + 4 * e);
-    }
+  // state of the chunk being prefetched (all wave-uniform)
+  __amdgpu_buffer_rsrc_t nsrd = wsrd;
+  int nC = 0, nc = 0, naff = -1;
+  bool nchan_ok = false;
+  auto next_chunk = [&](int s, int ch) {
+    const Seg sg = p.seg[s];
+    const T* src = reinterpret_cast<const T*>(sg.src) + (size_t)b * img_elems * sg.C;
+    nsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(src), 0, (int)(img_elems * sg.C * sizeof(T)), 0x00020000);
+    nC = sg.C;
+    const int c = ch * CK + q * EPS;
+    nchan_ok = c < sg.C;
+    nc = nchan_ok ? c : 0;
+    naff = sg.aff_off >= 0 ? (sg.aff_off + nc) * 8 : -1;  // byte offset of this slot's (a,d) pairs in the LDS table
   };
-  auto store_halo = [&](int buf) {
-    char* dst = hbuf + buf * G::HALO_BYTES;
-    const unsigned ok_mask = chan_ok ? pvalid : 0u;
-#pragma unroll
-    for (int i = 0; i < G::HITER; ++i) {
-      u32x4 v = hreg[i];
-      if (p.affine != nullptr) v = transform_slot<T, EPS>(v, af);
-      if (!((ok_mask >> i) & 1u)) v = u32x4{0u, 0u, 0u, 0u};  // zero padding AFTER the activation
-      if ((hexist >> i) & 1u) *reinterpret_cast<u32x4*>(dst + hlds[i]) = v;
-    }
+  auto load_halo_slot = [&](int i) { hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(nsrd, (pixl[i] * nC + nc) * (int)sizeof(T), 0, 0); };
+  auto store_halo_slot = [&](int i, int buf) {
+    u32x4 v = hreg[i];
+    if (naff >= 0) v = transform_slot<T, EPS>(v, afftab + naff);
+    if (!(nchan_ok && ((pvalid >> i) & 1u))) v = u32x4{0u, 0u, 0u, 0u};  // zero padding AFTER the activation
+    if ((hexist >> i) & 1u) *reinterpret_cast<u32x4*>(hbuf + buf * G::HALO_BYTES + hlds[i]) = v;
   };
-  constexpr bool W_EXACT = (G::BN % G::PPP) == 0;
-  auto load_w = [&](int step) {  // step = chunk * TAPS + tap; packed layout is [step][CoutPad][64 B]
-    const char* src = reinterpret_cast<const char*>(p.w) + ((size_t)step * p.CoutPad + n0) * 64 + q * 16;
-#pragma unroll
-    for (int i = 0; i < G::WITER; ++i) {
-      const int row = W_EXACT ? prow + i * G::PPP : (prow + i * G::PPP) % G::BN;
-      wreg[i] = *reinterpret_cast<const u32x4*>(src + (size_t)row * 64);
-    }
-  };
-  auto store_w = [&](int buf) {
+  // Weight slab of one step: BN rows x 80 B, contiguous in global memory with exactly the LDS image -> copied by
+  // direct-to-LDS DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB per wave instruction, destination =
+  // wave-uniform base + lane * 16).  No VGPR staging, no ds_write.
+  auto dma_w = [&](int step, int buf) {
+    constexpr int UNITS = G::W_BYTES / 16;
+    const char* src = reinterpret_cast<const char*>(p.w) + ((size_t)step * p.CoutPad + n0) * ROWB;
     char* dst = wbuf + buf * G::W_BYTES;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6), ln = t & 63;
 #pragma unroll
-    for (int i = 0; i < G::WITER; ++i) {
-      const int row = prow + i * G::PPP;
-      if (W_EXACT || row < G::BN) *reinterpret_cast<u32x4*>(dst + row * 64 + ((q ^ ((row >> 2) & 3)) << 4)) = wreg[i];
+    for (int k = 0; k < (UNITS + G::NTH - 1) / G::NTH; ++k) {
+      const int pce = wv + k * (G::NTH / 64);
+      if (pce * 64 + ln < UNITS)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pce * 1024 + ln * 16),
+                                         (__attribute__((address_space(3))) void*)(dst + pce * 1024), 16, 0, 0);
     }
   };
 
-  // ---- per-lane fragment coordinates ----------------------------------------------------------------
+  // ---- per-lane fragment coordinates ---------------------------------------------------------------------------
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave - wm * WN;
   const int l31 = lane & 31, lh = lane >> 5;
-  int hp_base[MT];  // halo pixel index of this lane's pixel for tap (0,0)
+  int pbase[MT];  // LDS byte offset (inside a halo buffer) of this lane's pixel for tap (0,0), k-half folded in
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
     const int pi = wm * MT + mi;
     const int r = 4 * (pi >> 1) + (l31 >> 3), c = 8 * (pi & 1) + (l31 & 7);
-    hp_base[mi] = r * G::PITCH + c;
+    pbase[mi] = (r * PITCH + c) * ROWB + lh * 16;
   }
-  int wrow_off[NT];  // byte offset of this lane's weight row, swizzle term kept separately
-  int wrow_sw[NT];
+  int wbase[NT];
 #pragma unroll
-  for (int nj = 0; nj < NT; ++nj) {
-    const int row = (wn * NT + nj) * 32 + l31;
-    wrow_off[nj] = row * 64;
-    wrow_sw[nj] = (row >> 2) & 3;
-  }
+  for (int nj = 0; nj < NT; ++nj) wbase[nj] = ((wn * NT + nj) * 32 + l31) * ROWB + lh * 16;
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -218,152 +245,287 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
 
-  // ---- pipeline ---------------------------------------------------------------------------------------
-  const int nsteps = p.nchunks * TAPS;
-  load_halo(0);
-  load_w(0);
-  store_halo(0);
-  store_w(0);
-  __syncthreads();
+  // ---- pipeline ----------------------------------------------------------------------------------------------------
+  // Steps s = (chunk, tap).  Per step every wave issues 2 x (MT*NT) MFMAs (k-halves ks = 0, 1).  The barrier sits in the
+  // MIDDLE of a step and the operand fragments are software-pipelined across it, so that each wave's LDS reads overlap
+  // its own MFMAs.  All global traffic is issued right after the barrier and has one full step to land (the barrier's
+  // implicit vmcnt(0) is then free):
+  //   phase A:  [store halo slot regs->LDS] | read frags(s, ks=1) || MFMA(s, ks=0)
+  //   barrier   (w(s+1) DMA landed, halo slots published, all reads of w(s) done)
+  //   phase B:  DMA w(s+2) -> buffer of w(s) | [load halo slot global->regs] | read frags(s+1, ks=0) || MFMA(s, ks=1)
+  if (p.affine) {  // stage the affine table of image b: [affC] x (a, d)
+    const float* ap = p.affine + (size_t)b * p.affC * 2;
+    for (int i = t; i < p.affC / 2; i += G::NTH) *reinterpret_cast<f32x4*>(afftab + i * 16) = *reinterpret_cast<const f32x4*>(ap + i * 4);
+    __syncthreads();
+  }
+  int n9 = 0, n1 = 0;
+  for (int s = 0; s < p.nseg; ++s) {
+    const int nch = (p.seg[s].C + CK - 1) / CK;
+    if (p.seg[s].taps == 9) n9 += nch; else n1 += nch;
+  }
+  const int nsteps = n9 * 9 + n1;
+  constexpr int CENTER = (PITCH + 1) * ROWB;
 
-  int chunk = 0, tap = 0;
-  for (int step = 0; step < nsteps; ++step) {
-    const bool more = step + 1 < nsteps;
-    const bool new_chunk = more && (tap == TAPS - 1);
-    if (more) load_w(step + 1);
-    if (new_chunk) load_halo(chunk + 1);
-
-    const char* hb = hbuf + (chunk & 1) * G::HALO_BYTES;
-    const char* wb = wbuf + (step & 1) * G::W_BYTES;
-    const int dy = (TAPS == 9) ? tap / 3 : 0;
-    const int dx = (TAPS == 9) ? tap - dy * 3 : 0;
-    const int tap_off = dy * G::PITCH + dx;
+  // Every barrier of the main loop must first drain this wave's LDS-DMA (and halo loads): hipcc's own waitcnt insertion
+  // loses the pending global_load_lds across the loop back-edge (it emitted a bare lgkmcnt(0) before the first barrier of
+  // the unrolled body), which let other waves read a weight piece that had not landed yet.
+  auto block_sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  u32x4 wfA[NT], pfA[MT], wfB[NT], pfB[MT];
+  auto read_frags = [&](u32x4 (&wf)[NT], u32x4 (&pf)[MT], const char* hb, const char* wb, int off) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int kq = 2 * ks + lh;
-      u32x4 wf[NT], pf[MT];
+    for (int nj = 0; nj < NT; ++nj) wf[nj] = *reinterpret_cast<const u32x4*>(wb + wbase[nj]);
 #pragma unroll
-      for (int nj = 0; nj < NT; ++nj)
-        wf[nj] = *reinterpret_cast<const u32x4*>(wb + wrow_off[nj] + ((kq ^ wrow_sw[nj]) << 4));
+    for (int mi = 0; mi < MT; ++mi) pf[mi] = *reinterpret_cast<const u32x4*>(hb + pbase[mi] + off);
+  };
+  // MFMAs of one k-half with the NEXT fragment reads issued right after the first MFMA: the compiler's s_waitcnt
+  // before the first MFMA then only covers the (old) fragments it consumes, and the new reads fly under the other MFMAs.
+  auto mma_then = [&](const u32x4 (&wf)[NT], const u32x4 (&pf)[MT], auto&& issue_reads) {
+    __builtin_amdgcn_sched_barrier(0);
+    Math<T>::mma(acc[0][0], wf[0], pf[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_reads();
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi) {
-        const int hp = hp_base[mi] + tap_off;
-        pf[mi] = *reinterpret_cast<const u32x4*>(hb + hp * 64 + ((kq ^ ((hp >> 2) & 3)) << 4));
-      }
+    for (int nj = 0; nj < NT; ++nj)
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
+        if (nj + mi > 0) Math<T>::mma(acc[mi][nj], wf[nj], pf[mi]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  int step = 0, hcur = 0;
+  next_chunk(0, 0);
 #pragma unroll
-        for (int nj = 0; nj < NT; ++nj) Math<T>::mma(acc[mi][nj], wf[nj], pf[mi]);
+  for (int i = 0; i < G::HITER; ++i) load_halo_slot(i);
+  dma_w(0, 0);
+  if (nsteps > 1) dma_w(1, 1);
+#pragma unroll
+  for (int i = 0; i < G::HITER; ++i) store_halo_slot(i, 0);
+  block_sync();
+  read_frags(wfA, pfA, hbuf, wbuf, n9 > 0 ? 0 : CENTER);  // (the k-half ks = 1 is addressed by passing hb + 32 / wb + 32)
+
+  int cs = 0, cch = 0;  // (segment, chunk) cursor
+  auto advance = [&](int& s_, int& ch_) {
+    ++ch_;
+    if (ch_ >= (p.seg[s_].C + CK - 1) / CK) { ++s_; ch_ = 0; }
+  };
+
+  // Two sequential loops (all 9-tap chunks, then all 1-tap shortcut chunks) so that each loop has a single MFMA
+  // site pair: with both tap counts inside one loop the compiler keeps two copies of the 128-register accumulator.
+  for (int i = 0; i < n9; ++i) {
+    const bool last_chunk = (i == n9 - 1) && n1 == 0;
+    advance(cs, cch);
+    if (!last_chunk) next_chunk(cs, cch);
+    const char* hb = hbuf + hcur * G::HALO_BYTES;
+    const char* hbn = hbuf + (hcur ^ 1) * G::HALO_BYTES;
+    const int first_off_next = (i == n9 - 1) ? CENTER : 0;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int imm = ((tap / 3) * PITCH + (tap % 3)) * ROWB;
+      const int imm_next = (((tap + 1) / 3) * PITCH + ((tap + 1) % 3)) * ROWB;
+      const bool m1 = step + 1 < nsteps, m2 = step + 2 < nsteps;
+      const char* wb = wbuf + (step & 1) * G::W_BYTES;
+      const char* wbn = wbuf + ((step + 1) & 1) * G::W_BYTES;
+      // ---- phase A
+      if (tap >= HLAG && tap - HLAG < G::HITER && !last_chunk) store_halo_slot(tap - HLAG, hcur ^ 1);
+      mma_then(wfA, pfA, [&]() { read_frags(wfB, pfB, hb + 32, wb + 32, imm); });
+      block_sync();
+      // ---- phase B
+      if (m2) dma_w(step + 2, step & 1);
+      if (tap < G::HITER && !last_chunk) load_halo_slot(tap);
+      mma_then(wfB, pfB, [&]() {
+        if (m1) {
+          if (tap < 8) read_frags(wfA, pfA, hb, wbn, imm_next);
+          else read_frags(wfA, pfA, hbn, wbn, first_off_next);
+        }
+      });
+      ++step;
     }
-
-    if (more) store_w((step + 1) & 1);
-    if (new_chunk) store_halo((chunk + 1) & 1);
-    __syncthreads();
-    if (++tap == TAPS) { tap = 0; ++chunk; }
+    hcur ^= 1;
   }
+  for (int i = 0; i < n1; ++i) {
+    const bool m1 = step + 1 < nsteps, m2 = step + 2 < nsteps;
+    const char* hb = hbuf + hcur * G::HALO_BYTES;
+    const char* hbn = hbuf + (hcur ^ 1) * G::HALO_BYTES;
+    const char* wb = wbuf + (step & 1) * G::W_BYTES;
+    const char* wbn = wbuf + ((step + 1) & 1) * G::W_BYTES;
+    advance(cs, cch);
+    if (m1) {  // the next 1-tap chunk's halo: loaded and published within this step
+      next_chunk(cs, cch);
+#pragma unroll
+      for (int k = 0; k < G::HITER; ++k) load_halo_slot(k);
+    }
+    mma_then(wfA, pfA, [&]() { read_frags(wfB, pfB, hb + 32, wb + 32, CENTER); });
+    if (m1) {
+#pragma unroll
+      for (int k = 0; k < G::HITER; ++k) store_halo_slot(k, hcur ^ 1);
+    }
+    block_sync();
+    if (m2) dma_w(step + 2, step & 1);
+    mma_then(wfB, pfB, [&]() { if (m1) read_frags(wfA, pfA, hbn, wbn, CENTER); });
+    ++step; hcur ^= 1;
+  }
+  __syncthreads();  // all fragment reads done before the epilogue reuses the LDS
 
-  // ---- epilogue: + bias, + skip, * scale, store 4 consecutive couts per lane-quad ---------------------
+  // ---- epilogue ------------------------------------------------------------------------------------------------------
+  // MT rounds; in round mi every wave stages its acc[mi][*] (32 pixels x NT*32 couts, f32) to LDS as
+  // [pixel (wm*32 + l31)][cout], then all threads sweep the WM*32 pixels with 8 couts (16/32 B) per lane.
   T* out = reinterpret_cast<T*>(p.out);
   const T* skip = reinterpret_cast<const T*>(p.skip);
-  const float* bias = p.bias ? p.bias + (size_t)(p.bias_rows > 1 ? b : 0) * p.Cout : nullptr;
+  const int oct = t % G::OCT, prow_e = t / G::OCT;
+  const int n_e = n0 + oct * 8;
+  const bool n_ok = n_e < p.Cout;
+  const int n_cnt = n_ok ? ((p.Cout - n_e) >= 8 ? 8 : (p.Cout - n_e)) : 0;  // 8, or 4 for the pyramid heads
+  float bv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bv[j] = 0.f;
+  if (p.bias && n_ok) {
+    const float* bp = p.bias + (size_t)(p.bias_rows > 1 ? b : 0) * p.Cout + n_e;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j < n_cnt) bv[j] = bp[j];
+  }
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ssum[j] = ssq[j] = 0.f;
+
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
-    const int pi = wm * MT + mi;
-    const int gh = h0 + 4 * (pi >> 1) + (l31 >> 3), gw = w0 + 8 * (pi & 1) + (l31 & 7);
-    if (gh >= H || gw >= W) continue;
-    const size_t pix = ((size_t)b * H + gh) * W + gw;
+    {
+      char* dst = smem + (wm * 32 + l31) * G::EP_ROWB + (wn * NT * 32 + 4 * lh) * 4;
 #pragma unroll
-    for (int nj = 0; nj < NT; ++nj) {
+      for (int nj = 0; nj < NT; ++nj)
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int n = n0 + (wn * NT + nj) * 32 + 8 * qd + 4 * lh;
-        if (n < p.Cout) {
-          float v[4];
+        for (int qd = 0; qd < 4; ++qd) {
+          f32x4 v = {acc[mi][nj][4 * qd], acc[mi][nj][4 * qd + 1], acc[mi][nj][4 * qd + 2], acc[mi][nj][4 * qd + 3]};
+          *reinterpret_cast<f32x4*>(dst + (nj * 32 + 8 * qd) * 4) = v;
+        }
+    }
+    __syncthreads();
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = acc[mi][nj][4 * qd + j];
-          if (bias) {
-            f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += bv[j];
-          }
+    for (int ps = 0; ps < G::NPASS; ++ps) {
+      const int pp = prow_e + ps * G::PPASS;          // staged pixel: wm' = pp >> 5, l31' = pp & 31
+      const int pi = (pp >> 5) * MT + mi;
+      const int gh = h0 + 4 * (pi >> 1) + ((pp & 31) >> 3), gw = w0 + 8 * (pi & 1) + (pp & 7);
+      if (n_ok && gh < H && gw < W) {
+        const float* sp = reinterpret_cast<const float*>(smem + pp * G::EP_ROWB) + oct * 8;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const size_t o = (((size_t)b * H + gh) * W + gw) * p.Cout + n_e;
+        if (n_cnt == 8) {
           if (skip) {
-            float s[4];
-            fd_load_vec<T, 4>(skip + pix * p.Cout + n, s);
+            float sk[8];
+            fd_load_vec<T, 8>(skip + o, sk);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += s[j];
+            for (int j = 0; j < 8; ++j) v[j] += sk[j];
           }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] *= p.scale;
-          fd_store_vec<T, 4>(out + pix * p.Cout + n, v);
+          for (int j = 0; j < 8; ++j) {
+            v[j] = (v[j] + bv[j]) * p.scale;
+            ssum[j] += v[j]; ssq[j] = fmaf(v[j], v[j], ssq[j]);
+          }
+          fd_store_vec<T, 8>(out + o, v);
+        } else {
+          float w4[4] = {v[0], v[1], v[2], v[3]};
+          if (skip) {
+            float sk[4];
+            fd_load_vec<T, 4>(skip + o, sk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w4[j] += sk[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            w4[j] = (w4[j] + bv[j]) * p.scale;
+            ssum[j] += w4[j]; ssq[j] = fmaf(w4[j], w4[j], ssq[j]);
+          }
+          fd_store_vec<T, 4>(out + o, w4);
         }
       }
+    }
+    __syncthreads();
+  }
+
+  if (p.stats) {  // per-tile partial sums of the output, reduced over the PPASS threads that share an octet
+    float* stg = reinterpret_cast<float*>(smem);  // [PPASS][BN][2]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      stg[((prow_e * G::BN) + oct * 8 + j) * 2] = ssum[j];
+      stg[((prow_e * G::BN) + oct * 8 + j) * 2 + 1] = ssq[j];
+    }
+    __syncthreads();
+    const int tile = th_i * p.tiles_w + tw_i;
+    for (int o = t; o < 2 * G::BN; o += G::NTH) {
+      float a = 0.f;
+#pragma unroll 4
+      for (int r = 0; r < G::PPASS; ++r) a += stg[r * G::BN * 2 + o];
+      if (n0 + (o >> 1) < p.CoutPad)
+        p.stats[(((size_t)b * p.tiles_h * p.tiles_w + tile) * p.CoutPad + n0) * 2 + o] = a;
     }
   }
 }
 
-// ---- weight packing: [Cout][Cin][k][k] f32 -> [chunk][tap][CoutPad][CK] -------------------------------
+// ---- weight packing: [Cout][Cin][k][k] f32 -> [step][CoutPad][ROWB bytes] ------------------------------------------
+// steps enumerate (concat segment, 64-byte channel chunk, tap); the last 16 bytes of every row are padding.
 template <typename T>
-__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout, int CoutPad, int C0,
-                                    int C1, int taps, int nchunk0, int nchunks) {
+__global__ void pack_weights_kernel(const float* __restrict__ w, char* __restrict__ dst, int Cout, int CoutPad, int C0, int C1,
+                                    int taps, long long step0) {
   constexpr int CK = 64 / sizeof(T);
-  const long long total = (long long)nchunks * taps * CoutPad * CK;
+  constexpr int RE = ROWB / sizeof(T);  // elements per padded row
+  const int nchunk0 = (C0 + CK - 1) / CK, nchunks = nchunk0 + (C1 + CK - 1) / CK;
+  const long long total = (long long)nchunks * taps * CoutPad * RE;
   const int Cin = C0 + C1;
+  T* d = reinterpret_cast<T*>(dst + step0 * CoutPad * ROWB);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(i % CK);
-    long long r = i / CK;
+    const int k = (int)(i % RE);
+    long long r = i / RE;
     const int n = (int)(r % CoutPad); r /= CoutPad;
     const int tap = (int)(r % taps);
     const int chunk = (int)(r / taps);
-    int c;  // channel index in the concatenated input, or -1 for padding
-    if (chunk < nchunk0) { c = chunk * CK + k; if (c >= C0) c = -1; }
-    else { c = (chunk - nchunk0) * CK + k; c = (c < C1) ? C0 + c : -1; }
     float v = 0.f;
-    if (c >= 0 && n < Cout) v = w[((size_t)n * Cin + c) * taps + tap];
-    dst[i] = (T)v;
+    if (k < CK && n < Cout) {
+      int c;
+      if (chunk < nchunk0) { c = chunk * CK + k; if (c >= C0) c = -1; }
+      else { c = (chunk - nchunk0) * CK + k; c = (c < C1) ? C0 + c : -1; }
+      if (c >= 0) v = w[((size_t)n * Cin + c) * taps + tap];
+    }
+    d[i] = (T)v;
   }
 }
 
 inline int pad_to(int x, int a) { return (x + a - 1) / a * a; }
-// rows of the packed weight slab: a multiple of the N tile of the config that will run (32 or 128)
-inline int cout_pad(int Cout) { return Cout <= 32 ? 32 : pad_to(Cout, 128); }
+inline int cout_pad(int Cout) { return Cout <= 32 ? 32 : (Cout <= 128 ? 128 : pad_to(Cout, 256)); }
+inline int n_steps(int C0, int C1, int taps, int CK) { return (fd_cdiv(C0, CK) + fd_cdiv(C1, CK)) * taps; }
 
-template <typename T, int TAPS, int WM, int WN, int MT, int NT>
-int launch_conv(ConvArgs a, hipStream_t st) {
-  using G = Geo<TAPS, WM, WN, MT, NT>;
-  a.tiles_h = fd_cdiv(a.H, G::TH);
-  a.tiles_w = fd_cdiv(a.W, G::TW);
-  a.tiles_n = fd_cdiv(a.Cout, G::BN);
-  auto kern = conv_mfma_kernel<T, TAPS, WM, WN, MT, NT>;
-  const long long nblk = (long long)a.B * a.tiles_h * a.tiles_w * a.tiles_n;
-  FD_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(G::NTH), G::LDS_BYTES, st, a);
-  FD_LAUNCH_CHECK();
-  return FD_OK;
-}
+int g_variant = 0;  // tuning hook: 0 = auto, 1 = force the BN=128 config
 
-// > 64 KiB of dynamic LDS needs an explicit opt-in per kernel; done once (not inside a stream capture)
-template <typename T, int TAPS, int WM, int WN, int MT, int NT>
+template <typename T, int WM, int WN, int MT, int NT>
 int set_attr() {
-  using G = Geo<TAPS, WM, WN, MT, NT>;
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, TAPS, WM, WN, MT, NT>),
+  using G = Geo<WM, WN, MT, NT>;
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, WM, WN, MT, NT>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
   return FD_OK;
 }
 
+template <typename T, int WM, int WN, int MT, int NT>
+int launch_conv(ConvArgs a, hipStream_t st) {
+  using G = Geo<WM, WN, MT, NT>;
+  a.tiles_h = fd_cdiv(a.H, G::TH);
+  a.tiles_w = fd_cdiv(a.W, G::TW);
+  a.tiles_n = fd_cdiv(a.Cout, G::BN);
+  const long long nblk = (long long)a.B * a.tiles_h * a.tiles_w * a.tiles_n;
+  FD_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
+  hipLaunchKernelGGL((conv_mfma_kernel<T, WM, WN, MT, NT>), dim3((unsigned)nblk), dim3(G::NTH), G::LDS_BYTES, st, a);
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}
+
 template <typename T>
-int dispatch_conv(ConvArgs a, int ksize, hipStream_t st) {
-  constexpr int CK = 64 / sizeof(T);
-  a.nchunk0 = fd_cdiv(a.C0, CK);
-  a.nchunks = a.nchunk0 + fd_cdiv(a.C1, CK);
-  const bool small_n = a.Cout <= 32;
-  a.CoutPad = cout_pad(a.Cout);
-  if (ksize == 3) {
-    if (small_n) return launch_conv<T, 9, 4, 1, 2, 1>(a, st);
-    return launch_conv<T, 9, 2, 2, 4, 2>(a, st);
-  } else {
-    if (small_n) return launch_conv<T, 1, 4, 1, 2, 1>(a, st);
-    return launch_conv<T, 1, 2, 2, 4, 2>(a, st);
-  }
+int dispatch_conv(const ConvArgs& a, hipStream_t st) {
+  if (a.Cout <= 32) return launch_conv<T, 4, 1, 2, 1>(a, st);                             // 4 waves, BN = 32 (pyramid heads)
+  if (a.Cout <= 128 || g_variant == 1) return launch_conv<T, 4, 2, 2, 2>(a, st);         // 8 waves, BN = 128
+  return launch_conv<T, 2, 4, 4, 2>(a, st);                                               // 8 waves, BN = 256
 }
 
 }  // namespace
@@ -371,57 +533,79 @@ int dispatch_conv(ConvArgs a, int ksize, hipStream_t st) {
 int fd_conv_init_attributes() {
   static bool done = false;
   if (done) return FD_OK;
-  FD_TRY((set_attr<bf16, 9, 4, 1, 2, 1>())); FD_TRY((set_attr<bf16, 9, 2, 2, 4, 2>()));
-  FD_TRY((set_attr<bf16, 1, 4, 1, 2, 1>())); FD_TRY((set_attr<bf16, 1, 2, 2, 4, 2>()));
-  FD_TRY((set_attr<float, 9, 4, 1, 2, 1>())); FD_TRY((set_attr<float, 9, 2, 2, 4, 2>()));
-  FD_TRY((set_attr<float, 1, 4, 1, 2, 1>())); FD_TRY((set_attr<float, 1, 2, 2, 4, 2>()));
+  FD_TRY((set_attr<bf16, 4, 1, 2, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2>()));
+  FD_TRY((set_attr<float, 4, 1, 2, 1>())); FD_TRY((set_attr<float, 4, 2, 2, 2>())); FD_TRY((set_attr<float, 2, 4, 4, 2>()));
   done = true;
   return FD_OK;
 }
 
-extern "C" long long fd_conv_packed_bytes(int Cout, int C0, int C1, int ksize, int wdtype) {
-  const int CK = wdtype == FD_BF16 ? 32 : 16;
-  return (long long)(fd_cdiv(C0, CK) + fd_cdiv(C1, CK)) * ksize * ksize * cout_pad(Cout) * 64;
+extern "C" int fd_tuning_set(const char* key, int value) {
+  FD_REQUIRE(key, "fd_tuning_set: null key");
+  if (!strcmp(key, "conv_variant")) { g_variant = value; return FD_OK; }
+  return fd_set_error(FD_EINVAL, "fd_tuning_set: unknown key '%s'", key);
 }
 
-extern "C" int fd_conv_pack_weights(const float* w, void* packed, int Cout, int C0, int C1, int ksize, int wdtype,
-                                    void* stream) {
+extern "C" int fd_conv_cout_pad(int Cout) { return cout_pad(Cout); }
+extern "C" int fd_conv_stats_tiles(int H, int W) { return fd_cdiv(H, 16) * fd_cdiv(W, 16); }
+
+extern "C" long long fd_conv_packed_bytes(int Cout, int C0, int C1, int ksize, int S0, int S1, int wdtype) {
+  const int CK = wdtype == FD_BF16 ? 32 : 16;
+  return (long long)(n_steps(C0, C1, ksize * ksize, CK) + n_steps(S0, S1, 1, CK)) * cout_pad(Cout) * ROWB;
+}
+
+extern "C" int fd_conv_pack_weights(const float* w, const float* w_sc, void* packed, int Cout, int C0, int C1, int ksize, int S0,
+                                    int S1, int wdtype, void* stream) {
   FD_REQUIRE(w && packed, "fd_conv_pack_weights: null pointer");
   FD_REQUIRE(ksize == 1 || ksize == 3, "fd_conv_pack_weights: ksize must be 1 or 3");
   FD_REQUIRE(wdtype == FD_BF16 || wdtype == FD_F32, "fd_conv_pack_weights: bad dtype");
-  const int taps = ksize * ksize;
-  const int CoutPad = cout_pad(Cout);
-  const int CK = wdtype == FD_BF16 ? 32 : 16;
-  const int nchunk0 = fd_cdiv(C0, CK), nchunks = nchunk0 + fd_cdiv(C1, CK);
-  const long long total = (long long)nchunks * taps * CoutPad * CK;
-  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  if (wdtype == FD_BF16)
-    hipLaunchKernelGGL(pack_weights_kernel<bf16>, dim3(blocks), dim3(256), 0, fd_stream(stream), w,
-                       reinterpret_cast<bf16*>(packed), Cout, CoutPad, C0, C1, taps, nchunk0, nchunks);
-  else
-    hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, fd_stream(stream), w,
-                       reinterpret_cast<float*>(packed), Cout, CoutPad, C0, C1, taps, nchunk0, nchunks);
+  FD_REQUIRE((S0 + S1 == 0) == (w_sc == nullptr), "fd_conv_pack_weights: shortcut weight / channel mismatch");
+  const int taps = ksize * ksize, CoutPad = cout_pad(Cout), CK = wdtype == FD_BF16 ? 32 : 16;
+  hipStream_t st = fd_stream(stream);
+  auto run = [&](const float* src, int c0, int c1, int tp, long long step0) {
+    const long long total = (long long)n_steps(c0, c1, tp, CK) * CoutPad * (ROWB / (wdtype == FD_BF16 ? 2 : 4));
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (wdtype == FD_BF16)
+      hipLaunchKernelGGL(pack_weights_kernel<bf16>, dim3(blocks), dim3(256), 0, st, src, (char*)packed, Cout, CoutPad, c0, c1, tp, step0);
+    else
+      hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, st, src, (char*)packed, Cout, CoutPad, c0, c1, tp, step0);
+  };
+  run(w, C0, C1, taps, 0);
+  if (w_sc) run(w_sc, S0, S1, 1, n_steps(C0, C1, taps, CK));
   FD_LAUNCH_CHECK();
   return FD_OK;
 }
 
-extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const float* affine, const void* packed_w,
-                         const float* bias, int bias_rows, const void* skip, float scale, void* out, int Cout, int B,
-                         int H, int W, int ksize, int dtype, int wdtype, void* stream) {
+extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const float* affine, const void* sc0, int S0,
+                         const void* sc1, int S1, const void* packed_w, const float* bias, int bias_rows, const void* skip,
+                         float scale, void* out, int Cout, float* stats, int B, int H, int W, int ksize, int dtype, void* stream) {
   FD_REQUIRE(in0 && packed_w && out, "fd_conv2d: null pointer");
   FD_REQUIRE(ksize == 1 || ksize == 3, "fd_conv2d: ksize must be 1 or 3 (got %d)", ksize);
-  FD_REQUIRE(dtype == wdtype && (dtype == FD_BF16 || dtype == FD_F32),
-             "fd_conv2d: supported modes are bf16 storage + bf16 MFMA, or f32 storage + f32 MFMA");
+  FD_REQUIRE(dtype == FD_BF16 || dtype == FD_F32, "fd_conv2d: dtype must be FD_BF16 (bf16 MFMA) or FD_F32 (f32 MFMA)");
   FD_REQUIRE(C0 > 0 && C0 % 8 == 0 && C1 >= 0 && C1 % 8 == 0, "fd_conv2d: input channels must be multiples of 8 (C0=%d C1=%d)", C0, C1);
-  FD_REQUIRE((C1 == 0) == (in1 == nullptr), "fd_conv2d: in1 / C1 mismatch");
-  FD_REQUIRE(Cout > 0 && Cout % 4 == 0, "fd_conv2d: Cout must be a multiple of 4 (got %d)", Cout);
+  FD_REQUIRE(S0 >= 0 && S0 % 8 == 0 && S1 >= 0 && S1 % 8 == 0, "fd_conv2d: shortcut channels must be multiples of 8 (S0=%d S1=%d)", S0, S1);
+  FD_REQUIRE((C1 == 0) == (in1 == nullptr) && (S0 == 0) == (sc0 == nullptr) && (S1 == 0) == (sc1 == nullptr),
+             "fd_conv2d: tensor / channel-count mismatch");
+  FD_REQUIRE(S1 == 0 || S0 > 0, "fd_conv2d: sc1 without sc0");
+  FD_REQUIRE(Cout > 0 && (Cout % 8 == 0 || Cout == 4), "fd_conv2d: Cout must be 4 or a multiple of 8 (got %d)", Cout);
   FD_REQUIRE(B > 0 && H > 0 && W > 0, "fd_conv2d: bad shape");
   FD_REQUIRE(bias == nullptr || bias_rows == 1 || bias_rows == B, "fd_conv2d: bias_rows must be 1 or B");
-  FD_REQUIRE((long long)B * H * W < (1ll << 31), "fd_conv2d: too many pixels for 32-bit indexing");
+  int cm = C0; if (C1 > cm) cm = C1; if (S0 > cm) cm = S0; if (S1 > cm) cm = S1; if (Cout > cm) cm = Cout;
+  FD_REQUIRE((long long)H * W * cm * 4 < (1ll << 31), "fd_conv2d: one image exceeds 2 GiB (32-bit buffer offsets)");
   FD_TRY(fd_conv_init_attributes());
+  const int taps = ksize * ksize;
   ConvArgs a{};
-  a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.affine = affine; a.w = packed_w; a.bias = bias;
-  a.bias_rows = bias_rows; a.skip = skip; a.scale = scale; a.out = out; a.Cout = Cout; a.B = B; a.H = H; a.W = W;
-  if (dtype == FD_BF16) return dispatch_conv<bf16>(a, ksize, fd_stream(stream));
-  return dispatch_conv<float>(a, ksize, fd_stream(stream));
+  int ns = 0;
+  a.seg[ns++] = Seg{in0, C0, affine ? 0 : -1, taps};
+  if (C1) a.seg[ns++] = Seg{in1, C1, affine ? C0 : -1, taps};
+  if (S0) a.seg[ns++] = Seg{sc0, S0, -1, 1};
+  if (S1) a.seg[ns++] = Seg{sc1, S1, -1, 1};
+  a.nseg = ns;
+  a.affine = affine; a.affC = C0 + C1;
+  a.w = packed_w; a.w_bytes = fd_conv_packed_bytes(Cout, C0, C1, ksize, S0, S1, dtype);
+  a.bias = bias; a.bias_rows = bias_rows; a.skip = skip; a.scale = scale; a.out = out; a.Cout = Cout; a.CoutPad = cout_pad(Cout);
+  a.stats = stats; a.B = B; a.H = H; a.W = W;
+  FD_REQUIRE(a.w_bytes < (1ll << 31), "fd_conv2d: packed weights exceed 2 GiB");
+  FD_REQUIRE(affine == nullptr || (C0 + C1) * 8 <= AFF_BYTES, "fd_conv2d: at most %d activated input channels", AFF_BYTES / 8);
+  if (dtype == FD_BF16) return dispatch_conv<bf16>(a, fd_stream(stream));
+  return dispatch_conv<float>(a, fd_stream(stream));
 }

@@ -10,9 +10,11 @@ namespace {
 // =====================================================================================================
 // GroupNorm statistics: per-(b, c) sum and sum of squares (nn.GroupNorm, layerspp.py:229,241)
 // =====================================================================================================
-// grid (blocks_per_image, B), 256 threads = (C/8 channel vectors) x (2048/C pixel lanes).
+// grid (blocks_per_image, B), 256 threads = (C/8 channel vectors) x (2048/C pixel lanes).  Every block writes its
+// own partial (sum, sum of squares) per channel: part[b][block][c][2] (float) -- deterministic, no atomics.  The
+// MFMA conv epilogue emits the same format for its output (one partial per 16x16 tile).
 template <typename T>
-__global__ __launch_bounds__(256) void channel_sums_kernel(const T* __restrict__ x, double* __restrict__ sums, int HW,
+__global__ __launch_bounds__(256) void channel_sums_kernel(const T* __restrict__ x, float* __restrict__ part, int HW,
                                                            int C, int px_per_block) {
   const int cv = C >> 3;            // channel vectors (power of two, <= 32)
   const int lanes = 256 / cv;       // pixel lanes
@@ -35,37 +37,61 @@ __global__ __launch_bounds__(256) void channel_sums_kernel(const T* __restrict__
 #pragma unroll
   for (int i = 0; i < 8; ++i) { red[t][i] = s[i]; red[t][8 + i] = ss[i]; }
   __syncthreads();
-  // thread j < 2*C... reduce over pixel lanes in double: C*2 outputs, C <= 256 -> up to 512 outputs, 2 per thread
   for (int o = t; o < 2 * C; o += 256) {
     const int c = o >> 1, which = o & 1;
     const int tv = c >> 3, e = (c & 7) + 8 * which;
-    double acc = 0.0;
-    for (int l = 0; l < lanes; ++l) acc += (double)red[l * cv + tv][e];
-    atomicAdd(&sums[((size_t)b * C + c) * 2 + which], acc);
+    float acc = 0.f;
+    for (int l = 0; l < lanes; ++l) acc += red[l * cv + tv][e];
+    part[(((size_t)b * gridDim.x + blockIdx.x) * C + c) * 2 + which] = acc;
   }
 }
 
-__global__ void gn_finalize_kernel(const double* __restrict__ s0, int C0, const double* __restrict__ s1, int C1,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ affine, int B, int groups, double inv_n, float eps) {
-  const int C = C0 + C1;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * C) return;
-  const int b = i / C, c = i - b * C;
-  const int cpg = C / groups;
-  const int g0 = (c / cpg) * cpg;
+// One block per (group, b): reduce the partials of the group's channels over all tiles in double, then write the
+// per-channel affine (a = rstd*gamma, d = beta - mean*rstd*gamma).  The group may straddle the two tensors of a
+// virtual concat [C0 | C1] (e.g. GroupNorm(32, 320) over cat(h[256], hs[64]), ncsnpp.py:337).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ p0, int tiles0, int stride0, int C0,
+                                                          const float* __restrict__ p1, int tiles1, int stride1, int C1,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ affine, int groups, double inv_n, float eps) {
+  const int C = C0 + C1, cpg = C / groups;
+  const int g = blockIdx.x, b = blockIdx.y;
+  const int c_lo = g * cpg;
   double s = 0.0, ss = 0.0;
-  for (int k = g0; k < g0 + cpg; ++k) {
-    const double* p = (k < C0) ? s0 + ((size_t)b * C0 + k) * 2 : s1 + ((size_t)b * C1 + (k - C0)) * 2;
-    s += p[0]; ss += p[1];
+  // channels of this group that live in tensor 0 / tensor 1
+  const int a0 = c_lo < C0 ? c_lo : C0, a1 = (c_lo + cpg) < C0 ? (c_lo + cpg) : C0;          // [a0, a1) in tensor 0
+  const int b0 = (c_lo > C0 ? c_lo : C0) - C0, b1 = ((c_lo + cpg) > C0 ? (c_lo + cpg) : C0) - C0;  // [b0, b1) in tensor 1
+  const int n0 = a1 - a0, n1 = b1 - b0;
+  for (int i = threadIdx.x; i < n0 * tiles0; i += 256) {
+    const int tl = i / n0, c = a0 + i % n0;
+    const float2 v = *reinterpret_cast<const float2*>(p0 + (((size_t)b * tiles0 + tl) * stride0 + c) * 2);
+    s += v.x; ss += v.y;
   }
-  const double mean = s * inv_n;
-  double var = ss * inv_n - mean * mean;
-  var = var < 0.0 ? 0.0 : var;
-  const double rstd = 1.0 / sqrt(var + (double)eps);
-  const float a = (float)rstd * gamma[c];
-  affine[2 * (size_t)i] = a;
-  affine[2 * (size_t)i + 1] = beta[c] - (float)(mean * rstd) * gamma[c];
+  for (int i = threadIdx.x; i < n1 * tiles1; i += 256) {
+    const int tl = i / n1, c = b0 + i % n1;
+    const float2 v = *reinterpret_cast<const float2*>(p1 + (((size_t)b * tiles1 + tl) * stride1 + c) * 2);
+    s += v.x; ss += v.y;
+  }
+  s = fd_wave_sum(s); ss = fd_wave_sum(ss);
+  __shared__ double rs[4], rss[4];
+  __shared__ float sh_mean_rstd[2];
+  if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rss[threadIdx.x >> 6] = ss; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double S = rs[0] + rs[1] + rs[2] + rs[3], SS = rss[0] + rss[1] + rss[2] + rss[3];
+    const double mean = S * inv_n;
+    double var = SS * inv_n - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    sh_mean_rstd[0] = (float)rstd;
+    sh_mean_rstd[1] = (float)(mean * rstd);
+  }
+  __syncthreads();
+  if (threadIdx.x < cpg) {
+    const int c = c_lo + threadIdx.x;
+    const float a = sh_mean_rstd[0] * gamma[c];
+    affine[((size_t)b * C + c) * 2] = a;
+    affine[((size_t)b * C + c) * 2 + 1] = beta[c] - sh_mean_rstd[1] * gamma[c];
+  }
 }
 
 // =====================================================================================================
@@ -411,32 +437,35 @@ inline int grid_for(long long n, int per_block = 256, int cap = 1 << 20) {
 // ---------------------------------------------------------------------------------------------------------
 // C ABI + internal launchers
 // ---------------------------------------------------------------------------------------------------------
-extern "C" int fd_channel_sums(const void* x, double* sums, int B, int H, int W, int C, int dtype, void* stream) {
-  FD_REQUIRE(x && sums, "fd_channel_sums: null pointer");
+extern "C" int fd_channel_sums_tiles(int H, int W) { return fd_cdiv((long long)H * W, 2048); }
+
+extern "C" int fd_channel_sums(const void* x, float* part, int B, int H, int W, int C, int dtype, void* stream) {
+  FD_REQUIRE(x && part, "fd_channel_sums: null pointer");
   FD_REQUIRE(C >= 8 && C <= 256 && (C & (C - 1)) == 0, "fd_channel_sums: C must be a power of two in [8,256] (got %d)", C);
   FD_REQUIRE(dtype == FD_F32 || dtype == FD_BF16, "fd_channel_sums: bad dtype");
   hipStream_t st = fd_stream(stream);
-  FD_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)B * C, st));
   const int HW = H * W;
   const int ppb = 2048;  // pixels per block
   dim3 grid(fd_cdiv(HW, ppb), B);
   if (dtype == FD_BF16)
-    hipLaunchKernelGGL(channel_sums_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, sums, HW, C, ppb);
+    hipLaunchKernelGGL(channel_sums_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, part, HW, C, ppb);
   else
-    hipLaunchKernelGGL(channel_sums_kernel<float>, grid, dim3(256), 0, st, (const float*)x, sums, HW, C, ppb);
+    hipLaunchKernelGGL(channel_sums_kernel<float>, grid, dim3(256), 0, st, (const float*)x, part, HW, C, ppb);
   FD_LAUNCH_CHECK();
   return FD_OK;
 }
 
-extern "C" int fd_gn_finalize(const double* sums0, int C0, const double* sums1, int C1, const float* gamma,
-                              const float* beta, float* affine, int B, int groups, long long hw, float eps, void* stream) {
-  FD_REQUIRE(sums0 && gamma && beta && affine, "fd_gn_finalize: null pointer");
-  FD_REQUIRE((C1 == 0) == (sums1 == nullptr), "fd_gn_finalize: sums1 / C1 mismatch");
+extern "C" int fd_gn_finalize(const float* part0, int tiles0, int stride0, int C0, const float* part1, int tiles1, int stride1,
+                              int C1, const float* gamma, const float* beta, float* affine, int B, int groups, long long hw,
+                              float eps, void* stream) {
+  FD_REQUIRE(part0 && gamma && beta && affine, "fd_gn_finalize: null pointer");
+  FD_REQUIRE((C1 == 0) == (part1 == nullptr), "fd_gn_finalize: part1 / C1 mismatch");
+  FD_REQUIRE(tiles0 > 0 && stride0 >= C0 && (C1 == 0 || (tiles1 > 0 && stride1 >= C1)), "fd_gn_finalize: bad partial geometry");
   const int C = C0 + C1;
-  FD_REQUIRE(groups > 0 && C % groups == 0, "fd_gn_finalize: C=%d not divisible by groups=%d", C, groups);
+  FD_REQUIRE(groups > 0 && C % groups == 0 && C / groups <= 256, "fd_gn_finalize: C=%d not divisible by groups=%d", C, groups);
   const double inv_n = 1.0 / ((double)hw * (C / groups));
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(fd_cdiv((long long)B * C, 256)), dim3(256), 0, fd_stream(stream), sums0, C0,
-                     sums1, C1, gamma, beta, affine, B, groups, inv_n, eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, fd_stream(stream), part0, tiles0, stride0, C0, part1, tiles1,
+                     stride1, C1, gamma, beta, affine, groups, inv_n, eps);
   FD_LAUNCH_CHECK();
   return FD_OK;
 }

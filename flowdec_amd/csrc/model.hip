@@ -25,7 +25,7 @@ struct Mod {
   // device pointers (filled by finalize)
   void* w0 = nullptr; void* w1 = nullptr; void* w2 = nullptr;   // packed conv weights
   float *gn0_g = nullptr, *gn0_b = nullptr, *gn1_g = nullptr, *gn1_b = nullptr;
-  float *b1 = nullptr, *b2 = nullptr;      // Conv_1 / Conv_2 bias
+  float* b1 = nullptr;                     // Conv_1 bias (+ Conv_2 bias when the shortcut conv is folded in)
   float* bias0_eff = nullptr;              // [nt][cout] Conv_0 bias + Dense_0(silu(temb)), model-owned scratch
   float *w_f32 = nullptr, *b_f32 = nullptr;  // small f32 weights (conv_in, combine, head bias, gn affine)
 };
@@ -78,7 +78,8 @@ class Arena {
 struct Tens {
   size_t off = (size_t)-1;
   int C = 0, H = 0, W = 0;
-  size_t sums = (size_t)-1;  // offset of the per-(b,c) (sum, sumsq) doubles, if computed
+  size_t sums = (size_t)-1;  // offset of the per-tile partial (sum, sumsq) floats [B][tiles][stride][2], if computed
+  int tiles = 0, stride = 0;
 };
 
 struct GraphKey {
@@ -195,14 +196,16 @@ int upload_f32(fd_model* m, const std::string& name, float** out) {
   return FD_OK;
 }
 
-int pack_conv(fd_model* m, const std::string& name, int Cout, int C0, int C1, int ks, void** out, hipStream_t st) {
-  float* src = nullptr;
+int pack_conv(fd_model* m, const std::string& name, int Cout, int C0, int C1, int ks, const std::string& sc_name, int S0, int S1,
+              void** out, hipStream_t st) {
+  float *src = nullptr, *sc = nullptr;
   FD_TRY(upload_f32(m, name, &src));
+  if (!sc_name.empty()) FD_TRY(upload_f32(m, sc_name, &sc));
   void* dst = nullptr;
-  const long long bytes = fd_conv_packed_bytes(Cout, C0, C1, ks, m->cfg.act_dtype);
+  const long long bytes = fd_conv_packed_bytes(Cout, C0, C1, ks, S0, S1, m->cfg.act_dtype);
   FD_HIP(hipMalloc(&dst, (size_t)bytes));
   m->dev_allocs.push_back(dst);
-  FD_TRY(fd_conv_pack_weights(src, dst, Cout, C0, C1, ks, m->cfg.act_dtype, st));
+  FD_TRY(fd_conv_pack_weights(src, sc, dst, Cout, C0, C1, ks, S0, S1, m->cfg.act_dtype, st));
   *out = dst;
   return FD_OK;
 }
@@ -235,9 +238,11 @@ struct Fwd {
   }
   int ensure_sums(Tens& t) {
     if (t.sums != (size_t)-1) return FD_OK;
-    t.sums = arena.alloc(sizeof(double) * 2 * (size_t)B * t.C);
+    t.tiles = fd_channel_sums_tiles(t.H, t.W);
+    t.stride = t.C;
+    t.sums = arena.alloc(sizeof(float) * 2 * (size_t)B * t.tiles * t.stride);
     if (dry) return FD_OK;
-    return fd_channel_sums(ptr(t.off), (double*)ptr(t.sums), B, t.H, t.W, t.C, dt, st);
+    return fd_channel_sums(ptr(t.off), (float*)ptr(t.sums), B, t.H, t.W, t.C, dt, st);
   }
   // GroupNorm over the virtual concat [a | b] -> affine pairs
   int gn_affine(Tens& a, Tens* b, const float* gamma, const float* beta, size_t* aff_off) {
@@ -246,11 +251,17 @@ struct Fwd {
     const int C = a.C + (b ? b->C : 0);
     *aff_off = arena.alloc(sizeof(float) * 2 * (size_t)B * C);
     if (dry) return FD_OK;
-    return fd_gn_finalize((const double*)ptr(a.sums), a.C, b ? (const double*)ptr(b->sums) : nullptr, b ? b->C : 0, gamma, beta,
-                          (float*)ptr(*aff_off), B, gn_groups(C), (long long)a.H * a.W, 1e-6f, st);
+    return fd_gn_finalize((const float*)ptr(a.sums), a.tiles, a.stride, a.C, b ? (const float*)ptr(b->sums) : nullptr, b ? b->tiles : 0,
+                          b ? b->stride : 0, b ? b->C : 0, gamma, beta, (float*)ptr(*aff_off), B, gn_groups(C), (long long)a.H * a.W, 1e-6f, st);
   }
-  int conv(const Tens& a, const Tens* b, size_t aff, const void* w, const float* bias, int bias_rows, const Tens* skip, float scale,
-           Tens& out, int ks) {
+  // out = scale * (conv_k(act([a|b])) + conv_1x1([s0|s1]) + bias + skip); optionally emits the GroupNorm partials of out
+  int conv(const Tens& a, const Tens* b, size_t aff, const Tens* s0, const Tens* s1, const void* w, const float* bias, int bias_rows,
+           const Tens* skip, float scale, Tens& out, int ks, bool want_stats) {
+    if (want_stats) {
+      out.tiles = fd_conv_stats_tiles(out.H, out.W);
+      out.stride = fd_conv_cout_pad(out.C);
+      out.sums = arena.alloc(sizeof(float) * 2 * (size_t)B * out.tiles * out.stride);
+    }
     if (dry) return FD_OK;
     if (m->profiling) {
       if (m->ev_used == m->ev.size()) {
@@ -260,12 +271,15 @@ struct Fwd {
       }
       FD_HIP(hipEventRecord(m->ev[m->ev_used].first, st));
     }
-    const int rc = fd_conv2d(ptr(a.off), a.C, b ? ptr(b->off) : nullptr, b ? b->C : 0, aff == (size_t)-1 ? nullptr : (const float*)ptr(aff), w,
-                             bias, bias_rows, skip ? ptr(skip->off) : nullptr, scale, ptr(out.off), out.C, B, out.H, out.W, ks, dt, dt, st);
+    const int rc = fd_conv2d(ptr(a.off), a.C, b ? ptr(b->off) : nullptr, b ? b->C : 0, aff == (size_t)-1 ? nullptr : (const float*)ptr(aff),
+                             s0 ? ptr(s0->off) : nullptr, s0 ? s0->C : 0, s1 ? ptr(s1->off) : nullptr, s1 ? s1->C : 0, w, bias, bias_rows,
+                             skip ? ptr(skip->off) : nullptr, scale, ptr(out.off), out.C, want_stats ? (float*)ptr(out.sums) : nullptr, B,
+                             out.H, out.W, ks, dt, st);
     if (m->profiling) {
       FD_HIP(hipEventRecord(m->ev[m->ev_used].second, st));
       ++m->ev_used;
-      m->prof_flops += 2.0 * B * out.H * out.W * (double)out.C * (a.C + (b ? b->C : 0)) * ks * ks;
+      m->prof_flops += 2.0 * B * out.H * out.W * (double)out.C *
+                       ((a.C + (b ? b->C : 0)) * ks * ks + (s0 ? s0->C : 0) + (s1 ? s1->C : 0));
     }
     return rc;
   }
@@ -281,23 +295,20 @@ struct Fwd {
     if (md.up || md.down) {
       xr = talloc(md.cin, OH, OW); hr = talloc(md.cin, OH, OW);
       if (!dry) FD_TRY(fd_fir_resample(ptr(x0.off), (const float*)ptr(aff0), ptr(xr.off), ptr(hr.off), B, H, W, md.cin, md.up ? 1 : -1, dt, st));
-      FD_TRY(conv(hr, nullptr, (size_t)-1, md.w0, md.bias0_eff, nt, nullptr, 1.f, h1, 3));
+      FD_TRY(conv(hr, nullptr, (size_t)-1, nullptr, nullptr, md.w0, md.bias0_eff, nt, nullptr, 1.f, h1, 3, true));
       tfree(hr);
     } else {
-      FD_TRY(conv(x0, x1, aff0, md.w0, md.bias0_eff, nt, nullptr, 1.f, h1, 3));
+      FD_TRY(conv(x0, x1, aff0, nullptr, nullptr, md.w0, md.bias0_eff, nt, nullptr, 1.f, h1, 3, true));
     }
     arena.release(aff0);
     size_t aff1;
     FD_TRY(gn_affine(h1, nullptr, md.gn1_g, md.gn1_b, &aff1));
     out = talloc(md.cout, OH, OW);
-    if (md.has_c2) {
-      Tens sk = talloc(md.cout, OH, OW);
-      if (md.up || md.down) FD_TRY(conv(xr, nullptr, (size_t)-1, md.w2, md.b2, 1, nullptr, 1.f, sk, 1));
-      else FD_TRY(conv(x0, x1, (size_t)-1, md.w2, md.b2, 1, nullptr, 1.f, sk, 1));
-      FD_TRY(conv(h1, nullptr, aff1, md.w1, md.b1, 1, &sk, rs2, out, 3));
-      tfree(sk);
+    if (md.has_c2) {  // Conv_1(act(GN1(h))) + Conv_2(x) in one launch (shortcut conv folded in as extra K steps)
+      if (md.up || md.down) FD_TRY(conv(h1, nullptr, aff1, &xr, nullptr, md.w1, md.b1, 1, nullptr, rs2, out, 3, true));
+      else FD_TRY(conv(h1, nullptr, aff1, &x0, x1, md.w1, md.b1, 1, nullptr, rs2, out, 3, true));
     } else {
-      FD_TRY(conv(h1, nullptr, aff1, md.w1, md.b1, 1, &x0, rs2, out, 3));
+      FD_TRY(conv(h1, nullptr, aff1, nullptr, nullptr, md.w1, md.b1, 1, &x0, rs2, out, 3, true));
     }
     if (md.up || md.down) tfree(xr);
     arena.release(aff1);
@@ -374,10 +385,10 @@ struct Fwd {
       if (have_pyr) {
         Tens pu = talloc(4, h.H, h.W);
         if (!dry) FD_TRY(fd_fir_resample(ptr(pyramid.off), nullptr, ptr(pu.off), nullptr, B, pyramid.H, pyramid.W, 4, +1, dt, st));
-        FD_TRY(conv(h, nullptr, aff, head.w0, head.b_f32, 1, &pu, 1.f, pnew, 3));
+        FD_TRY(conv(h, nullptr, aff, nullptr, nullptr, head.w0, head.b_f32, 1, &pu, 1.f, pnew, 3, false));
         tfree(pu); tfree(pyramid);
       } else {
-        FD_TRY(conv(h, nullptr, aff, head.w0, head.b_f32, 1, nullptr, 1.f, pnew, 3));
+        FD_TRY(conv(h, nullptr, aff, nullptr, nullptr, head.w0, head.b_f32, 1, nullptr, 1.f, pnew, 3, false));
       }
       arena.release(aff);
       pyramid = pnew; have_pyr = true;
@@ -616,17 +627,23 @@ extern "C" int fd_model_finalize(fd_model* m, void* stream) {
         FD_TRY(upload_f32(m, p + "bias", &md.gn0_b));
         break;
       case M_CONV_HEAD:
-        FD_TRY(pack_conv(m, p + "weight", md.cout, md.cin, 0, 3, &md.w0, st));
+        FD_TRY(pack_conv(m, p + "weight", md.cout, md.cin, 0, 3, "", 0, 0, &md.w0, st));
         FD_TRY(upload_f32(m, p + "bias", &md.b_f32));
         break;
       case M_RB: {
         FD_TRY(upload_f32(m, p + "GroupNorm_0.weight", &md.gn0_g)); FD_TRY(upload_f32(m, p + "GroupNorm_0.bias", &md.gn0_b));
         FD_TRY(upload_f32(m, p + "GroupNorm_1.weight", &md.gn1_g)); FD_TRY(upload_f32(m, p + "GroupNorm_1.bias", &md.gn1_b));
         // up/down blocks resample the (single) input first, so Conv_0 / Conv_2 see one tensor of cin channels
-        FD_TRY(pack_conv(m, p + "Conv_0.weight", md.cout, md.c0, md.c1, 3, &md.w0, st));
-        FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, &md.w1, st));
+        FD_TRY(pack_conv(m, p + "Conv_0.weight", md.cout, md.c0, md.c1, 3, "", 0, 0, &md.w0, st));
+        if (md.has_c2) {  // fold the 1x1 shortcut into Conv_1's K loop; biases add
+          FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, p + "Conv_2.weight", md.c0, md.c1, &md.w1, st));
+          std::vector<float>& b1 = m->host[p + "Conv_1.bias"];
+          const std::vector<float>& b2 = m->host[p + "Conv_2.bias"];
+          for (size_t i = 0; i < b1.size(); ++i) b1[i] += b2[i];
+        } else {
+          FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, "", 0, 0, &md.w1, st));
+        }
         FD_TRY(upload_f32(m, p + "Conv_1.bias", &md.b1));
-        if (md.has_c2) { FD_TRY(pack_conv(m, p + "Conv_2.weight", md.cout, md.c0, md.c1, 1, &md.w2, st)); FD_TRY(upload_f32(m, p + "Conv_2.bias", &md.b2)); }
         fd_temb_job j{};
         FD_TRY(upload_f32(m, p + "Dense_0.weight", &tmp)); j.dense_w = tmp;
         FD_TRY(upload_f32(m, p + "Dense_0.bias", &tmp)); j.dense_b = tmp;

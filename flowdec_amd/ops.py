@@ -26,27 +26,30 @@ def to_nchw(x_nhwc):
 
 
 def channel_sums(x):
+    """Stand-alone statistics pass -> partial sums [B, tiles, C, 2] float32."""
     B, H, W, Cc = _nhwc(x)
-    out = torch.empty(B, Cc, 2, dtype=torch.float64, device=x.device)
+    tiles = L.load().fd_channel_sums_tiles(H, W)
+    out = torch.empty(B, tiles, Cc, 2, dtype=torch.float32, device=x.device)
     L.check(L.load().fd_channel_sums(L.ptr(x), L.ptr(out), B, H, W, Cc, L.dtype_id(x.dtype), L.stream()))
     return out
 
 
-def gn_finalize(sums0, sums1, gamma, beta, groups, hw, eps=1e-6):
-    B, C0 = sums0.shape[0], sums0.shape[1]
-    C1 = 0 if sums1 is None else sums1.shape[1]
-    out = torch.empty(B, C0 + C1, 2, dtype=torch.float32, device=sums0.device)
-    L.check(L.load().fd_gn_finalize(L.ptr(sums0), C0, L.ptr(sums1), C1, L.ptr(gamma), L.ptr(beta), L.ptr(out), B, groups, hw,
-                                    eps, L.stream()))
+def gn_finalize(part0, C0, part1, C1, gamma, beta, groups, hw, eps=1e-6):
+    """part: [B, tiles, stride, 2] partial sums (stride >= C) of one or two tensors -> affine [B, C0+C1, 2]."""
+    B = part0.shape[0]
+    out = torch.empty(B, C0 + C1, 2, dtype=torch.float32, device=part0.device)
+    t1, s1 = (0, 0) if part1 is None else (part1.shape[1], part1.shape[2])
+    L.check(L.load().fd_gn_finalize(L.ptr(part0), part0.shape[1], part0.shape[2], C0, L.ptr(part1), t1, s1, C1, L.ptr(gamma),
+                                    L.ptr(beta), L.ptr(out), B, groups, hw, eps, L.stream()))
     return out
 
 
 def gn_affine(x0, x1, gamma, beta, eps=1e-6):
     """GroupNorm(min(C//4, 32), C) statistics of the virtual concat [x0 | x1] as per-(b, c) affine pairs."""
-    Cc = x0.shape[3] + (0 if x1 is None else x1.shape[3])
+    C0, C1 = x0.shape[3], (0 if x1 is None else x1.shape[3])
     s0 = channel_sums(x0)
     s1 = None if x1 is None else channel_sums(x1)
-    return gn_finalize(s0, s1, gamma, beta, min(Cc // 4, 32), x0.shape[1] * x0.shape[2], eps)
+    return gn_finalize(s0, C0, s1, C1, gamma, beta, min((C0 + C1) // 4, 32), x0.shape[1] * x0.shape[2], eps)
 
 
 def fir_resample(x, direction, affine=None, want_raw=True):
@@ -60,27 +63,37 @@ def fir_resample(x, direction, affine=None, want_raw=True):
     return raw, act
 
 
-def pack_conv_weight(w, C0=None, dtype=torch.bfloat16):
-    """w: [Cout, Cin, k, k] float32 (GPU).  C0 = channels of the first concat segment (default: all)."""
-    L.require_cuda(w)
+def pack_conv_weight(w, C0=None, dtype=torch.bfloat16, w_sc=None, S0=None):
+    """w: [Cout, Cin, k, k] float32 (GPU); C0 = channels of the first concat segment (default: all).
+    w_sc: optional 1x1 shortcut weight [Cout, S, 1, 1] folded behind the main K loop (S0 = first segment)."""
+    L.require_cuda(w, w_sc)
     w = w.contiguous().float()
     Cout, Cin, k, _ = w.shape
     C0 = Cin if C0 is None else C0
-    nbytes = L.load().fd_conv_packed_bytes(Cout, C0, Cin - C0, k, L.dtype_id(dtype))
+    S = 0 if w_sc is None else w_sc.shape[1]
+    S0 = S if S0 is None else S0
+    if w_sc is not None:
+        w_sc = w_sc.contiguous().float()
+    dt = L.dtype_id(dtype)
+    nbytes = L.load().fd_conv_packed_bytes(Cout, C0, Cin - C0, k, S0, S - S0, dt)
     packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    L.check(L.load().fd_conv_pack_weights(L.ptr(w), L.ptr(packed), Cout, C0, Cin - C0, k, L.dtype_id(dtype), L.stream()))
+    L.check(L.load().fd_conv_pack_weights(L.ptr(w), L.ptr(w_sc), L.ptr(packed), Cout, C0, Cin - C0, k, S0, S - S0, dt, L.stream()))
     return packed
 
 
-def conv2d(x0, packed_w, Cout, ksize, x1=None, affine=None, bias=None, skip=None, scale=1.0):
+def conv2d(x0, packed_w, Cout, ksize, x1=None, affine=None, bias=None, skip=None, scale=1.0, sc0=None, sc1=None, want_stats=False):
+    """Returns out, or (out, stats partials [B, tiles, CoutPad, 2]) with want_stats."""
     B, H, W, C0 = _nhwc(x0)
+    lib = L.load()
     C1 = 0 if x1 is None else x1.shape[3]
+    S0 = 0 if sc0 is None else sc0.shape[3]
+    S1 = 0 if sc1 is None else sc1.shape[3]
     out = torch.empty(B, H, W, Cout, dtype=x0.dtype, device=x0.device)
+    stats = torch.zeros(B, lib.fd_conv_stats_tiles(H, W), lib.fd_conv_cout_pad(Cout), 2, dtype=torch.float32, device=x0.device) if want_stats else None
     rows = 0 if bias is None else (1 if bias.ndim == 1 else bias.shape[0])
-    dt = L.dtype_id(x0.dtype)
-    L.check(L.load().fd_conv2d(L.ptr(x0), C0, L.ptr(x1), C1, L.ptr(affine), L.ptr(packed_w), L.ptr(bias), rows, L.ptr(skip),
-                               float(scale), L.ptr(out), Cout, B, H, W, ksize, dt, dt, L.stream()))
-    return out
+    L.check(lib.fd_conv2d(L.ptr(x0), C0, L.ptr(x1), C1, L.ptr(affine), L.ptr(sc0), S0, L.ptr(sc1), S1, L.ptr(packed_w), L.ptr(bias), rows,
+                          L.ptr(skip), float(scale), L.ptr(out), Cout, L.ptr(stats), B, H, W, ksize, L.dtype_id(x0.dtype), L.stream()))
+    return (out, stats) if want_stats else out
 
 
 def time_embedding(t, gfp_w, w1, b1, w2, b2):

@@ -77,34 +77,44 @@ int fd_fused_bias_act(const float* x, const float* bias, float* out, long long n
 int fd_fir_resample(const void* x, const float* affine, void* out_raw, void* out_act, int B, int H, int W, int C,
                     int direction, int dtype, void* stream);
 
-/* GroupNorm statistics, split in two so that a stats pass can be shared by consumers that group the
- * channels differently (nn.GroupNorm(min(C//4,32), C, eps=1e-6), layerspp.py:229,241):
- *  fd_channel_sums : sums[b][c] = (sum x, sum x^2) over H*W, float64 pairs, for an NHWC tensor.
- *  fd_gn_finalize  : combine the per-channel sums of one or two tensors (virtual channel concat
- *                    [C0 | C1], ncsnpp.py:337) into per-(b,c) affine pairs
- *                    a = rstd*gamma[c], d = beta[c] - mean*rstd*gamma[c]  (biased variance). */
-int fd_channel_sums(const void* x, double* sums, int B, int H, int W, int C, int dtype, void* stream);
-int fd_gn_finalize(const double* sums0, int C0, const double* sums1, int C1, const float* gamma, const float* beta,
-                   float* affine, int B, int groups, long long hw, float eps, void* stream);
+/* GroupNorm statistics (nn.GroupNorm(min(C//4,32), C, eps=1e-6), layerspp.py:229,241), split in two so that one
+ * statistics pass can be shared by consumers that group the channels differently:
+ *  partial sums  : part[b][tile][stride][2] = per-channel (sum x, sum x^2) of one spatial tile, float32.  Produced
+ *                  either by fd_channel_sums (stand-alone pass; tiles = fd_channel_sums_tiles(H, W), stride = C) or by
+ *                  fd_conv2d for its OUTPUT (tiles = fd_conv_stats_tiles(H, W), stride = fd_conv_cout_pad(Cout)).
+ *  fd_gn_finalize: reduce the partials of one or two tensors (virtual channel concat [C0 | C1], ncsnpp.py:337) in
+ *                  float64 and emit per-(b,c) affine pairs a = rstd*gamma[c], d = beta[c] - mean*rstd*gamma[c]. */
+int fd_channel_sums_tiles(int H, int W);
+int fd_channel_sums(const void* x, float* part, int B, int H, int W, int C, int dtype, void* stream);
+int fd_gn_finalize(const float* part0, int tiles0, int stride0, int C0, const float* part1, int tiles1, int stride1, int C1,
+                   const float* gamma, const float* beta, float* affine, int B, int groups, long long hw, float eps,
+                   void* stream);
 
-/* Packs a PyTorch conv weight [Cout][Cin][k][k] float32 (device) into the MFMA layout
- * [chunk][tap][CoutPad][32] (bf16 or f32), channels split at `C0` into two 32-padded segments
- * (virtual concat).  fd_conv_packed_bytes gives the byte size of the destination. */
-long long fd_conv_packed_bytes(int Cout, int C0, int C1, int ksize, int wdtype);
-int fd_conv_pack_weights(const float* w, void* packed, int Cout, int C0, int C1, int ksize, int wdtype, void* stream);
+/* Packs PyTorch conv weights [Cout][Cin][k][k] float32 (device) into the MFMA layout [step][CoutPad][80 B]
+ * (bf16: 32 channels, f32: 16 channels + 16 B pad per row; step = (concat segment, channel chunk, tap)).  Input channels
+ * are split at C0 into two chunk-padded segments (virtual concat).  `w_sc` (optional, [Cout][S0+S1][1][1]) is the
+ * 1x1 shortcut conv of a ResnetBlock (Conv_2, layerspp.py:244-245) whose K steps are appended so that one launch
+ * computes Conv_1(h) + Conv_2(x). */
+long long fd_conv_packed_bytes(int Cout, int C0, int C1, int ksize, int S0, int S1, int wdtype);
+int fd_conv_pack_weights(const float* w, const float* w_sc, void* packed, int Cout, int C0, int C1, int ksize, int S0, int S1,
+                         int wdtype, void* stream);
+int fd_conv_cout_pad(int Cout);          /* row count of a packed slab / channel stride of the stats partials */
+int fd_conv_stats_tiles(int H, int W);   /* 16x16 tiles per image */
 
 /* Implicit-GEMM convolution, stride 1, 'same' zero padding, ksize 3 or 1 (ddpm_conv3x3 / ddpm_conv1x1,
  * layers.py:110-134) on MFMA:
- *   out = scale * ( conv( act([in0 | in1]) ) + bias[b] + skip )
- * act(x) = silu(a*x+d) per (b,c) if `affine` != NULL (GroupNorm+SiLU folded into the operand load),
- * identity otherwise; [in0|in1] is a virtual channel concat (in1 may be NULL, C1 = 0);
- * bias: [bias_rows][Cout] float32 with bias_rows in {1, B} (conv bias + Dense_0(act(temb)), layerspp.py:272-273);
- * skip: optional NHWC tensor of `Cout` channels ((x+h)/sqrt(2), layerspp.py:281-284; Combine 'sum' :66).
- * `wdtype` selects the arithmetic: FD_BF16 = bf16 operands / f32 accumulate (v_mfma_f32_32x32x16_bf16),
- * FD_F32 = exact f32 (v_mfma_f32_32x32x2_f32).  Channel counts must be multiples of 8 (in) / 4 (out). */
-int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const float* affine, const void* packed_w,
-              const float* bias, int bias_rows, const void* skip, float scale, void* out, int Cout, int B, int H, int W,
-              int ksize, int dtype, int wdtype, void* stream);
+ *   out = scale * ( conv_k( act([in0 | in1]) ) + conv_1x1([sc0 | sc1]) + bias[b] + skip )
+ * act(x) = silu(a*x+d) per (b,c) if `affine` != NULL (GroupNorm+SiLU folded into the operand load), identity otherwise;
+ * [in0|in1] / [sc0|sc1] are virtual channel concats (second tensors optional); bias: [bias_rows][Cout] float32 with
+ * bias_rows in {1, B} (conv bias + Dense_0(act(temb)), layerspp.py:272-273); skip: optional NHWC tensor of Cout
+ * channels ((x+h)/sqrt(2), layerspp.py:281-284); stats: optional partial sums of the output (see above).
+ * dtype selects storage AND arithmetic: FD_BF16 = bf16 operands / f32 accumulate (v_mfma_f32_32x32x16_bf16),
+ * FD_F32 = exact f32 (v_mfma_f32_32x32x2_f32).  Input channel counts must be multiples of 8, Cout 4 or a multiple of 8. */
+int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const float* affine, const void* sc0, int S0, const void* sc1,
+              int S1, const void* packed_w, const float* bias, int bias_rows, const void* skip, float scale, void* out,
+              int Cout, float* stats, int B, int H, int W, int ksize, int dtype, void* stream);
+/* Tuning hook used by the benchmarks ("conv_variant": 0 auto, 1 force the 4-wave BN=128 configuration). */
+int fd_tuning_set(const char* key, int value);
 
 /* Time embedding: GaussianFourierProjection -> Linear -> SiLU -> Linear (ncsnpp.py:263-274,
  * layerspp.py:42-51); t [nt] float32 -> temb [nt][4*nf]. */

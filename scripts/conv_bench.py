@@ -23,6 +23,8 @@ SHAPES = [  # name, H, W, C0, C1, Cout, k, affine, skip
     ("L0 256->256 1x1", 768, 256, 256, 0, 256, 1, False, False),
     ("L0 256->4 3x3 head aff", 768, 256, 256, 0, 4, 3, True, True),
 ]
+# ResBlock tail with the shortcut conv folded in: Conv_1(256->256 3x3, aff) + Conv_2(512->256 1x1)
+FOLDED = [("L0 rb31 tail 256+sc512", 768, 256, 256, 512), ("L0 rb4 tail 256+sc64", 768, 256, 256, 64)]
 
 
 def main():
@@ -31,8 +33,12 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--stats", type=int, default=1)
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    from flowdec_amd import _lib as L
+    L.check(L.load().fd_tuning_set(b"conv_variant", a.variant))
     g = torch.Generator(device="cuda").manual_seed(0)
     for i, (name, H, W, C0, C1, Cout, k, aff, skip) in enumerate(SHAPES):
         if a.only >= 0 and i != a.only:
@@ -46,7 +52,7 @@ def main():
                               0.1 * torch.randn(B, C0 + C1, device="cuda", generator=g)], -1).contiguous() if aff else None
         bias = torch.randn(Cout, device="cuda", generator=g)
         sk = torch.randn(B, H, W, Cout, device="cuda", generator=g).to(dt) if skip else None
-        f = lambda: ops.conv2d(x0, pw, Cout, k, x1=x1, affine=affine, bias=bias, skip=sk, scale=0.7071)
+        f = lambda: ops.conv2d(x0, pw, Cout, k, x1=x1, affine=affine, bias=bias, skip=sk, scale=0.7071, want_stats=bool(a.stats) and Cout > 4)
         f(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -56,6 +62,33 @@ def main():
         ms = e0.elapsed_time(e1) / a.iters
         fl = 2.0 * B * H * W * Cout * (C0 + C1) * k * k
         print(f"{i:2d} {name:28s} B={B} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s", flush=True)
+    if a.only < 0:
+        folded(a)
+
+
+def folded(a):
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for name, H, W, C, S in FOLDED:
+        B = a.B
+        x0 = torch.randn(B, H, W, C, device="cuda", generator=g).to(dt)
+        s0 = torch.randn(B, H, W, min(S, 256), device="cuda", generator=g).to(dt)
+        s1 = torch.randn(B, H, W, S - 256, device="cuda", generator=g).to(dt) if S > 256 else None
+        w = torch.randn(C, C, 3, 3, device="cuda", generator=g) / (9 * C) ** 0.5
+        ws = torch.randn(C, S, 1, 1, device="cuda", generator=g) / S ** 0.5
+        pw = ops.pack_conv_weight(w, dtype=dt, w_sc=ws, S0=min(S, 256))
+        affine = torch.stack([1 + 0.1 * torch.randn(B, C, device="cuda", generator=g), 0.1 * torch.randn(B, C, device="cuda", generator=g)], -1).contiguous()
+        bias = torch.randn(C, device="cuda", generator=g)
+        f = lambda: ops.conv2d(x0, pw, C, 3, affine=affine, bias=bias, scale=0.7071, sc0=s0, sc1=s1, want_stats=True)
+        f(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            f()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        fl = 2.0 * B * H * W * C * (C * 9 + S)
+        print(f"   {name:28s} B={B} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":

@@ -56,27 +56,31 @@ def bf16r(a):
 # conv (MFMA implicit GEMM)
 # ---------------------------------------------------------------------------------------------------------
 CONV_CASES = [
-    # name, B, H, W, C0, C1, Cout, k, affine, bias_rows, skip
-    ("3x3_basic", 1, 16, 16, 32, 0, 128, 3, False, 0, False),
-    ("3x3_two_ntiles", 2, 32, 16, 64, 0, 256, 3, False, 1, False),
-    ("3x3_affine_bias_skip", 2, 16, 32, 64, 0, 128, 3, True, 2, True),
-    ("3x3_concat", 1, 16, 16, 64, 32, 128, 3, True, 1, True),
-    ("3x3_concat_pad", 2, 16, 16, 32, 16, 128, 3, True, 1, False),     # second segment padded to a chunk
-    ("3x3_partial_tiles", 1, 24, 8, 32, 0, 128, 3, True, 1, True),     # W = 8 < tile, H not multiple of 16
-    ("3x3_head_cout4", 2, 16, 16, 128, 0, 4, 3, True, 1, True),
-    ("3x3_small_c8", 1, 16, 16, 8, 0, 8, 3, True, 1, False),
-    ("3x3_cout16", 1, 32, 16, 16, 8, 16, 3, True, 1, True),
-    ("1x1_basic", 2, 16, 16, 64, 0, 128, 1, False, 1, False),
-    ("1x1_concat", 1, 16, 16, 128, 64, 256, 1, False, 1, False),
-    ("1x1_small", 2, 8, 8, 8, 0, 32, 1, False, 1, False),
-    ("3x3_deepk", 1, 16, 16, 256, 256, 256, 3, True, 1, True),
+    # name, B, H, W, C0, C1, Cout, k, affine, bias_rows, skip, S0, S1 (folded 1x1 shortcut conv operand)
+    ("3x3_basic", 1, 16, 16, 32, 0, 128, 3, False, 0, False, 0, 0),
+    ("3x3_two_ntiles", 2, 32, 16, 64, 0, 256, 3, False, 1, False, 0, 0),
+    ("3x3_affine_bias_skip", 2, 16, 32, 64, 0, 128, 3, True, 2, True, 0, 0),
+    ("3x3_concat", 1, 16, 16, 64, 32, 128, 3, True, 1, True, 0, 0),
+    ("3x3_concat_pad", 2, 16, 16, 32, 16, 128, 3, True, 1, False, 0, 0),     # second segment padded to a chunk
+    ("3x3_partial_tiles", 1, 24, 8, 32, 0, 128, 3, True, 1, True, 0, 0),     # W = 8 < tile, H not multiple of 16
+    ("3x3_head_cout4", 2, 16, 16, 128, 0, 4, 3, True, 1, True, 0, 0),
+    ("3x3_small_c8", 1, 16, 16, 8, 0, 8, 3, True, 1, False, 0, 0),
+    ("3x3_cout16", 1, 32, 16, 16, 8, 16, 3, True, 1, True, 0, 0),
+    ("1x1_basic", 2, 16, 16, 64, 0, 128, 1, False, 1, False, 0, 0),
+    ("1x1_concat", 1, 16, 16, 128, 64, 256, 1, False, 1, False, 0, 0),
+    ("1x1_small", 2, 8, 8, 8, 0, 32, 1, False, 1, False, 0, 0),
+    ("3x3_deepk", 1, 16, 16, 256, 256, 256, 3, True, 1, True, 0, 0),
+    ("3x3_shortcut", 2, 16, 16, 256, 0, 256, 3, True, 1, False, 64, 0),      # ResBlock 64->256: Conv_1(h) + Conv_2(x)
+    ("3x3_shortcut_cat", 1, 32, 16, 128, 0, 128, 3, True, 1, False, 128, 256),  # up-path block: shortcut over cat(h, skip)
+    ("3x3_shortcut_small", 1, 16, 16, 32, 0, 32, 3, True, 1, False, 32, 16),
+    ("3x3_wide_image", 1, 16, 48, 32, 0, 256, 3, True, 1, True, 0, 0),
 ]
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv2d(ops, case, prec):
-    name, B, H, W, C0, C1, Cout, k, use_aff, bias_rows, use_skip = case
+    name, B, H, W, C0, C1, Cout, k, use_aff, bias_rows, use_skip, S0, S1 = case
     import zlib
     rng = np.random.default_rng(zlib.crc32(name.encode()))
     dt = DT[prec]
@@ -95,6 +99,14 @@ def test_conv2d(ops, case, prec):
             xin = bf16r(xin)  # the kernel rounds the activated operand to bf16 before the MFMA
     bias = None
     ref = O.conv2d(xin.astype(np.float64), w.astype(np.float64), None)
+    sc0 = sc1 = w_sc = None
+    if S0:
+        xs = q(rng.standard_normal((B, S0 + S1, H, W)))
+        ws = q(rng.standard_normal((Cout, S0 + S1, 1, 1)) / np.sqrt(S0 + S1))
+        ref = ref + O.conv2d(xs.astype(np.float64), ws.astype(np.float64), None)
+        sc0 = nhwc(xs[:, :S0], dt)
+        sc1 = nhwc(xs[:, S0:], dt) if S1 else None
+        w_sc = dev(ws)
     if bias_rows:
         bv = rng.standard_normal((bias_rows, Cout)).astype(np.float32)
         bias = dev(bv if bias_rows > 1 else bv[0])
@@ -109,13 +121,36 @@ def test_conv2d(ops, case, prec):
     ref = ref * scale
     x0 = nhwc(x[:, :C0], dt)
     x1 = nhwc(x[:, C0:], dt) if C1 else None
-    pw = ops.pack_conv_weight(dev(w), C0=C0, dtype=dt)
-    out = ops.conv2d(x0, pw, Cout, k, x1=x1, affine=aff, bias=bias, skip=skip, scale=scale)
+    pw = ops.pack_conv_weight(dev(w), C0=C0, dtype=dt, w_sc=w_sc, S0=S0 if S0 else None)
+    out, stats = ops.conv2d(x0, pw, Cout, k, x1=x1, affine=aff, bias=bias, skip=skip, scale=scale, sc0=sc0, sc1=sc1, want_stats=True)
     torch.cuda.synchronize()
     got = from_nhwc(out)
     # bf16: output rounding 2^-9 relative + transcendental differences of the fused SiLU; f32: accumulation order
     tol = 6e-3 if prec == "bf16" else 2e-5
     check(f"conv2d[{name},{prec}]", got, ref, tol)
+    # fused GroupNorm partial sums of the (un-rounded) output: reduce over tiles, compare with the reference sums
+    st = stats.double().sum(dim=1).cpu().numpy()[:, :Cout]            # [B, Cout, 2]
+    ref_s = np.stack([ref.sum(axis=(2, 3)), (ref ** 2).sum(axis=(2, 3))], axis=-1)
+    tol_s = 3e-3 if prec == "bf16" else 2e-5
+    e = float(np.abs(st - ref_s).max() / np.abs(ref_s).max())
+    report(f"conv2d_stats[{name},{prec}]", e, tol_s)
+    assert e < tol_s
+    assert float(stats[:, :, Cout:].abs().max()) == 0.0 if stats.shape[2] > Cout else True
+
+
+def test_conv2d_stats_feed_groupnorm(ops):
+    """conv output partials -> fd_gn_finalize == GroupNorm statistics of the stored tensor."""
+    rng = np.random.default_rng(11)
+    B, H, W, Ci, Co = 2, 32, 16, 32, 256
+    x = rng.standard_normal((B, Ci, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Co, Ci, 3, 3)) / np.sqrt(9 * Ci)).astype(np.float32)
+    gam = (1 + 0.1 * rng.standard_normal(Co)).astype(np.float32); bet = (0.1 * rng.standard_normal(Co)).astype(np.float32)
+    out, stats = ops.conv2d(nhwc(x, torch.float32), ops.pack_conv_weight(dev(w), dtype=torch.float32), Co, 3, want_stats=True)
+    aff = ops.gn_finalize(stats, Co, None, 0, dev(gam), dev(bet), 32, H * W).cpu().numpy()
+    o = from_nhwc(out)
+    got = o * aff[:, :, 0][:, :, None, None] + aff[:, :, 1][:, :, None, None]
+    ref = O.group_norm(o.astype(np.float64), 32, gam.astype(np.float64), bet.astype(np.float64))
+    check("conv_stats_to_groupnorm", got, ref, 5e-6)
 
 
 def test_conv2d_matches_torch_layout(ops):
