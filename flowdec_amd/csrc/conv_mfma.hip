@@ -22,6 +22,8 @@
 //     squares of the f32 result are reduced per tile for the consumer GroupNorm (deterministic, no atomics).
 #include <string.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "internal.h"
 
@@ -107,7 +109,7 @@ __device__ __forceinline__ u32x4 transform_slot(u32x4 raw, const char* ad) {
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 constexpr int AFF_BYTES = 512 * 8;  // per-(b,c) (a,d) pairs of up to 512 activated input channels, staged in LDS
-constexpr int HLAG = 1;             // a halo slot loaded in phase B of tap i is transformed + stored in phase A of tap i + HLAG
+constexpr int HLAG = 2;             // a halo slot loaded in phase B of tap i is transformed + stored in phase A of tap i + HLAG
 
 template <int WM, int WN, int MT, int NT>
 struct Geo {
@@ -118,7 +120,8 @@ struct Geo {
   static constexpr int BN = WN * NT * 32;
   static constexpr int HALO_BYTES = HH * PITCH * ROWB;
   static constexpr int W_BYTES = BN * ROWB;
-  static constexpr int MAIN_BYTES = 2 * HALO_BYTES + 2 * W_BYTES + AFF_BYTES;
+  static constexpr int W_LDS = (W_BYTES + 1023) / 1024 * 1024;  // LDS size of one weight buffer (DMA granularity)
+  static constexpr int MAIN_BYTES = 2 * HALO_BYTES + 2 * W_LDS + AFF_BYTES;
   // epilogue staging: one M-tile row of the block (WM * 32 pixels) x BN floats (+16 B pad per pixel)
   static constexpr int EP_PIX = WM * 32;
   static constexpr int EP_ROWB = BN * 4 + 16;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const hbuf = smem;
   char* const wbuf = smem + 2 * G::HALO_BYTES;
-  char* const afftab = wbuf + 2 * G::W_BYTES;
+  char* const afftab = wbuf + 2 * G::W_LDS;
 
   // ---- tile decode with XCD-aware remap: consecutive logical tiles share an XCD's L2 ------------------------
   const int bid = blockIdx.x, nblk = gridDim.x;
@@ -209,16 +212,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // direct-to-LDS DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB per wave instruction, destination =
   // wave-uniform base + lane * 16).  No VGPR staging, no ds_write.
   auto dma_w = [&](int step, int buf) {
-    constexpr int UNITS = G::W_BYTES / 16;
-    const char* src = reinterpret_cast<const char*>(p.w) + ((size_t)step * p.CoutPad + n0) * ROWB;
-    char* dst = wbuf + buf * G::W_BYTES;
-    const int wv = __builtin_amdgcn_readfirstlane(t >> 6), ln = t & 63;
+    // straight-line code (no exec masking, no branches): the slab is copied in NPIECE 1-KiB pieces, every wave issues
+    // PER_WAVE of them; surplus slots re-copy another piece (identical bytes), and a partial last piece over-reads into
+    // the next slab / the 1 KiB slack of the packed buffer and lands in the padding of the (1 KiB-rounded) LDS buffer.
+    constexpr int NPIECE = G::W_LDS / 1024;
+    constexpr int NW = G::NTH / 64;
+    constexpr int PER_WAVE = (NPIECE + NW - 1) / NW;
+    const char* src = reinterpret_cast<const char*>(p.w) + ((size_t)step * p.CoutPad + n0) * ROWB + (t & 63) * 16;
+    char* dst = wbuf + buf * G::W_LDS;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
 #pragma unroll
-    for (int k = 0; k < (UNITS + G::NTH - 1) / G::NTH; ++k) {
-      const int pce = wv + k * (G::NTH / 64);
-      if (pce * 64 + ln < UNITS)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pce * 1024 + ln * 16),
-                                         (__attribute__((address_space(3))) void*)(dst + pce * 1024), 16, 0, 0);
+    for (int k = 0; k < PER_WAVE; ++k) {
+      const int pce = (wv + k * NW) % NPIECE;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pce * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + pce * 1024), 16, 0, 0);
     }
   };
 
@@ -266,13 +273,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const int nsteps = n9 * 9 + n1;
   constexpr int CENTER = (PITCH + 1) * ROWB;
 
-  // Every barrier of the main loop must first drain this wave's LDS-DMA (and halo loads): hipcc's own waitcnt insertion
-  // loses the pending global_load_lds across the loop back-edge (it emitted a bare lgkmcnt(0) before the first barrier of
-  // the unrolled body), which let other waves read a weight piece that had not landed yet.
-  auto block_sync = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  // Every barrier of the main loop first waits for this wave's LDS-DMA explicitly: hipcc's own waitcnt insertion loses the
+  // pending global_load_lds across the loop back-edge (it emitted a bare lgkmcnt(0) before the first barrier of the
+  // unrolled body), which let other waves read a weight piece that had not landed yet.  KEEP = number of YOUNGER vector
+  // loads that may stay in flight across the barrier (the halo slot load issued after the DMA in the previous phase B).
+  auto block_sync = [&](auto keep) {
+    if constexpr (decltype(keep)::value == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+
   u32x4 wfA[NT], pfA[MT], wfB[NT], pfB[MT];
   auto read_frags = [&](u32x4 (&wf)[NT], u32x4 (&pf)[MT], const char* hb, const char* wb, int off) {
 #pragma unroll
@@ -280,20 +293,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) pf[mi] = *reinterpret_cast<const u32x4*>(hb + pbase[mi] + off);
   };
-  // MFMAs of one k-half with the NEXT fragment reads issued right after the first MFMA: the compiler's s_waitcnt
-  // before the first MFMA then only covers the (old) fragments it consumes, and the new reads fly under the other MFMAs.
-  auto mma_then = [&](const u32x4 (&wf)[NT], const u32x4 (&pf)[MT], auto&& issue_reads) {
-    __builtin_amdgcn_sched_barrier(0);
-    Math<T>::mma(acc[0][0], wf[0], pf[0]);
-    __builtin_amdgcn_sched_barrier(0);
-    issue_reads();
-    __builtin_amdgcn_sched_barrier(0);
+  // All MFMAs of one k-half.  The caller has already issued (in program order) the non-MFMA work of the phase; the
+  // instruction-group hints ask the scheduler to spread that work BETWEEN the MFMAs (a few instructions per gap run under
+  // the 32-cycle MFMA issue interval) instead of as a serial block while the matrix pipe idles.
+  auto mma_all = [&](const u32x4 (&wf)[NT], const u32x4 (&pf)[MT]) {
 #pragma unroll
     for (int nj = 0; nj < NT; ++nj)
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi)
-        if (nj + mi > 0) Math<T>::mma(acc[mi][nj], wf[nj], pf[mi]);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int mi = 0; mi < MT; ++mi) Math<T>::mma(acc[mi][nj], wf[nj], pf[mi]);
+    constexpr int NM = MT * NT * (sizeof(T) == 2 ? 1 : 4);
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+      __builtin_amdgcn_sched_group_barrier(0x004, 4, 0);   // 4 SALU
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
+    }
   };
 
   int step = 0, hcur = 0;
@@ -301,10 +318,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #pragma unroll
   for (int i = 0; i < G::HITER; ++i) load_halo_slot(i);
   dma_w(0, 0);
-  if (nsteps > 1) dma_w(1, 1);
+  dma_w(nsteps > 1 ? 1 : 0, 1);
 #pragma unroll
   for (int i = 0; i < G::HITER; ++i) store_halo_slot(i, 0);
-  block_sync();
+  block_sync(K0{});
   read_frags(wfA, pfA, hbuf, wbuf, n9 > 0 ? 0 : CENTER);  // (the k-half ks = 1 is addressed by passing hb + 32 / wb + 32)
 
   int cs = 0, cch = 0;  // (segment, chunk) cursor
@@ -312,13 +329,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     ++ch_;
     if (ch_ >= (p.seg[s_].C + CK - 1) / CK) { ++s_; ch_ = 0; }
   };
+  const int last_step = nsteps - 1;
 
   // Two sequential loops (all 9-tap chunks, then all 1-tap shortcut chunks) so that each loop has a single MFMA
   // site pair: with both tap counts inside one loop the compiler keeps two copies of the 128-register accumulator.
+  // The phases are straight-line code: work past the end of the K loop (the DMA / halo prefetch / fragment reads of the
+  // last steps) is not branched around but redirected to harmless targets (re-load of the last slab / the current chunk).
   for (int i = 0; i < n9; ++i) {
     const bool last_chunk = (i == n9 - 1) && n1 == 0;
-    advance(cs, cch);
-    if (!last_chunk) next_chunk(cs, cch);
+    if (!last_chunk) { advance(cs, cch); next_chunk(cs, cch); }   // else: keep prefetching the current chunk (unused)
     const char* hb = hbuf + hcur * G::HALO_BYTES;
     const char* hbn = hbuf + (hcur ^ 1) * G::HALO_BYTES;
     const int first_off_next = (i == n9 - 1) ? CENTER : 0;
@@ -326,49 +345,45 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     for (int tap = 0; tap < 9; ++tap) {
       const int imm = ((tap / 3) * PITCH + (tap % 3)) * ROWB;
       const int imm_next = (((tap + 1) / 3) * PITCH + ((tap + 1) % 3)) * ROWB;
-      const bool m1 = step + 1 < nsteps, m2 = step + 2 < nsteps;
-      const char* wb = wbuf + (step & 1) * G::W_BYTES;
-      const char* wbn = wbuf + ((step + 1) & 1) * G::W_BYTES;
-      // ---- phase A
-      if (tap >= HLAG && tap - HLAG < G::HITER && !last_chunk) store_halo_slot(tap - HLAG, hcur ^ 1);
-      mma_then(wfA, pfA, [&]() { read_frags(wfB, pfB, hb + 32, wb + 32, imm); });
-      block_sync();
-      // ---- phase B
-      if (m2) dma_w(step + 2, step & 1);
-      if (tap < G::HITER && !last_chunk) load_halo_slot(tap);
-      mma_then(wfB, pfB, [&]() {
-        if (m1) {
-          if (tap < 8) read_frags(wfA, pfA, hb, wbn, imm_next);
-          else read_frags(wfA, pfA, hbn, wbn, first_off_next);
-        }
-      });
+      const char* wb = wbuf + (step & 1) * G::W_LDS;
+      const char* wbn = wbuf + ((step + 1) & 1) * G::W_LDS;
+      // ---- phase A: [store halo slot] | read frags(s, ks=1) || MFMA(s, ks=0)
+      if (tap >= HLAG && tap - HLAG < G::HITER) store_halo_slot(tap - HLAG, hcur ^ 1);
+      read_frags(wfB, pfB, hb + 32, wb + 32, imm);
+      mma_all(wfA, pfA);
+      block_sync(K0{});  // (K1 would need the DMA-before-halo-load issue order pinned; not relied upon)
+      // ---- phase B: DMA w(s+2) | [load halo slot] | read frags(s+1, ks=0) || MFMA(s, ks=1)
+      dma_w(step + 2 <= last_step ? step + 2 : last_step, step & 1);
+      if (tap < G::HITER) load_halo_slot(tap);
+      if (tap < 8) read_frags(wfA, pfA, hb, wbn, imm_next);
+      else read_frags(wfA, pfA, hbn, wbn, first_off_next);
+      mma_all(wfB, pfB);
       ++step;
     }
     hcur ^= 1;
   }
   for (int i = 0; i < n1; ++i) {
-    const bool m1 = step + 1 < nsteps, m2 = step + 2 < nsteps;
+    const bool m1 = step + 1 < nsteps;
     const char* hb = hbuf + hcur * G::HALO_BYTES;
     const char* hbn = hbuf + (hcur ^ 1) * G::HALO_BYTES;
-    const char* wb = wbuf + (step & 1) * G::W_BYTES;
-    const char* wbn = wbuf + ((step + 1) & 1) * G::W_BYTES;
-    advance(cs, cch);
-    if (m1) {  // the next 1-tap chunk's halo: loaded and published within this step
-      next_chunk(cs, cch);
+    const char* wb = wbuf + (step & 1) * G::W_LDS;
+    const char* wbn = wbuf + ((step + 1) & 1) * G::W_LDS;
+    if (m1) { advance(cs, cch); next_chunk(cs, cch); }
+    // the next 1-tap chunk's halo: loaded and published within this step
 #pragma unroll
-      for (int k = 0; k < G::HITER; ++k) load_halo_slot(k);
-    }
-    mma_then(wfA, pfA, [&]() { read_frags(wfB, pfB, hb + 32, wb + 32, CENTER); });
-    if (m1) {
+    for (int k = 0; k < G::HITER; ++k) load_halo_slot(k);
+    read_frags(wfB, pfB, hb + 32, wb + 32, CENTER);
+    mma_all(wfA, pfA);
 #pragma unroll
-      for (int k = 0; k < G::HITER; ++k) store_halo_slot(k, hcur ^ 1);
-    }
-    block_sync();
-    if (m2) dma_w(step + 2, step & 1);
-    mma_then(wfB, pfB, [&]() { if (m1) read_frags(wfA, pfA, hbn, wbn, CENTER); });
+    for (int k = 0; k < G::HITER; ++k) store_halo_slot(k, hcur ^ 1);
+    block_sync(K0{});
+    dma_w(step + 2 <= last_step ? step + 2 : last_step, step & 1);
+    read_frags(wfA, pfA, hbn, wbn, CENTER);
+    mma_all(wfB, pfB);
     ++step; hcur ^= 1;
   }
-  __syncthreads();  // all fragment reads done before the epilogue reuses the LDS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // all fragment reads / DMA done before the epilogue reuses the LDS
 
   // ---- epilogue ------------------------------------------------------------------------------------------------------
   // MT rounds; in round mi every wave stages its acc[mi][*] (32 pixels x NT*32 couts, f32) to LDS as
@@ -550,7 +565,8 @@ extern "C" int fd_conv_stats_tiles(int H, int W) { return fd_cdiv(H, 16) * fd_cd
 
 extern "C" long long fd_conv_packed_bytes(int Cout, int C0, int C1, int ksize, int S0, int S1, int wdtype) {
   const int CK = wdtype == FD_BF16 ? 32 : 16;
-  return (long long)(n_steps(C0, C1, ksize * ksize, CK) + n_steps(S0, S1, 1, CK)) * cout_pad(Cout) * ROWB;
+  // + 1 KiB slack: the DMA of a partial last 1-KiB piece (BN = 32 configuration) over-reads past the final slab
+  return (long long)(n_steps(C0, C1, ksize * ksize, CK) + n_steps(S0, S1, 1, CK)) * cout_pad(Cout) * ROWB + 1024;
 }
 
 extern "C" int fd_conv_pack_weights(const float* w, const float* w_sc, void* packed, int Cout, int C0, int C1, int ksize, int S0,
