@@ -109,7 +109,10 @@ __device__ __forceinline__ u32x4 transform_slot(u32x4 raw, const char* ad) {
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 constexpr int AFF_BYTES = 512 * 8;  // per-(b,c) (a,d) pairs of up to 512 activated input channels, staged in LDS
-constexpr int HLAG = 2;             // a halo slot loaded in phase B of tap i is transformed + stored in phase A of tap i + HLAG
+#ifndef FD_HLAG
+#define FD_HLAG 3
+#endif
+constexpr int HLAG = FD_HLAG;             // a halo slot loaded in phase B of tap i is transformed + stored in phase A of tap i + HLAG
 
 template <int WM, int WN, int MT, int NT>
 struct Geo {
@@ -121,7 +124,9 @@ struct Geo {
   static constexpr int HALO_BYTES = HH * PITCH * ROWB;
   static constexpr int W_BYTES = BN * ROWB;
   static constexpr int W_LDS = (W_BYTES + 1023) / 1024 * 1024;  // LDS size of one weight buffer (DMA granularity)
-  static constexpr int MAIN_BYTES = 2 * HALO_BYTES + 2 * W_LDS + AFF_BYTES;
+  static constexpr int NWBUF = BN <= 32 ? 2 : 3;                  // weight slabs in LDS: DMA runs NWBUF-1 steps ahead (the small
+                                                                  // config keeps 2 so that two workgroups fit a CU)
+  static constexpr int MAIN_BYTES = 2 * HALO_BYTES + NWBUF * W_LDS + AFF_BYTES;
   // epilogue staging: one M-tile row of the block (WM * 32 pixels) x BN floats (+16 B pad per pixel)
   static constexpr int EP_PIX = WM * 32;
   static constexpr int EP_ROWB = BN * 4 + 16;
@@ -131,6 +136,7 @@ struct Geo {
   static constexpr int NPASS = EP_PIX / PPASS;
   static constexpr int ST_BYTES = PPASS * BN * 2 * 4;
   static constexpr int LDS_BYTES = cmax(MAIN_BYTES, cmax(EP_BYTES, ST_BYTES));
+  static constexpr int DMA_PER_WAVE = (W_LDS / 1024 + NTH / 64 - 1) / (NTH / 64);  // DMA instructions per wave per slab
   static constexpr int PPP = NTH / 4;            // rows covered per loader pass (4 slots per row)
   static constexpr int HITER = (HH * HW + PPP - 1) / PPP;
   static_assert(EP_PIX % PPASS == 0, "epilogue pass geometry");
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const hbuf = smem;
   char* const wbuf = smem + 2 * G::HALO_BYTES;
-  char* const afftab = wbuf + 2 * G::W_LDS;
+  char* const afftab = wbuf + G::NWBUF * G::W_LDS;
 
   // ---- tile decode with XCD-aware remap: consecutive logical tiles share an XCD's L2 ------------------------
   const int bid = blockIdx.x, nblk = gridDim.x;
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     // the next slab / the 1 KiB slack of the packed buffer and lands in the padding of the (1 KiB-rounded) LDS buffer.
     constexpr int NPIECE = G::W_LDS / 1024;
     constexpr int NW = G::NTH / 64;
-    constexpr int PER_WAVE = (NPIECE + NW - 1) / NW;
+    constexpr int PER_WAVE = G::DMA_PER_WAVE;
     const char* src = reinterpret_cast<const char*>(p.w) + ((size_t)step * p.CoutPad + n0) * ROWB + (t & 63) * 16;
     char* dst = wbuf + buf * G::W_LDS;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -273,18 +279,32 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const int nsteps = n9 * 9 + n1;
   constexpr int CENTER = (PITCH + 1) * ROWB;
 
-  // Every barrier of the main loop first waits for this wave's LDS-DMA explicitly: hipcc's own waitcnt insertion loses the
-  // pending global_load_lds across the loop back-edge (it emitted a bare lgkmcnt(0) before the first barrier of the
-  // unrolled body), which let other waves read a weight piece that had not landed yet.  KEEP = number of YOUNGER vector
-  // loads that may stay in flight across the barrier (the halo slot load issued after the DMA in the previous phase B).
+  // Barriers of the main loop wait for this wave's LDS-DMA EXPLICITLY: hipcc's own waitcnt insertion loses a pending
+  // global_load_lds across the loop back-edge (it emitted a bare lgkmcnt(0) before the first barrier of the unrolled
+  // body), which let other waves read a weight piece that had not landed.  The wait is COUNTED: an LDS-DMA slab takes
+  // about one step (~1 us under load) from issue to landed, so slabs are issued TWO steps ahead into three LDS buffers
+  // and a barrier only retires everything older than the vector-memory ops of the immediately preceding phase B
+  // (KEEP = DMA_PER_WAVE pieces of the youngest slab + the halo slot load, in whatever order the scheduler emitted them).
   auto block_sync = [&](auto keep) {
-    if constexpr (decltype(keep)::value == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    constexpr int KEEP = decltype(keep)::value;
+    static_assert(KEEP >= 0 && KEEP <= 8, "vmcnt immediate");
+    if constexpr (KEEP == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (KEEP == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (KEEP == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (KEEP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (KEEP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (KEEP == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (KEEP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (KEEP == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
   using K0 = std::integral_constant<int, 0>;
-  using K1 = std::integral_constant<int, 1>;
+  // with only two slabs the youngest DMA is the one the barrier must retire -> full drain
+  using KD = std::integral_constant<int, G::NWBUF == 3 ? G::DMA_PER_WAVE : 0>;        // previous phase B issued a slab only
+  using KDH = std::integral_constant<int, G::NWBUF == 3 ? G::DMA_PER_WAVE + 1 : 0>;   // ... and one halo slot load
 
   u32x4 wfA[NT], pfA[MT], wfB[NT], pfB[MT];
   auto read_frags = [&](u32x4 (&wf)[NT], u32x4 (&pf)[MT], const char* hb, const char* wb, int off) {
@@ -297,11 +317,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // instruction-group hints ask the scheduler to spread that work BETWEEN the MFMAs (a few instructions per gap run under
   // the 32-cycle MFMA issue interval) instead of as a serial block while the matrix pipe idles.
   auto mma_all = [&](const u32x4 (&wf)[NT], const u32x4 (&pf)[MT]) {
+#ifdef FD_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int nj = 0; nj < NT; ++nj)
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) Math<T>::mma(acc[mi][nj], wf[nj], pf[mi]);
+#ifdef FD_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     constexpr int NM = MT * NT * (sizeof(T) == 2 ? 1 : 4);
+#ifndef FD_NO_SGB
 #pragma unroll
     for (int i = 0; i < NM; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
@@ -311,14 +338,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
       __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
     }
+#endif
   };
 
   int step = 0, hcur = 0;
+  int ws0 = 0, ws1 = 1, ws2 = 2;  // LDS slab holding w(step), w(step+1), w(step+2); rotated every step
   next_chunk(0, 0);
 #pragma unroll
   for (int i = 0; i < G::HITER; ++i) load_halo_slot(i);
+  const int last_step = nsteps - 1;
   dma_w(0, 0);
-  dma_w(nsteps > 1 ? 1 : 0, 1);
+  dma_w(1 <= last_step ? 1 : last_step, 1);
+  if constexpr (G::NWBUF == 3) dma_w(2 <= last_step ? 2 : last_step, 2);
 #pragma unroll
   for (int i = 0; i < G::HITER; ++i) store_halo_slot(i, 0);
   block_sync(K0{});
@@ -329,7 +360,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     ++ch_;
     if (ch_ >= (p.seg[s_].C + CK - 1) / CK) { ++s_; ch_ = 0; }
   };
-  const int last_step = nsteps - 1;
 
   // Two sequential loops (all 9-tap chunks, then all 1-tap shortcut chunks) so that each loop has a single MFMA
   // site pair: with both tap counts inside one loop the compiler keeps two copies of the 128-register accumulator.
@@ -345,20 +375,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     for (int tap = 0; tap < 9; ++tap) {
       const int imm = ((tap / 3) * PITCH + (tap % 3)) * ROWB;
       const int imm_next = (((tap + 1) / 3) * PITCH + ((tap + 1) % 3)) * ROWB;
-      const char* wb = wbuf + (step & 1) * G::W_LDS;
-      const char* wbn = wbuf + ((step + 1) & 1) * G::W_LDS;
+      const char* wb = wbuf + ws0 * G::W_LDS;
+      const char* wbn = wbuf + ws1 * G::W_LDS;
       // ---- phase A: [store halo slot] | read frags(s, ks=1) || MFMA(s, ks=0)
       if (tap >= HLAG && tap - HLAG < G::HITER) store_halo_slot(tap - HLAG, hcur ^ 1);
       read_frags(wfB, pfB, hb + 32, wb + 32, imm);
       mma_all(wfA, pfA);
-      block_sync(K0{});  // (K1 would need the DMA-before-halo-load issue order pinned; not relied upon)
-      // ---- phase B: DMA w(s+2) | [load halo slot] | read frags(s+1, ks=0) || MFMA(s, ks=1)
-      dma_w(step + 2 <= last_step ? step + 2 : last_step, step & 1);
+      // retire everything but the previous phase B's own loads: w(s+1) has landed, w(s+2) may still be in flight
+      if (tap >= 1 && tap - 1 < G::HITER) block_sync(KDH{}); else block_sync(KD{});
+      // ---- phase B: DMA w(s+3) into the slab of w(s) | [load halo slot] | read frags(s+1, ks=0) || MFMA(s, ks=1)
+      dma_w(step + G::NWBUF <= last_step ? step + G::NWBUF : last_step, ws0);
       if (tap < G::HITER) load_halo_slot(tap);
       if (tap < 8) read_frags(wfA, pfA, hb, wbn, imm_next);
       else read_frags(wfA, pfA, hbn, wbn, first_off_next);
       mma_all(wfB, pfB);
       ++step;
+      { const int tmp = ws0; ws0 = ws1; if constexpr (G::NWBUF == 3) { ws1 = ws2; ws2 = tmp; } else { ws1 = tmp; } }
     }
     hcur ^= 1;
   }
@@ -366,10 +398,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     const bool m1 = step + 1 < nsteps;
     const char* hb = hbuf + hcur * G::HALO_BYTES;
     const char* hbn = hbuf + (hcur ^ 1) * G::HALO_BYTES;
-    const char* wb = wbuf + (step & 1) * G::W_LDS;
-    const char* wbn = wbuf + ((step + 1) & 1) * G::W_LDS;
+    const char* wb = wbuf + ws0 * G::W_LDS;
+    const char* wbn = wbuf + ws1 * G::W_LDS;
     if (m1) { advance(cs, cch); next_chunk(cs, cch); }
-    // the next 1-tap chunk's halo: loaded and published within this step
+    // the next 1-tap chunk's halo: loaded and published within this step (this loop drains the queue every step)
 #pragma unroll
     for (int k = 0; k < G::HITER; ++k) load_halo_slot(k);
     read_frags(wfB, pfB, hb + 32, wb + 32, CENTER);
@@ -377,10 +409,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #pragma unroll
     for (int k = 0; k < G::HITER; ++k) store_halo_slot(k, hcur ^ 1);
     block_sync(K0{});
-    dma_w(step + 2 <= last_step ? step + 2 : last_step, step & 1);
+    dma_w(step + G::NWBUF <= last_step ? step + G::NWBUF : last_step, ws0);
     read_frags(wfA, pfA, hbn, wbn, CENTER);
     mma_all(wfB, pfB);
     ++step; hcur ^= 1;
+    { const int tmp = ws0; ws0 = ws1; if constexpr (G::NWBUF == 3) { ws1 = ws2; ws2 = tmp; } else { ws1 = tmp; } }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // all fragment reads / DMA done before the epilogue reuses the LDS
