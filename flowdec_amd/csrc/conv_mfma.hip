@@ -53,6 +53,7 @@ struct ConvArgs {
   void* out;
   int Cout, CoutPad;
   float* stats;                    // [B][tiles_h*tiles_w][CoutPad][2] or null
+  unsigned long long* dbg;         // FD_TIMING builds only
   int B, H, W;
   int tiles_h, tiles_w, tiles_n;
 };
@@ -135,7 +136,7 @@ struct Geo {
   static constexpr int PPASS = NTH / OCT;        // pixels per epilogue pass
   static constexpr int NPASS = EP_PIX / PPASS;
   static constexpr int ST_BYTES = PPASS * BN * 2 * 4;
-  static constexpr int LDS_BYTES = cmax(MAIN_BYTES, cmax(EP_BYTES, ST_BYTES));
+  static constexpr int LDS_BYTES = cmax(MAIN_BYTES, cmax(2 * EP_BYTES, ST_BYTES));   // epilogue staging is double-buffered
   static constexpr int DMA_PER_WAVE = (W_LDS / 1024 + NTH / 64 - 1) / (NTH / 64);  // DMA instructions per wave per slab
   static constexpr int PPP = NTH / 4;            // rows covered per loader pass (4 slots per row)
   static constexpr int HITER = (HH * HW + PPP - 1) / PPP;
@@ -285,9 +286,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // about one step (~1 us under load) from issue to landed, so slabs are issued TWO steps ahead into three LDS buffers
   // and a barrier only retires everything older than the vector-memory ops of the immediately preceding phase B
   // (KEEP = DMA_PER_WAVE pieces of the youngest slab + the halo slot load, in whatever order the scheduler emitted them).
+#ifdef FD_TIMING
+  unsigned long long tm_vm = 0, tm_bar = 0, tm_loop0 = 0, tm_n = 0;
+#endif
   auto block_sync = [&](auto keep) {
     constexpr int KEEP = decltype(keep)::value;
     static_assert(KEEP >= 0 && KEEP <= 8, "vmcnt immediate");
+#ifdef FD_TIMING
+    const unsigned long long t_a = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (KEEP == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (KEEP == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else if constexpr (KEEP == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -297,9 +304,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     else if constexpr (KEEP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (KEEP == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#ifdef FD_TIMING
+    const unsigned long long t_b = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifdef FD_TIMING
+    const unsigned long long t_c = __builtin_amdgcn_s_memtime();
+    tm_vm += t_b - t_a; tm_bar += t_c - t_b; ++tm_n;
+#endif
   };
   using K0 = std::integral_constant<int, 0>;
   // with only two slabs the youngest DMA is the one the barrier must retire -> full drain
@@ -341,6 +355,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #endif
   };
 
+#ifdef FD_TIMING
+  tm_loop0 = __builtin_amdgcn_s_memtime();
+#endif
   int step = 0, hcur = 0;
   int ws0 = 0, ws1 = 1, ws2 = 2;  // LDS slab holding w(step), w(step+1), w(step+2); rotated every step
   next_chunk(0, 0);
@@ -417,6 +434,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // all fragment reads / DMA done before the epilogue reuses the LDS
+#ifdef FD_TIMING
+  const unsigned long long tm_loop1 = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- epilogue ------------------------------------------------------------------------------------------------------
   // MT rounds; in round mi every wave stages its acc[mi][*] (32 pixels x NT*32 couts, f32) to LDS as
@@ -439,10 +459,32 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #pragma unroll
   for (int j = 0; j < 8; ++j) ssum[j] = ssq[j] = 0.f;
 
+  // MT rounds, staging double-buffered (one barrier per round: the writes of round r+1 go to the other buffer, and
+  // every wave has finished reading round r-1 from it before it arrived at barrier r).  The skip values of a round are
+  // prefetched into registers BEFORE the staging of that round so that their latency hides behind the LDS round trip.
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
+    char* const stage = smem + (mi & 1) * G::EP_BYTES;
+    // (a) addresses + skip prefetch for this round's passes
+    size_t oaddr[G::NPASS];
+    bool ovalid[G::NPASS];
+    u32x4 skraw[G::NPASS][sizeof(T) == 2 ? 1 : 2];
+#pragma unroll
+    for (int ps = 0; ps < G::NPASS; ++ps) {
+      const int pp = prow_e + ps * G::PPASS;          // staged pixel: wm' = pp >> 5, l31' = pp & 31
+      const int pi = (pp >> 5) * MT + mi;
+      const int gh = h0 + 4 * (pi >> 1) + ((pp & 31) >> 3), gw = w0 + 8 * (pi & 1) + (pp & 7);
+      ovalid[ps] = n_ok && gh < H && gw < W;
+      oaddr[ps] = ovalid[ps] ? (((size_t)b * H + gh) * W + gw) * p.Cout + n_e : (size_t)0;
+      if (skip && n_cnt == 8) {
+        const u32x4* sp = reinterpret_cast<const u32x4*>(skip + oaddr[ps]);
+        skraw[ps][0] = sp[0];
+        if constexpr (sizeof(T) == 4) skraw[ps][1] = sp[1];
+      }
+    }
+    // (b) stage this wave's acc[mi][*] as [pixel][cout] f32
     {
-      char* dst = smem + (wm * 32 + l31) * G::EP_ROWB + (wn * NT * 32 + 4 * lh) * 4;
+      char* dst = stage + (wm * 32 + l31) * G::EP_ROWB + (wn * NT * 32 + 4 * lh) * 4;
 #pragma unroll
       for (int nj = 0; nj < NT; ++nj)
 #pragma unroll
@@ -452,48 +494,51 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         }
     }
     __syncthreads();
+    // (c) sweep: 8 couts (16 / 32 B) per lane, fully coalesced
 #pragma unroll
     for (int ps = 0; ps < G::NPASS; ++ps) {
-      const int pp = prow_e + ps * G::PPASS;          // staged pixel: wm' = pp >> 5, l31' = pp & 31
-      const int pi = (pp >> 5) * MT + mi;
-      const int gh = h0 + 4 * (pi >> 1) + ((pp & 31) >> 3), gw = w0 + 8 * (pi & 1) + (pp & 7);
-      if (n_ok && gh < H && gw < W) {
-        const float* sp = reinterpret_cast<const float*>(smem + pp * G::EP_ROWB) + oct * 8;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const size_t o = (((size_t)b * H + gh) * W + gw) * p.Cout + n_e;
-        if (n_cnt == 8) {
-          if (skip) {
-            float sk[8];
-            fd_load_vec<T, 8>(skip + o, sk);
+      if (!ovalid[ps]) continue;
+      const int pp = prow_e + ps * G::PPASS;
+      const float* sp = reinterpret_cast<const float*>(stage + pp * G::EP_ROWB) + oct * 8;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      const size_t o = oaddr[ps];
+      if (n_cnt == 8) {
+        if (skip) {
+          if constexpr (sizeof(T) == 2) {
+            const bf16x8 sk = __builtin_bit_cast(bf16x8, skraw[ps][0]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += sk[j];
-          }
+            for (int j = 0; j < 8; ++j) v[j] += (float)sk[j];
+          } else {
+            const f32x4 s0 = __builtin_bit_cast(f32x4, skraw[ps][0]), s1 = __builtin_bit_cast(f32x4, skraw[ps][1]);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            v[j] = (v[j] + bv[j]) * p.scale;
-            ssum[j] += v[j]; ssq[j] = fmaf(v[j], v[j], ssq[j]);
+            for (int j = 0; j < 4; ++j) { v[j] += s0[j]; v[4 + j] += s1[j]; }
           }
-          fd_store_vec<T, 8>(out + o, v);
-        } else {
-          float w4[4] = {v[0], v[1], v[2], v[3]};
-          if (skip) {
-            float sk[4];
-            fd_load_vec<T, 4>(skip + o, sk);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) w4[j] += sk[j];
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            w4[j] = (w4[j] + bv[j]) * p.scale;
-            ssum[j] += w4[j]; ssq[j] = fmaf(w4[j], w4[j], ssq[j]);
-          }
-          fd_store_vec<T, 4>(out + o, w4);
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v[j] = (v[j] + bv[j]) * p.scale;
+          ssum[j] += v[j]; ssq[j] = fmaf(v[j], v[j], ssq[j]);
+        }
+        fd_store_vec<T, 8>(out + o, v);
+      } else {  // 4 valid channels (pyramid heads: Cout = 4)
+        float w4[4] = {v[0], v[1], v[2], v[3]};
+        if (skip) {
+          float sk[4];
+          fd_load_vec<T, 4>(skip + o, sk);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w4[j] += sk[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          w4[j] = (w4[j] + bv[j]) * p.scale;
+          ssum[j] += w4[j]; ssq[j] = fmaf(w4[j], w4[j], ssq[j]);
+        }
+        fd_store_vec<T, 4>(out + o, w4);
       }
     }
-    __syncthreads();
   }
+  __syncthreads();
 
   if (p.stats) {  // per-tile partial sums of the output, reduced over the PPASS threads that share an octet
     float* stg = reinterpret_cast<float*>(smem);  // [PPASS][BN][2]
@@ -512,6 +557,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         p.stats[(((size_t)b * p.tiles_h * p.tiles_w + tile) * p.CoutPad + n0) * 2 + o] = a;
     }
   }
+#ifdef FD_TIMING
+  if (p.dbg && (t & 63) == 0) {
+    const unsigned long long tm_end = __builtin_amdgcn_s_memtime();
+    atomicAdd(&p.dbg[0], tm_loop1 - tm_loop0);   // main loop (incl. prologue staging)
+    atomicAdd(&p.dbg[1], tm_vm);                 // time in s_waitcnt vmcnt at barriers
+    atomicAdd(&p.dbg[2], tm_bar);                // lgkmcnt wait + barrier
+    atomicAdd(&p.dbg[3], tm_end - tm_loop1);     // epilogue
+    atomicAdd(&p.dbg[4], tm_n);                  // barriers
+    atomicAdd(&p.dbg[5], 1ull);                  // waves
+  }
+#endif
 }
 
 // ---- weight packing: [Cout][Cin][k][k] f32 -> [step][CoutPad][ROWB bytes] ------------------------------------------
@@ -547,6 +603,7 @@ inline int cout_pad(int Cout) { return Cout <= 32 ? 32 : (Cout <= 128 ? 128 : pa
 inline int n_steps(int C0, int C1, int taps, int CK) { return (fd_cdiv(C0, CK) + fd_cdiv(C1, CK)) * taps; }
 
 int g_variant = 0;  // tuning hook: 0 = auto, 1 = force the BN=128 config
+unsigned long long* g_dbg = nullptr;  // FD_TIMING builds: device buffer of 8 counters
 
 template <typename T, int WM, int WN, int MT, int NT>
 int set_attr() {
@@ -592,6 +649,8 @@ extern "C" int fd_tuning_set(const char* key, int value) {
   if (!strcmp(key, "conv_variant")) { g_variant = value; return FD_OK; }
   return fd_set_error(FD_EINVAL, "fd_tuning_set: unknown key '%s'", key);
 }
+
+extern "C" int fd_debug_buffer(void* p) { g_dbg = reinterpret_cast<unsigned long long*>(p); return FD_OK; }
 
 extern "C" int fd_conv_cout_pad(int Cout) { return cout_pad(Cout); }
 extern "C" int fd_conv_stats_tiles(int H, int W) { return fd_cdiv(H, 16) * fd_cdiv(W, 16); }
@@ -652,7 +711,7 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   a.affine = affine; a.affC = C0 + C1;
   a.w = packed_w; a.w_bytes = fd_conv_packed_bytes(Cout, C0, C1, ksize, S0, S1, dtype);
   a.bias = bias; a.bias_rows = bias_rows; a.skip = skip; a.scale = scale; a.out = out; a.Cout = Cout; a.CoutPad = cout_pad(Cout);
-  a.stats = stats; a.B = B; a.H = H; a.W = W;
+  a.stats = stats; a.B = B; a.H = H; a.W = W; a.dbg = g_dbg;
   FD_REQUIRE(a.w_bytes < (1ll << 31), "fd_conv2d: packed weights exceed 2 GiB");
   FD_REQUIRE(affine == nullptr || (C0 + C1) * 8 <= AFF_BYTES, "fd_conv2d: at most %d activated input channels", AFF_BYTES / 8);
   if (dtype == FD_BF16) return dispatch_conv<bf16>(a, fd_stream(stream));
