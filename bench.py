@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--N", type=int, default=6)
     ap.add_argument("--solver", default="euler")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--preset", default="flowdec_75m")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -83,7 +84,7 @@ def main():
     torch.cuda.set_device(dev)
 
     # synthetic data + seeded random-init weights of the FlowDec-75m architecture (no checkpoints offline)
-    model = flowdec_amd.from_preset("flowdec_75m", precision=args.precision)
+    model = flowdec_amd.from_preset(args.preset, precision=args.precision)
     g = torch.Generator().manual_seed(1234)
     sd = {}
     for k, v in model.state_dict().items():
@@ -137,7 +138,7 @@ def main():
         "value": audio_seconds / elapsed, "unit": "audio-seconds/second", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic (0.1*randn waveforms, seeded random-init weights of the FlowDec-75m architecture)",
-        "config": {"workload": f"FlowDec-75m enhance(): batch={B} x {args.seconds:g} s clips @48 kHz per GPU, {args.N}-step {args.solver} "
+        "config": {"workload": f"{args.preset} enhance(): batch={B} x {args.seconds:g} s clips @48 kHz per GPU, {args.N}-step {args.solver} "
                                f"(NFE {nfe}), T_pad={Tp} frames, inputs resident in HBM", "global_batch": world * B, "nfe": nfe,
                    "parallelism": f"batch-shard x{world}", "hipgraph": not args.no_graph},
     }

@@ -125,8 +125,13 @@ struct Geo {
   static constexpr int HALO_BYTES = HH * PITCH * ROWB;
   static constexpr int W_BYTES = BN * ROWB;
   static constexpr int W_LDS = (W_BYTES + 1023) / 1024 * 1024;  // LDS size of one weight buffer (DMA granularity)
-  static constexpr int NWBUF = BN <= 32 ? 2 : 3;                  // weight slabs in LDS: DMA runs NWBUF-1 steps ahead (the small
-                                                                  // config keeps 2 so that two workgroups fit a CU)
+  // Weight slabs live in a ring of NWBUF LDS slots.  The large configurations process the 9 taps of a chunk as
+  // (0,1)(2,3)(4,5)(6,7)(8) with ONE barrier per group (5 instead of 9 per chunk): the per-barrier cost (~800 cycles of
+  // drain + skew) is then amortised over 32 instead of 16 MFMAs per wave.  After each barrier the slots freed by the
+  // finished group are refilled by DMA with the next slabs in K order.  The small configuration keeps 2 slots and a
+  // barrier per tap so that two workgroups fit a CU.
+  static constexpr bool PAIRS = BN > 32;
+  static constexpr int NWBUF = PAIRS ? 4 : 2;
   static constexpr int MAIN_BYTES = 2 * HALO_BYTES + NWBUF * W_LDS + AFF_BYTES;
   // epilogue staging: one M-tile row of the block (WM * 32 pixels) x BN floats (+16 B pad per pixel)
   static constexpr int EP_PIX = WM * 32;
@@ -282,10 +287,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 
   // Barriers of the main loop wait for this wave's LDS-DMA EXPLICITLY: hipcc's own waitcnt insertion loses a pending
   // global_load_lds across the loop back-edge (it emitted a bare lgkmcnt(0) before the first barrier of the unrolled
-  // body), which let other waves read a weight piece that had not landed.  The wait is COUNTED: an LDS-DMA slab takes
-  // about one step (~1 us under load) from issue to landed, so slabs are issued TWO steps ahead into three LDS buffers
-  // and a barrier only retires everything older than the vector-memory ops of the immediately preceding phase B
-  // (KEEP = DMA_PER_WAVE pieces of the youngest slab + the halo slot load, in whatever order the scheduler emitted them).
+  // body), which let other waves read a weight piece that had not landed.  All vector-memory traffic is issued right
+  // after a barrier and is needed (landed + published) at the next one.
 #ifdef FD_TIMING
   unsigned long long tm_vm = 0, tm_bar = 0, tm_loop0 = 0, tm_n = 0;
 #endif
@@ -316,9 +319,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #endif
   };
   using K0 = std::integral_constant<int, 0>;
-  // with only two slabs the youngest DMA is the one the barrier must retire -> full drain
-  using KD = std::integral_constant<int, G::NWBUF == 3 ? G::DMA_PER_WAVE : 0>;        // previous phase B issued a slab only
-  using KDH = std::integral_constant<int, G::NWBUF == 3 ? G::DMA_PER_WAVE + 1 : 0>;   // ... and one halo slot load
 
   u32x4 wfA[NT], pfA[MT], wfB[NT], pfB[MT];
   auto read_frags = [&](u32x4 (&wf)[NT], u32x4 (&pf)[MT], const char* hb, const char* wb, int off) {
@@ -358,15 +358,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #ifdef FD_TIMING
   tm_loop0 = __builtin_amdgcn_s_memtime();
 #endif
-  int step = 0, hcur = 0;
-  int ws0 = 0, ws1 = 1, ws2 = 2;  // LDS slab holding w(step), w(step+1), w(step+2); rotated every step
+  int step = 0, hcur = 0;   // step = running (chunk, tap) index = index of the weight slab in K order
+  int fetch = 0;            // next slab to DMA; slab i lives in ring slot i % NWBUF
+  const int last_step = nsteps - 1;
+  auto slot_of = [&](int i) { return wbuf + (i % G::NWBUF) * G::W_LDS; };
+  auto fetch_slabs = [&](int n) {
+    for (int k = 0; k < n; ++k) { dma_w(fetch <= last_step ? fetch : last_step, fetch % G::NWBUF); ++fetch; }
+  };
   next_chunk(0, 0);
 #pragma unroll
   for (int i = 0; i < G::HITER; ++i) load_halo_slot(i);
-  const int last_step = nsteps - 1;
-  dma_w(0, 0);
-  dma_w(1 <= last_step ? 1 : last_step, 1);
-  if constexpr (G::NWBUF == 3) dma_w(2 <= last_step ? 2 : last_step, 2);
+  fetch_slabs(G::NWBUF);
 #pragma unroll
   for (int i = 0; i < G::HITER; ++i) store_halo_slot(i, 0);
   block_sync(K0{});
@@ -392,22 +394,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     for (int tap = 0; tap < 9; ++tap) {
       const int imm = ((tap / 3) * PITCH + (tap % 3)) * ROWB;
       const int imm_next = (((tap + 1) / 3) * PITCH + ((tap + 1) % 3)) * ROWB;
-      const char* wb = wbuf + ws0 * G::W_LDS;
-      const char* wbn = wbuf + ws1 * G::W_LDS;
+      const bool barrier_here = !G::PAIRS || (tap & 1) || tap == 8;   // last tap of its group
+      const char* wb = slot_of(step);
+      const char* wbn = slot_of(step + 1);
       // ---- phase A: [store halo slot] | read frags(s, ks=1) || MFMA(s, ks=0)
       if (tap >= HLAG && tap - HLAG < G::HITER) store_halo_slot(tap - HLAG, hcur ^ 1);
       read_frags(wfB, pfB, hb + 32, wb + 32, imm);
       mma_all(wfA, pfA);
-      // retire everything but the previous phase B's own loads: w(s+1) has landed, w(s+2) may still be in flight
-      if (tap >= 1 && tap - 1 < G::HITER) block_sync(KDH{}); else block_sync(KD{});
-      // ---- phase B: DMA w(s+3) into the slab of w(s) | [load halo slot] | read frags(s+1, ks=0) || MFMA(s, ks=1)
-      dma_w(step + G::NWBUF <= last_step ? step + G::NWBUF : last_step, ws0);
+      if (barrier_here) {
+        // everything issued after the previous barrier has landed and is published; all reads of the finished group's
+        // slabs are complete, so their ring slots are refilled with the next slabs in K order
+        block_sync(K0{});
+        fetch_slabs(!G::PAIRS ? 1 : (tap == 8 ? 1 : 2));
+      }
+      // ---- phase B: [load halo slot] | read frags(s+1, ks=0) || MFMA(s, ks=1)
       if (tap < G::HITER) load_halo_slot(tap);
       if (tap < 8) read_frags(wfA, pfA, hb, wbn, imm_next);
       else read_frags(wfA, pfA, hbn, wbn, first_off_next);
       mma_all(wfB, pfB);
       ++step;
-      { const int tmp = ws0; ws0 = ws1; if constexpr (G::NWBUF == 3) { ws1 = ws2; ws2 = tmp; } else { ws1 = tmp; } }
     }
     hcur ^= 1;
   }
@@ -415,10 +420,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     const bool m1 = step + 1 < nsteps;
     const char* hb = hbuf + hcur * G::HALO_BYTES;
     const char* hbn = hbuf + (hcur ^ 1) * G::HALO_BYTES;
-    const char* wb = wbuf + ws0 * G::W_LDS;
-    const char* wbn = wbuf + ws1 * G::W_LDS;
+    const char* wb = slot_of(step);
+    const char* wbn = slot_of(step + 1);
     if (m1) { advance(cs, cch); next_chunk(cs, cch); }
-    // the next 1-tap chunk's halo: loaded and published within this step (this loop drains the queue every step)
+    // the next 1-tap chunk's halo: loaded and published within this step
 #pragma unroll
     for (int k = 0; k < G::HITER; ++k) load_halo_slot(k);
     read_frags(wfB, pfB, hb + 32, wb + 32, CENTER);
@@ -426,11 +431,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #pragma unroll
     for (int k = 0; k < G::HITER; ++k) store_halo_slot(k, hcur ^ 1);
     block_sync(K0{});
-    dma_w(step + G::NWBUF <= last_step ? step + G::NWBUF : last_step, ws0);
+    fetch_slabs(1);
     read_frags(wfA, pfA, hbn, wbn, CENTER);
     mma_all(wfB, pfB);
     ++step; hcur ^= 1;
-    { const int tmp = ws0; ws0 = ws1; if constexpr (G::NWBUF == 3) { ws1 = ws2; ws2 = tmp; } else { ws1 = tmp; } }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // all fragment reads / DMA done before the epilogue reuses the LDS
