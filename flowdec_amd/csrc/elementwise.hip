@@ -315,13 +315,14 @@ __global__ __launch_bounds__(256) void temb_bias_single_kernel(fd_temb_job job, 
 // =====================================================================================================
 // Edge-of-network kernels on the 4-channel tensors
 // =====================================================================================================
-// cat(x.re, x.im, y.re, y.im) (ncsnpp.py:401-404) -> NHWC [B][F][T][4]
+// cat(x.re, x.im, y.re, y.im) (ncsnpp.py:401-404) -> NHWC [B][F][T][8]; channels 4..7 are zero padding so that the
+// tensor (and its FIR-downsampled pyramid) can feed the MFMA conv, whose input channel counts are multiples of 8
 template <typename T>
 __global__ void pack_input_kernel(const float2* __restrict__ x, const float2* __restrict__ y, T* __restrict__ out, long long n) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float2 a = x[i], b = y[i];
-    const float v[4] = {a.x, a.y, b.x, b.y};
-    fd_store_vec<T, 4>(out + 4 * i, v);
+    const float v[8] = {a.x, a.y, b.x, b.y, 0.f, 0.f, 0.f, 0.f};
+    fd_store_vec<T, 8>(out + 8 * i, v);
   }
 }
 
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const T* __restrict__ p4, 
   const int cg = (int)(idx % tpp);
   const long long pix = idx / tpp;
   float v[4], hv[8], o[8];
-  fd_load_vec<T, 4>(p4 + pix * 4, v);
+  fd_load_vec<T, 4>(p4 + pix * 8, v);   // the 4-channel pyramid is stored with 8-channel stride (see pack_input_kernel)
   fd_load_vec<T, 8>(h + pix * Cout + cg * 8, hv);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {

@@ -328,14 +328,15 @@ struct Fwd {
       FD_TRY(fd_temb_bias_batched(m->jobs_dev, m->njobs, m->temb, nt, m->temb_dim, st));
     }
     size_t mi = 3;
-    Tens in4 = talloc(4, F, T);
+    Tens in4 = talloc(8, F, T);   // 4 real channels + 4 zero channels (MFMA conv needs Cin % 8 == 0)
     if (!dry) { fd_edge_args a; a.x = x; a.y = y; a.out = ptr(in4.off); a.B = B; a.H = F; a.W = T; FD_TRY(fd_edge_op(0, a, dt, st)); }
     std::vector<Tens> hs;
     {
       const Mod& md = mods[mi++];
       Tens h0 = talloc(md.cout, F, T);
-      if (!dry) { fd_edge_args a; a.x = ptr(in4.off); a.w = md.w_f32; a.bias = md.b_f32; a.out = ptr(h0.off); a.B = B; a.H = F; a.W = T; a.Cout = md.cout;
-                  FD_TRY(fd_edge_op(1, a, dt, st)); }
+      // all_modules.3 (3x3, 4 -> nf) on the matrix cores, emitting the GroupNorm partials of its output
+      FD_TRY(conv(in4, nullptr, (size_t)-1, nullptr, nullptr, md.w0, md.b_f32, 1, nullptr, 1.f, h0, 3, true));
+      if (!dry && m->profiling) m->prof_flops -= 2.0 * B * F * T * (double)md.cout * 4 * 9;  // the 4 padding channels are not algorithmic work
       hs.push_back(h0);
     }
     Tens pyr_in = in4;  // input pyramid (owned here)
@@ -348,8 +349,8 @@ struct Fwd {
       if (lvl != R - 1) {
         Tens hd;
         FD_TRY(resblock(mods[mi++], hs.back(), nullptr, nt, hd));
-        Tens p2 = talloc(4, pyr_in.H / 2, pyr_in.W / 2);
-        if (!dry) FD_TRY(fd_fir_resample(ptr(pyr_in.off), nullptr, ptr(p2.off), nullptr, B, pyr_in.H, pyr_in.W, 4, -1, dt, st));
+        Tens p2 = talloc(8, pyr_in.H / 2, pyr_in.W / 2);
+        if (!dry) FD_TRY(fd_fir_resample(ptr(pyr_in.off), nullptr, ptr(p2.off), nullptr, B, pyr_in.H, pyr_in.W, 8, -1, dt, st));
         tfree(pyr_in);
         pyr_in = p2;
         const Mod& md = mods[mi++];
@@ -615,7 +616,18 @@ extern "C" int fd_model_finalize(fd_model* m, void* stream) {
   for (Mod& md : m->mods) {
     const std::string p = pref(md.idx);
     switch (md.kind) {
-      case M_CONV_IN:
+      case M_CONV_IN: {
+        // zero-pad the 4 input channels to 8 and pack for the MFMA conv
+        const std::vector<float>& w4 = m->host[p + "weight"];
+        std::vector<float>& w8 = m->host[p + "weight.pad8"];
+        w8.assign((size_t)md.cout * 8 * 9, 0.f);
+        for (int o = 0; o < md.cout; ++o)
+          for (int c = 0; c < 4; ++c)
+            for (int k = 0; k < 9; ++k) w8[((size_t)o * 8 + c) * 9 + k] = w4[((size_t)o * 4 + c) * 9 + k];
+        FD_TRY(pack_conv(m, p + "weight.pad8", md.cout, 8, 0, 3, "", 0, 0, &md.w0, st));
+        FD_TRY(upload_f32(m, p + "bias", &md.b_f32));
+        break;
+      }
       case M_COMBINE: {
         const std::string q = md.kind == M_COMBINE ? p + "Conv_0." : p;
         FD_TRY(upload_f32(m, q + "weight", &md.w_f32));
