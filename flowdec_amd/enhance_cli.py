@@ -1,0 +1,233 @@
+"""Command-line driver equivalent to the reference's `enhance.py`.
+
+    python -m flowdec_amd.enhance_cli --ckpt flowdec_75m.ckpt --files noisy_dir/ --outdir out/ --N 3 --solver midpoint [--rtf]
+
+Same arguments and file conventions as the reference (enhance.py:24-49): `--files` is a directory of *.wav, a file list
+(one path per line, or `clean ---> noisy` / `clean,noisy` pair lines, enhance.py:146-164) or, with `--single-file`, one
+wav; files longer than 30 s are skipped (:115,:139); `--rtf` writes `path,runtime,filetime,rtf` rows (:94,:135) with
+rtf = runtime / filetime like the reference.  The score-model-only options are accepted and ignored.
+
+Checkpoints: a Lightning `.ckpt` (dict with `_pl_ema_state_dict` and/or `state_dict`, optionally `hyper_parameters`
+holding the resolved config: callbacks/ema.py:201-215, model.py:100,119) or a bare state_dict.  `--ema` (default)
+selects the EMA weights exactly like `demo.ipynb` cell 2.
+
+Not bit-identical to the reference in ONE place: resampling of non-48 kHz input uses scipy.signal.resample_poly
+(torchaudio is not a dependency); 48 kHz files -- the codec's native rate -- are untouched.
+"""
+import argparse
+import contextlib
+import glob
+import os
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .model import BACKBONE_FINAL_NO_ATTN, AmplitudeCompressedComplexSTFT, FlowModel, NCSNpp, from_preset
+
+MAX_SECONDS = 30.0  # enhance.py:115
+
+
+# ------------------------------------------------------------------------------------------------
+# file lists / wav I/O
+# ------------------------------------------------------------------------------------------------
+def read_list(listfile: str) -> Tuple[list, bool]:
+    """enhance.py:146-164: plain list, or pair lists (`a ---> b` or `a,b`) whose SECOND entry is the input."""
+    filenames, from_pairs = [], False
+    with open(listfile, "r") as f:
+        for line in f:
+            line = line.strip()
+            if not line:
+                continue
+            if " ---> " in line:
+                from_pairs = True
+                filenames.append(line.split(" ---> "))
+            elif "," in line:
+                from_pairs = True
+                filenames.append(line.split(","))
+            else:
+                assert not from_pairs, "Inconsistent file list format with and without pairs detected!"
+                filenames.append(line)
+    return filenames, from_pairs
+
+
+def load_wav(path: str) -> Tuple[torch.Tensor, int]:
+    """-> (float32 tensor [C, L] in [-1, 1], sampling rate), like torchaudio.load."""
+    from scipy.io import wavfile
+    sr, data = wavfile.read(path)
+    if data.dtype == np.int16:
+        x = data.astype(np.float32) / 32768.0
+    elif data.dtype == np.int32:
+        x = data.astype(np.float32) / 2147483648.0
+    elif data.dtype == np.uint8:
+        x = (data.astype(np.float32) - 128.0) / 128.0
+    else:
+        x = data.astype(np.float32)
+    if x.ndim == 1:
+        x = x[:, None]
+    return torch.from_numpy(np.ascontiguousarray(x.T)), int(sr)
+
+
+def save_wav(path: str, x: torch.Tensor, sr: int) -> None:
+    """float32 wav, [C, L] or [L] (the reference saves float tensors through torchaudio.save)."""
+    from scipy.io import wavfile
+    a = x.detach().cpu().float().numpy()
+    if a.ndim == 2:
+        a = a.T
+    wavfile.write(path, sr, np.ascontiguousarray(a, dtype=np.float32))
+
+
+def resample(y: torch.Tensor, sr: int, target: int) -> torch.Tensor:
+    from math import gcd
+    from scipy.signal import resample_poly
+    g = gcd(sr, target)
+    return torch.from_numpy(resample_poly(y.numpy(), target // g, sr // g, axis=-1).astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+# checkpoint reader
+# ------------------------------------------------------------------------------------------------
+def _cfg_get(cfg, *path, default=None):
+    for k in path:
+        if isinstance(cfg, dict) and k in cfg:
+            cfg = cfg[k]
+        else:
+            return default
+    return cfg
+
+
+def model_from_checkpoint(ckpt, ema: bool = True, precision: str = "bf16", preset: str = "flowdec_75m") -> FlowModel:
+    """Build a FlowModel from a loaded checkpoint object (see module docstring for the accepted layouts)."""
+    if not isinstance(ckpt, dict):
+        raise RuntimeError("checkpoint must be a dict")
+    if "_pl_ema_state_dict" in ckpt or "state_dict" in ckpt:
+        key = "_pl_ema_state_dict" if (ema and "_pl_ema_state_dict" in ckpt) else "state_dict"
+        if key not in ckpt:
+            raise RuntimeError(f"checkpoint has no '{key}' (available: {[k for k in ckpt if 'state_dict' in k]})")
+        sd = ckpt[key]
+    else:
+        sd = ckpt  # bare state_dict
+    hp = ckpt.get("hyper_parameters") if isinstance(ckpt.get("hyper_parameters", None), dict) else None
+    mcfg = _cfg_get(hp, "model") or {}
+    bb_cfg = dict(BACKBONE_FINAL_NO_ATTN)
+    for k, v in (mcfg.get("backbone") or {}).items():
+        if k != "_target_":
+            bb_cfg[k] = tuple(v) if isinstance(v, list) else v
+    if not mcfg.get("backbone") and "backbone.all_modules.0.W" in sd:      # infer the width from the weights
+        bb_cfg["nf"] = int(sd["backbone.all_modules.0.W"].shape[0])
+    fe_cfg = mcfg.get("feature_extractor") or {}
+    fe = AmplitudeCompressedComplexSTFT(window_fn=fe_cfg.get("window_fn", "hann"), n_fft=int(fe_cfg.get("n_fft", 1534)),
+                                        n_hops=int(fe_cfg.get("n_hops", 4)) if "hop_length" not in fe_cfg else None,
+                                        hop_length=fe_cfg.get("hop_length"), sampling_rate=int(_cfg_get(hp, "sampling_rate", default=48000)),
+                                        alpha=float(fe_cfg.get("alpha", 0.3)), beta=float(fe_cfg.get("beta", 0.33)))
+    sigma_y = sd["sigma_y"] if "sigma_y" in sd else from_preset(preset, nf=8).sigma_y.data
+    model = FlowModel(backbone=NCSNpp(precision=precision, **bb_cfg), feature_extractor=fe,
+                      sampling_rate=int(_cfg_get(hp, "sampling_rate", default=48000)), sigma_x=0.0, sigma_y=sigma_y.clone())
+    res = model.load_state_dict(sd, strict=False)  # strict_loading = False in the reference (model.py:397)
+    missing = [k for k in res.missing_keys if k.startswith("backbone.")]
+    if missing:
+        raise RuntimeError(f"checkpoint is missing backbone parameters, e.g. {missing[:3]}")
+    return model.eval()
+
+
+def load_from_checkpoint(path: str, map_location="cpu", ema: bool = True, precision: str = "bf16") -> FlowModel:
+    """Replacement for `EnhancementModel.load_from_checkpoint(ckpt, map_location=..., ema=...)` (enhance.py:66)."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    model = model_from_checkpoint(ckpt, ema=ema, precision=precision)
+    return model.to(map_location) if map_location is not None else model
+
+
+# ------------------------------------------------------------------------------------------------
+# main loop
+# ------------------------------------------------------------------------------------------------
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="Enhance wav files with a FlowDec postfilter on MI355X")
+    p.add_argument("--ckpt", type=str, required=True)
+    p.add_argument("--files", type=str, required=True)
+    p.add_argument("--outdir", type=str, required=True)
+    p.add_argument("--N", type=int, required=True)
+    p.add_argument("--single-file", action="store_true")
+    p.add_argument("--exclude-files-matching", type=str, required=False)
+    p.add_argument("--predictor", type=str, default="reverse_diffusion")   # score model only (ignored)
+    p.add_argument("--corrector", type=str, default="ald")
+    p.add_argument("--snr", type=float, default=0.5)
+    p.add_argument("--solver", type=str, default="midpoint")
+    p.add_argument("--device", type=str, default="cuda:0")
+    p.add_argument("--ema", type=lambda s: str(s).lower() not in ("0", "false", "no"), default=True)
+    p.add_argument("--skip-existing", type=lambda s: str(s).lower() not in ("0", "false", "no"), default=True)
+    p.add_argument("--i-min", type=int, default=None)
+    p.add_argument("--i-max", type=int, default=None)
+    p.add_argument("--rtf", action="store_true")
+    p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--seed", type=int, default=None, help="seed of the initial-noise generator (default: nondeterministic like the reference)")
+    return p
+
+
+def collect_files(files: str, single_file: bool) -> Tuple[List[str], Optional[List[str]]]:
+    """-> (noisy paths, clean paths or None)."""
+    if os.path.isfile(files):
+        if single_file:
+            return [files], None
+        entries, from_pairs = read_list(files)
+        if from_pairs:
+            return [e[1] for e in entries], [e[0] for e in entries]
+        return list(entries), None
+    return sorted(glob.glob(f"{files}/*.wav")), None
+
+
+def main(argv=None, model: Optional[FlowModel] = None) -> int:
+    args = build_parser().parse_args(argv)
+    os.makedirs(args.outdir, exist_ok=True)
+    if model is None:
+        print("Loading model from checkpoint...")
+        model = load_from_checkpoint(args.ckpt, map_location=args.device, ema=args.ema, precision=args.precision)
+        print("Done loading model.")
+    noisy, clean = collect_files(args.files, args.single_file)
+    if args.exclude_files_matching is not None:
+        keep = [i for i, f in enumerate(noisy) if args.exclude_files_matching not in f]
+        noisy = [noisy[i] for i in keep]
+        clean = [clean[i] for i in keep] if clean is not None else None
+    suffix = f"_{args.i_min}-{args.i_max}" if args.i_max else ""
+    triples_path = os.path.join(args.outdir, f"triples_list{suffix}.txt") if clean is not None else None
+    rtf_path = os.path.join(args.outdir, f"rtfs{suffix}.csv") if args.rtf else None
+    gen = None
+    if args.seed is not None:
+        gen = torch.Generator(device=model.device).manual_seed(args.seed)
+    n_done = 0
+    with (open(triples_path, "w") if triples_path else contextlib.nullcontext()) as trf, \
+            (open(rtf_path, "w") if rtf_path else contextlib.nullcontext()) as rtf_f:
+        if rtf_f is not None:
+            print("path,runtime,filetime,rtf", file=rtf_f)
+        for i, path in enumerate(noisy):
+            if args.i_min is not None and i < args.i_min:
+                continue
+            if args.i_max is not None and i > args.i_max:
+                continue
+            out_path = os.path.join(args.outdir, os.path.basename(path))
+            if not os.path.exists(out_path) or not args.skip_existing:
+                y, sr = load_wav(path)
+                if y.shape[-1] / sr <= MAX_SECONDS:
+                    if sr != model.sampling_rate:
+                        print("RESAMPLING from", sr, "to", model.sampling_rate)
+                        y, sr = resample(y, sr, model.sampling_rate), model.sampling_rate
+                    if args.rtf:
+                        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        start.record()
+                    x_hat = model.enhance(y, N=args.N, solver=args.solver, generator=gen)
+                    if args.rtf:
+                        end.record()
+                        torch.cuda.synchronize()
+                        runtime, filetime = start.elapsed_time(end) / 1000.0, y.shape[-1] / sr
+                        print(runtime, filetime, "-> rtf =", runtime / filetime)
+                        print(f"{out_path},{runtime:.5f},{filetime:.5f},{runtime / filetime:.5f}", file=rtf_f)
+                    save_wav(out_path, x_hat.cpu(), sr)
+                    n_done += 1
+                else:
+                    print("Skipping file due to length:", path)
+            if trf is not None:
+                print(f"{clean[i]} ---> {noisy[i]} ---> {out_path}", file=trf)
+    return n_done
+
+
+if __name__ == "__main__":
+    main()

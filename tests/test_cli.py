@@ -1,0 +1,101 @@
+"""enhance.py-equivalent driver and checkpoint reader."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import flowdec_oracle as O
+
+
+def synthetic_ckpt(nf=8, seed=8, with_hp=True):
+    sd = {k: torch.from_numpy(v) for k, v in O.random_state_dict(seed=seed, nf=nf).items()}
+    ema = {k: v.clone() for k, v in sd.items()}
+    ema["backbone.all_modules.3.bias"] = ema["backbone.all_modules.3.bias"] + 1.0   # make EMA != raw weights
+    sig = torch.full((768, 1), 0.4, dtype=torch.float64)
+    for d in (sd, ema):
+        d["sigma_y"] = sig.clone(); d["sigma_x"] = torch.tensor(0.0)
+        d["feature_extractor.complex_stft.window"] = torch.signal.windows.hann(1534)
+    ckpt = {"state_dict": sd, "_pl_ema_state_dict": ema, "epoch": 3}
+    if with_hp:
+        ckpt["hyper_parameters"] = {"sampling_rate": 48000, "model": {
+            "backbone": {"_target_": "flowdec.backbones.ncsnpp.NCSNpp", "nf": nf, "ch_mult": [4, 4, 4, 2], "num_res_blocks": 1,
+                         "attn_resolutions": [], "bottleneck_attn": False, "image_size": 768},
+            "feature_extractor": {"n_fft": 1534, "n_hops": 4, "window_fn": "hann", "alpha": 0.3, "beta": 0.33}}}
+    return ckpt
+
+
+def test_read_list_formats(tmp_path):
+    from flowdec_amd.enhance_cli import collect_files, read_list
+    a = tmp_path / "plain.txt"; a.write_text("x/a.wav\n\nx/b.wav\n")
+    assert read_list(str(a)) == (["x/a.wav", "x/b.wav"], False)
+    b = tmp_path / "pairs.txt"; b.write_text("c/a.wav ---> n/a.wav\nc/b.wav,n/b.wav\n")
+    files, pairs = read_list(str(b))
+    assert pairs and files == [["c/a.wav", "n/a.wav"], ["c/b.wav", "n/b.wav"]]
+    assert collect_files(str(b), False) == (["n/a.wav", "n/b.wav"], ["c/a.wav", "c/b.wav"])   # second entry is the input
+    assert collect_files(str(a), True) == ([str(a)], None)
+    bad = tmp_path / "bad.txt"; bad.write_text("c/a.wav,n/a.wav\nplain.wav\n")
+    with pytest.raises(AssertionError):
+        read_list(str(bad))
+    (tmp_path / "d").mkdir()
+    for n in ("b.wav", "a.wav", "c.txt"):
+        (tmp_path / "d" / n).write_bytes(b"")
+    assert [os.path.basename(f) for f in collect_files(str(tmp_path / "d"), False)[0]] == ["a.wav", "b.wav"]
+
+
+def test_wav_roundtrip_and_resample(tmp_path):
+    from flowdec_amd.enhance_cli import load_wav, resample, save_wav
+    x = torch.from_numpy((0.3 * np.sin(np.arange(4800) * 0.05)).astype(np.float32))[None]
+    save_wav(str(tmp_path / "f.wav"), x, 48000)
+    y, sr = load_wav(str(tmp_path / "f.wav"))
+    assert sr == 48000 and y.shape == (1, 4800) and torch.equal(x, y)
+    from scipy.io import wavfile
+    wavfile.write(str(tmp_path / "i16.wav"), 16000, (x[0].numpy() * 32767).astype(np.int16))
+    z, sr2 = load_wav(str(tmp_path / "i16.wav"))
+    assert sr2 == 16000 and float((z - x).abs().max()) < 1e-4
+    assert resample(z, 16000, 48000).shape == (1, 14400)
+
+
+def test_checkpoint_reader_cpu():
+    from flowdec_amd.enhance_cli import model_from_checkpoint
+    ckpt = synthetic_ckpt()
+    m_ema = model_from_checkpoint(ckpt, ema=True)
+    m_raw = model_from_checkpoint(ckpt, ema=False)
+    assert m_ema.backbone.nf == 8 and m_ema.sigma_y.dtype == torch.float64 and float(m_ema.sigma_y[0]) == pytest.approx(0.4)
+    b_e = m_ema.state_dict()["backbone.all_modules.3.bias"]; b_r = m_raw.state_dict()["backbone.all_modules.3.bias"]
+    assert torch.allclose(b_e, b_r + 1.0)                      # --ema picks _pl_ema_state_dict (callbacks/ema.py:201-215)
+    m2 = model_from_checkpoint(synthetic_ckpt(with_hp=False))  # no hyper_parameters: width inferred from the weights
+    assert m2.backbone.nf == 8
+    m3 = model_from_checkpoint(ckpt["_pl_ema_state_dict"])      # bare state_dict
+    assert torch.equal(m3.state_dict()["backbone.all_modules.3.bias"], b_e)
+    broken = {k: v for k, v in ckpt["state_dict"].items() if "all_modules.4.Conv_0" not in k}
+    with pytest.raises(RuntimeError):
+        model_from_checkpoint({"state_dict": broken}, ema=False)
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end(tmp_path):
+    from flowdec_amd import enhance_cli
+    torch.save(synthetic_ckpt(), tmp_path / "m.ckpt")
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    rng = np.random.default_rng(0)
+    for name, n, sr in (("a.wav", 24000, 48000), ("b.wav", 16000, 16000), ("long.wav", 31 * 8000, 8000)):
+        enhance_cli.save_wav(str(ind / name), torch.from_numpy((0.1 * rng.standard_normal(n)).astype(np.float32))[None], sr)
+    n = enhance_cli.main(["--ckpt", str(tmp_path / "m.ckpt"), "--files", str(ind), "--outdir", str(outd), "--N", "2", "--solver", "midpoint",
+                          "--rtf", "--seed", "3"])
+    assert n == 2 and not (outd / "long.wav").exists()          # > 30 s files are skipped (enhance.py:115,139)
+    a, sr = enhance_cli.load_wav(str(outd / "a.wav"))
+    assert sr == 48000 and a.shape == (1, 24000) and torch.isfinite(a).all()
+    b, sr = enhance_cli.load_wav(str(outd / "b.wav"))
+    assert sr == 48000 and b.shape == (1, 48000)                 # resampled 16 k -> 48 k
+    rows = (outd / "rtfs.csv").read_text().strip().splitlines()
+    assert rows[0] == "path,runtime,filetime,rtf" and len(rows) == 3
+    path, runtime, filetime, rtf = rows[1].split(",")
+    assert float(filetime) == pytest.approx(0.5) and float(rtf) == pytest.approx(float(runtime) / 0.5, rel=1e-3)
+    assert enhance_cli.main(["--ckpt", str(tmp_path / "m.ckpt"), "--files", str(ind), "--outdir", str(outd), "--N", "2"]) == 0  # skip-existing
+    # the CLI result equals a direct enhance() call with the same seed
+    m = enhance_cli.load_from_checkpoint(str(tmp_path / "m.ckpt"), map_location="cuda:0")
+    y, _ = enhance_cli.load_wav(str(ind / "a.wav"))
+    ref = m.enhance(y, N=2, solver="midpoint", generator=torch.Generator(device="cuda:0").manual_seed(3))
+    assert torch.equal(ref, a)
