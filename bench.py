@@ -21,6 +21,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+TRAFFIC_FILE = "r01_conv_traffic.json"
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -150,15 +151,27 @@ def main():
         L.check(lib.fd_profile_enable(h, 1))
         model.enhance(y, N=args.N, solver=args.solver, noise=noise, use_graph=False)
         torch.cuda.synchronize(dev)
-        ms, n, fl = C.c_double(), C.c_longlong(), C.c_double()
-        L.check(lib.fd_profile_read(h, C.byref(ms), C.byref(n), C.byref(fl)))
+        ms, n, fl, by = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
+        L.check(lib.fd_profile_read(h, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
         L.check(lib.fd_profile_enable(h, 0))
         achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[args.precision]
+        nl = max(int(n.value), 1)
         result["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel (implicit-GEMM 3x3/1x1)", "achieved": achieved, "peak": peak,
                               "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "launches": int(n.value),
-                              "avg_launch_ms": ms.value / max(int(n.value), 1), "conv_ms_per_step": ms.value,
-                              "algorithmic_tflop_per_step": fl.value / 1e12}
+                              "avg_launch_ms": ms.value / nl, "conv_ms_per_step": ms.value, "algorithmic_tflop_per_step": fl.value / 1e12,
+                              "algorithmic_tflop_per_launch": fl.value / 1e12 / nl, "algorithmic_bytes_per_launch": by.value / nl,
+                              "hbm_GBps_algorithmic": by.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0}
+        # HBM bytes per launch from the committed PMC passes of this same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # corrected as profiles/summarize_pmc.py documents); PMC counters cannot be collected from inside the timed run.
+        default_cfg = (args.preset, args.precision, args.solver, args.N, B, args.seconds) == ("flowdec_75m", "bf16", "euler", 6, 8, 2.0)
+        tf = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+        if default_cfg and os.path.exists(tf):
+            with open(tf) as f:
+                tr = json.load(f)["conv_mfma_kernel"]
+            if tr["launches_per_step"] == int(n.value):
+                result["roofline"]["traffic"] = tr["traffic_per_launch"]
+                result["roofline"]["traffic_source"] = f"profiles/{TRAFFIC_FILE} (bytes/launch: fetch {tr['fetch_corrected_per_launch']:.4g} + write {tr['write_per_launch']:.4g})"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:

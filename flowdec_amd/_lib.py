@@ -23,6 +23,14 @@ class FdModelConfig(C.Structure):
                 ("n_fft", c_int), ("hop", c_int), ("alpha", c_float), ("beta", c_float), ("act_dtype", c_int)]
 
 
+class FdScoreConfig(C.Structure):
+    _fields_ = [("theta", c_float), ("sigma_min", c_float), ("sigma_max", c_float), ("t_eps", c_float), ("snr", c_float),
+                ("N", c_int), ("predictor", c_int), ("corrector", c_int), ("corrector_steps", c_int), ("denoise", c_int)]
+
+
+PREDICTORS = {"reverse_diffusion": 0, "euler_maruyama": 1, "none": 2}
+CORRECTORS = {"ald": 0, "none": 1}
+
 # name -> (restype, [argtypes]); must list every function declared in include/flowdec_hip.h
 _P = c_void_p
 SIGNATURES = {
@@ -62,8 +70,11 @@ SIGNATURES = {
     "fd_ode_solve": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "fd_enhance_workspace_bytes": (c_size_t, [_P, c_int, c_int]),
     "fd_enhance": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
+    "fd_score_num_draws": (c_int, [C.POINTER(FdScoreConfig)]),
+    "fd_score_enhance": (c_int, [_P, _P, _P, C.POINTER(FdScoreConfig), _P, c_int, c_int, _P, c_size_t, c_int, _P]),
+    "fd_regression_enhance": (c_int, [_P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "fd_profile_enable": (c_int, [_P, c_int]),
-    "fd_profile_read": (c_int, [_P, C.POINTER(C.c_double), C.POINTER(c_ll), C.POINTER(C.c_double)]),
+    "fd_profile_read": (c_int, [_P, C.POINTER(C.c_double), C.POINTER(c_ll), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None

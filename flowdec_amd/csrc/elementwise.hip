@@ -326,50 +326,6 @@ __global__ void pack_input_kernel(const float2* __restrict__ x, const float2* __
   }
 }
 
-// 3x3 conv 4 -> Cout (all_modules.3).  Weights [Cout][4][3][3] f32 staged in LDS as [36][Cout].
-// One thread = one pixel x 8 couts.
-template <typename T>
-__global__ __launch_bounds__(256) void conv_in_kernel(const T* __restrict__ in4, const float* __restrict__ w, const float* __restrict__ bias,
-                                                      T* __restrict__ out, int B, int H, int W, int Cout) {
-  extern __shared__ float wl[];  // [36][Cout]
-  for (int i = threadIdx.x; i < 36 * Cout; i += 256) {
-    const int co = i % Cout, k = i / Cout;  // k = ci*9 + tap in the source -> reorder to tap*4+ci
-    const int tap = k / 4, ci = k % 4;
-    wl[i] = w[((size_t)co * 4 + ci) * 9 + tap];
-  }
-  __syncthreads();
-  const int tpp = Cout >> 3;  // threads per pixel
-  const long long total = (long long)B * H * W * tpp;
-  const long long idx = blockIdx.x * 256ll + threadIdx.x;
-  if (idx >= total) return;
-  const int cg = (int)(idx % tpp);
-  long long r = idx / tpp;
-  const int xw = (int)(r % W); r /= W;
-  const int yh = (int)(r % H);
-  const int b = (int)(r / H);
-  float acc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = bias[cg * 8 + i];
-#pragma unroll
-  for (int dy = 0; dy < 3; ++dy) {
-    const int yy = yh + dy - 1;
-    if (yy < 0 || yy >= H) continue;
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const int xx = xw + dx - 1;
-      if (xx < 0 || xx >= W) continue;
-      float v[4];
-      fd_load_vec<T, 4>(in4 + (((size_t)b * H + yy) * W + xx) * 4, v);
-      const float* wp = wl + ((dy * 3 + dx) * 4) * Cout + cg * 8;
-#pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = fmaf(wp[ci * Cout + i], v[ci], acc[i]);
-    }
-  }
-  fd_store_vec<T, 8>(out + (((size_t)b * H + yh) * W + xw) * Cout + cg * 8, acc);
-}
-
 // Combine 'sum' (layerspp.py:54-69): out = conv1x1(p4) + bias + h.  One thread = pixel x 8 couts.
 template <typename T>
 __global__ __launch_bounds__(256) void combine_kernel(const T* __restrict__ p4, const float* __restrict__ w, const float* __restrict__ bias,
@@ -425,6 +381,36 @@ __global__ void init_state_kernel(const float2* __restrict__ Y, const float2* __
     const float nx = (float)(s * (double)nz.x), ny = (float)(s * (double)nz.y);
     float2 o = {yv.x + sigma_fac * nx, yv.y + sigma_fac * ny};
     x0[i] = o;
+  }
+}
+
+// Predictor / corrector update of the ScoreDec sampler (sampling/predictors.py:48-71, correctors.py:52-66) fused with the
+// output layer:  dst = cb * base + cy * Y + cn * v + cz * z   (v = output_layer(pyr) as complex; every coefficient is a
+// real scalar that the host derives from the OUVE closed forms, sdes.py:168-192).
+template <typename T>
+__global__ void score_update_kernel(const T* __restrict__ pyr, const float* __restrict__ wo, const float2* __restrict__ base, float cb,
+                                    const float2* __restrict__ Y, float cy, float cn, const float2* __restrict__ z, float cz,
+                                    float2* __restrict__ dst, long long n) {
+  const float w0 = wo[0], w1 = wo[1], w2 = wo[2], w3 = wo[3], w4 = wo[4], w5 = wo[5], w6 = wo[6], w7 = wo[7];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float p[4];
+    fd_load_vec<T, 4>(pyr + 4 * i, p);
+    const float vx = fmaf(w3, p[3], fmaf(w2, p[2], fmaf(w1, p[1], w0 * p[0])));
+    const float vy = fmaf(w7, p[3], fmaf(w6, p[2], fmaf(w5, p[1], w4 * p[0])));
+    const float2 b = base[i];
+    float2 o = {fmaf(cn, vx, cb * b.x), fmaf(cn, vy, cb * b.y)};
+    if (cy != 0.f) { const float2 yv = Y[i]; o.x = fmaf(cy, yv.x, o.x); o.y = fmaf(cy, yv.y, o.y); }
+    if (cz != 0.f) { const float2 zv = z[i]; o.x = fmaf(cz, zv.x, o.x); o.y = fmaf(cz, zv.y, o.y); }
+    dst[i] = o;
+  }
+}
+
+// dst = a + cq * q  (prior sample x_T = Y + std(T) * z, sdes.py:197-202)
+__global__ void caxpy_kernel(const float2* __restrict__ a, const float2* __restrict__ q, float cq, float2* __restrict__ dst, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float2 av = a[i], qv = q[i];
+    float2 o = {fmaf(cq, qv.x, av.x), fmaf(cq, qv.y, av.y)};
+    dst[i] = o;
   }
 }
 
@@ -579,11 +565,6 @@ static int edge_launch(int which, const fd_edge_args& a, hipStream_t st) {
       hipLaunchKernelGGL(pack_input_kernel<T>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, (const float2*)a.x, (const float2*)a.y, (T*)a.out, n);
       break;
     }
-    case 1: {  // conv_in
-      const long long n = (long long)a.B * a.H * a.W * (a.Cout / 8);
-      hipLaunchKernelGGL(conv_in_kernel<T>, dim3(fd_cdiv(n, 256)), dim3(256), sizeof(float) * 36 * a.Cout, st, (const T*)a.x, a.w, a.bias, (T*)a.out, a.B, a.H, a.W, a.Cout);
-      break;
-    }
     case 2: {  // combine
       const long long npix = (long long)a.B * a.H * a.W;
       hipLaunchKernelGGL(combine_kernel<T>, dim3(fd_cdiv(npix * (a.Cout / 8), 256)), dim3(256), 0, st, (const T*)a.x, a.w, a.bias, (const T*)a.y, (T*)a.out, npix, a.Cout);
@@ -594,6 +575,12 @@ static int edge_launch(int which, const fd_edge_args& a, hipStream_t st) {
       hipLaunchKernelGGL(output_update_kernel<T>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, (const T*)a.x, a.w, (const float2*)a.base, (const float2*)a.kold, a.coef, (float2*)a.out, (float2*)a.ksave, n);
       break;
     }
+    case 4: {  // output + score-sampler update
+      const long long n = (long long)a.B * a.H * a.W;
+      hipLaunchKernelGGL(score_update_kernel<T>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, (const T*)a.x, a.w, (const float2*)a.base, a.cb,
+                         (const float2*)a.y, a.cy, a.coef, (const float2*)a.z, a.cz, (float2*)a.out, n);
+      break;
+    }
     default: return fd_set_error(FD_EINVAL, "edge_launch: bad op");
   }
   FD_LAUNCH_CHECK();
@@ -601,7 +588,7 @@ static int edge_launch(int which, const fd_edge_args& a, hipStream_t st) {
 }
 
 int fd_edge_op(int which, const fd_edge_args& a, int dtype, hipStream_t st) {
-  if (which == 1 || which == 2) FD_REQUIRE(a.Cout % 8 == 0, "edge op: Cout must be a multiple of 8");
+  if (which == 2) FD_REQUIRE(a.Cout % 8 == 0, "edge op: Cout must be a multiple of 8");
   return dtype == FD_BF16 ? edge_launch<bf16>(which, a, st) : edge_launch<float>(which, a, st);
 }
 
@@ -610,6 +597,12 @@ int fd_init_state(const float* Y, const float* noise, const double* sigma_dev, i
   const long long n = (long long)B * F * T;
   hipLaunchKernelGGL(init_state_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, (const float2*)Y, (const float2*)noise, sigma_dev, sigma_n,
                      sigma_fac, (float2*)x0, F, T, n);
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}
+
+int fd_caxpy(const float* a, const float* q, float cq, float* dst, long long n, hipStream_t st) {
+  hipLaunchKernelGGL(caxpy_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, (const float2*)a, (const float2*)q, cq, (float2*)dst, n);
   FD_LAUNCH_CHECK();
   return FD_OK;
 }

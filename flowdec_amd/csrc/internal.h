@@ -20,6 +20,8 @@ struct fd_edge_args {
   const void* kold = nullptr;
   void* ksave = nullptr;
   float coef = 1.f;
+  const void* z = nullptr;     // score update: dst = cb*base + cy*y + coef*v + cz*z
+  float cb = 1.f, cy = 0.f, cz = 0.f;
   int B = 0, H = 0, W = 0, Cout = 0;
 };
 
@@ -27,10 +29,12 @@ struct fd_edge_args {
 int fd_time_embedding_impl(const float* t, float t_imm, int nt, const float* gfp_w, int nf, const float* w1, const float* b1,
                            const float* w2, const float* b2, float* temb, hipStream_t st);
 int fd_temb_bias_batched(const fd_temb_job* jobs_dev, int njobs, const float* temb, int nt, int temb_dim, hipStream_t st);
-// which: 0 = pack_input, 1 = conv_in (3x3, 4->Cout), 2 = combine (1x1 4->Cout + h), 3 = output layer + state update
+// which: 0 = pack_input, 2 = combine (1x1 4->Cout + h), 3 = output layer + state update,
+//        4 = output layer + score-sampler update
 int fd_edge_op(int which, const fd_edge_args& a, int dtype, hipStream_t st);
 int fd_init_state(const float* Y, const float* noise, const double* sigma_dev, int sigma_n, float sigma_fac, float* x0, int B,
                   int F, int T, hipStream_t st);
+int fd_caxpy(const float* a, const float* q, float cq, float* dst, long long n, hipStream_t st);
 // conv_mfma.hip
 int fd_conv_init_attributes();
 // stft.hip

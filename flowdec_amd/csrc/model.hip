@@ -86,6 +86,7 @@ struct GraphKey {
   const void *Y, *noise, *X, *traj, *ws, *y, *xhat;
   int B, T, N, solver, L, kind;
   float sigma_fac;
+  fd_score_config score;   // kind 3 only (zero otherwise)
   bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
 };
 
@@ -114,6 +115,7 @@ struct fd_model {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   size_t ev_used = 0;
   double prof_flops = 0.0;
+  double prof_bytes = 0.0;   // algorithmic HBM bytes of the timed launches: every operand read once + output written once
   static constexpr int MAX_NT = 256;
 };
 
@@ -219,6 +221,11 @@ struct OutSpec {           // what to do with v = NCSNpp(x, y, t):  dst = base +
   float coef = 1.f;
   float* dst = nullptr;
   float* ksave = nullptr;
+  // score-sampler form (score = true):  dst = cb * base + cy * yv + coef * v + cz * z
+  bool score = false;
+  const float* yv = nullptr;
+  const float* z = nullptr;
+  float cb = 1.f, cy = 0.f, cz = 0.f;
 };
 
 struct Fwd {
@@ -280,6 +287,8 @@ struct Fwd {
       ++m->ev_used;
       m->prof_flops += 2.0 * B * out.H * out.W * (double)out.C *
                        ((a.C + (b ? b->C : 0)) * ks * ks + (s0 ? s0->C : 0) + (s1 ? s1->C : 0));
+      const double cin = a.C + (b ? b->C : 0), csc = (s0 ? s0->C : 0) + (s1 ? s1->C : 0);
+      m->prof_bytes += (double)B * out.H * out.W * esz * (cin + csc + (skip ? out.C : 0) + out.C) + (double)esz * out.C * (cin * ks * ks + csc);
     }
     return rc;
   }
@@ -405,7 +414,8 @@ struct Fwd {
     if (!dry) {
       fd_edge_args a; a.x = ptr(pyramid.off); a.w = m->wo; a.base = os.base; a.kold = os.kold; a.coef = os.coef; a.out = os.dst; a.ksave = os.ksave;
       a.B = B; a.H = F; a.W = T;
-      FD_TRY(fd_edge_op(3, a, dt, st));
+      if (os.score) { a.y = os.yv; a.z = os.z; a.cb = os.cb; a.cy = os.cy; a.cz = os.cz; }
+      FD_TRY(fd_edge_op(os.score ? 4 : 3, a, dt, st));
     }
     tfree(pyramid);
     return FD_OK;
@@ -503,6 +513,63 @@ int ode_enqueue(fd_model* m, const float* Y, const float* noise, float sigma_fac
     if (traj) FD_HIP(hipMemcpyAsync(traj + 2 * nstate * i, X, sizeof(float) * 2 * nstate, hipMemcpyDeviceToDevice, st));
     t = t + dt;
     if (i < N) dt = ts[i + 1] - t;
+  }
+  return FD_OK;
+}
+
+// ---- ScoreDec baseline: OUVE closed forms + predictor-corrector sampler -------------------
+// float32 scalar arithmetic like the reference's [B]-shaped tensors (sdes.py:168-192)
+float ouve_std(const fd_score_config& c, float t) {
+  const float th = c.theta, ls = logf(c.sigma_max / c.sigma_min);
+  const float num = c.sigma_min * c.sigma_min * expf(-2.f * th * t) * (expf(2.f * (th + ls) * t) - 1.f) * ls;
+  return sqrtf(num / (th + ls));
+}
+float ouve_diffusion(const fd_score_config& c, float t) {
+  const float ls = logf(c.sigma_max / c.sigma_min);
+  return c.sigma_min * powf(c.sigma_max / c.sigma_min, t) * sqrtf(2.f * ls);
+}
+// torch.linspace(start, end, steps) in float32 (see oracle linspace_f32)
+std::vector<float> linspace_f32(float start, float end, int steps) {
+  std::vector<float> out(steps);
+  if (steps == 1) { out[0] = start; return out; }
+  const float step = (end - start) / (float)(steps - 1);
+  const int half = steps / 2;
+  for (int i = 0; i < steps; ++i) out[i] = i < half ? fmaf(step, (float)i, start) : fmaf(-step, (float)(steps - 1 - i), end);
+  return out;
+}
+int score_draws(const fd_score_config& c) {
+  return 1 + c.N * ((c.corrector == FD_CORRECTOR_ALD ? c.corrector_steps : 0) + (c.predictor != FD_PREDICTOR_NONE ? 1 : 0));
+}
+
+// sampling/__init__.py:57-70.  noise = [draws][B][F][T] complex64, consumed in the reference's order of randn_like calls.
+int score_enqueue(fd_model* m, const float* Y, const float* noise, const fd_score_config& c, float* X, int B, int T, void* ws, size_t ws_bytes,
+                  hipStream_t st) {
+  const size_t nstate = (size_t)B * m->n_freq * T;
+  const float* z = noise;
+  auto next_z = [&]() { const float* r = z; z += 2 * nstate; return r; };
+  FD_TRY(fd_caxpy(Y, next_z(), ouve_std(c, 1.0f), X, (long long)nstate, st));                 // prior, sdes.py:197-202
+  const std::vector<float> ts = linspace_f32(1.0f, c.t_eps, c.N);
+  for (int i = 0; i < c.N; ++i) {
+    const float t = ts[i], std_t = ouve_std(c, t);
+    if (c.corrector == FD_CORRECTOR_ALD) {                                                      // correctors.py:52-66
+      for (int k = 0; k < c.corrector_steps; ++k) {
+        const float step = (c.snr * std_t) * (c.snr * std_t) * 2.f;
+        OutSpec os; os.score = true; os.base = X; os.dst = X; os.coef = -step / std_t; os.z = next_z(); os.cz = sqrtf(step * 2.f);
+        FD_TRY(forward_call(m, X, Y, nullptr, t, 1, os, B, T, ws, ws_bytes, st));
+      }
+    }
+    const bool last = i == c.N - 1 && c.denoise;                                                // result = x_mean of the last predictor step
+    if (c.predictor == FD_PREDICTOR_REVERSE_DIFFUSION) {                                        // predictors.py:61-71, sdes.py:62-77,111-116
+      const float dt = 1.f / (float)c.N, G = ouve_diffusion(c, t) * sqrtf(dt);
+      OutSpec os; os.score = true; os.base = X; os.dst = X; os.yv = Y;
+      os.cb = 1.f + c.theta * dt; os.cy = -c.theta * dt; os.coef = -(G * G) / std_t; os.z = next_z(); os.cz = last ? 0.f : G;
+      FD_TRY(forward_call(m, X, Y, nullptr, t, 1, os, B, T, ws, ws_bytes, st));
+    } else if (c.predictor == FD_PREDICTOR_EULER_MARUYAMA) {                                    // predictors.py:48-58, sdes.py:93-109
+      const float dt = -1.f / (float)c.N, g = ouve_diffusion(c, t);
+      OutSpec os; os.score = true; os.base = X; os.dst = X; os.yv = Y;
+      os.cb = 1.f - c.theta * dt; os.cy = c.theta * dt; os.coef = g * g * dt / std_t; os.z = next_z(); os.cz = last ? 0.f : g * sqrtf(-dt);
+      FD_TRY(forward_call(m, X, Y, nullptr, t, 1, os, B, T, ws, ws_bytes, st));
+    }
   }
   return FD_OK;
 }
@@ -754,15 +821,75 @@ extern "C" int fd_enhance(fd_model* m, const float* y, const float* noise, float
   });
 }
 
+// Shared front end / back end of the three enhancement models:  STFT -> body(Y, X) -> iSTFT
+template <typename Body>
+static int enhance_common(fd_model* m, const char* who, const float* y, float* x_hat, int B, int L, void* ws, size_t ws_bytes, GraphKey key,
+                          int use_graph, void* stream, Body&& body) {
+  FD_TRY(check_ready(m));
+  FD_REQUIRE(y && x_hat && ws, "%s: null pointer", who);
+  FD_REQUIRE(B > 0 && L > m->cfg.n_fft / 2, "%s: clips must be longer than %d samples", who, m->cfg.n_fft / 2);
+  const int T = 1 + L / m->cfg.hop, Tp = fd_padded_frames(T);
+  FD_TRY(check_shape(m, B, Tp));
+  const size_t need = fd_enhance_workspace_bytes(m, B, L);
+  if (ws_bytes < need) return fd_set_error(FD_ENOMEM, "%s: workspace %zu < required %zu bytes", who, ws_bytes, need);
+  hipStream_t st = fd_stream(stream);
+  const size_t state = fd_align(sizeof(float) * 2 * (size_t)B * m->n_freq * Tp);
+  float* Y = (float*)ws;
+  float* X = (float*)((char*)ws + state);
+  float* normfac = (float*)((char*)ws + 2 * state);
+  char* rest = (char*)ws + 2 * state + fd_align(sizeof(float) * B);
+  const size_t rest_bytes = ws_bytes - (2 * state + fd_align(sizeof(float) * B));
+  key.y = y; key.xhat = x_hat; key.ws = ws; key.B = B; key.L = L;
+  return run_maybe_graph(m, key, use_graph != 0, st, [&]() {
+    FD_TRY(fd_stft_forward(m->stft, y, B, L, m->cfg.alpha, m->cfg.beta, 1, normfac, Y, Tp, rest, rest_bytes, st));
+    FD_TRY(body(Y, X, Tp, (void*)rest, rest_bytes, st));
+    FD_TRY(fd_stft_inverse(m->stft, X, B, T, Tp, m->cfg.alpha, m->cfg.beta, normfac, x_hat, L, rest, rest_bytes, st));
+    return FD_OK;
+  });
+}
+
+extern "C" int fd_score_num_draws(const fd_score_config* c) {
+  if (!c || c->N < 1 || c->corrector_steps < 0) return -1;
+  return score_draws(*c);
+}
+
+extern "C" int fd_score_enhance(fd_model* m, const float* y, const float* noise, const fd_score_config* c, float* x_hat, int B, int L, void* ws,
+                                size_t ws_bytes, int use_graph, void* stream) {
+  FD_REQUIRE(c && noise, "fd_score_enhance: null pointer");
+  FD_REQUIRE(c->N >= 1, "fd_score_enhance: N must be >= 1");
+  FD_REQUIRE(c->predictor >= FD_PREDICTOR_REVERSE_DIFFUSION && c->predictor <= FD_PREDICTOR_NONE, "fd_score_enhance: unknown predictor id %d", c->predictor);
+  FD_REQUIRE(c->corrector == FD_CORRECTOR_ALD || c->corrector == FD_CORRECTOR_NONE, "fd_score_enhance: unknown corrector id %d", c->corrector);
+  FD_REQUIRE(c->corrector_steps >= 0 && c->corrector_steps <= 64, "fd_score_enhance: corrector_steps out of range");
+  FD_REQUIRE(c->sigma_min > 0.f && c->sigma_max > c->sigma_min && c->theta > 0.f, "fd_score_enhance: bad OUVE parameters");
+  FD_REQUIRE(c->t_eps > 0.f && c->t_eps < 1.f, "fd_score_enhance: t_eps must be in (0, 1)");
+  GraphKey key{}; key.noise = noise; key.kind = 3; key.score = *c;
+  const fd_score_config cfg = *c;
+  return enhance_common(m, "fd_score_enhance", y, x_hat, B, L, ws, ws_bytes, key, use_graph, stream,
+                        [&](float* Y, float* X, int Tp, void* rest, size_t rest_bytes, hipStream_t st) {
+                          return score_enqueue(m, Y, noise, cfg, X, B, Tp, rest, rest_bytes, st);
+                        });
+}
+
+extern "C" int fd_regression_enhance(fd_model* m, const float* y, float* x_hat, int B, int L, void* ws, size_t ws_bytes, int use_graph,
+                                     void* stream) {
+  GraphKey key{}; key.kind = 4;
+  return enhance_common(m, "fd_regression_enhance", y, x_hat, B, L, ws, ws_bytes, key, use_graph, stream,
+                        [&](float* Y, float* X, int Tp, void* rest, size_t rest_bytes, hipStream_t st) {
+                          OutSpec os; os.dst = X; os.coef = 1.f;                                 // X_hat = backbone(Y, Y, t = 0), model.py:566-578
+                          return forward_call(m, Y, Y, nullptr, 0.f, 1, os, B, Tp, rest, rest_bytes, st);
+                        });
+}
+
 extern "C" int fd_profile_enable(fd_model* m, int enable) {
   FD_REQUIRE(m, "fd_profile_enable: null model");
   m->profiling = enable != 0;
   m->ev_used = 0;
   m->prof_flops = 0.0;
+  m->prof_bytes = 0.0;
   return FD_OK;
 }
 
-extern "C" int fd_profile_read(fd_model* m, double* conv_ms_total, long long* conv_launches, double* conv_flops_total) {
+extern "C" int fd_profile_read(fd_model* m, double* conv_ms_total, long long* conv_launches, double* conv_flops_total, double* conv_bytes_total) {
   FD_REQUIRE(m, "fd_profile_read: null model");
   double ms = 0.0;
   for (size_t i = 0; i < m->ev_used; ++i) {
@@ -774,6 +901,8 @@ extern "C" int fd_profile_read(fd_model* m, double* conv_ms_total, long long* co
   if (conv_ms_total) *conv_ms_total = ms;
   if (conv_launches) *conv_launches = (long long)m->ev_used;
   if (conv_flops_total) *conv_flops_total = m->prof_flops;
+  if (conv_bytes_total) *conv_bytes_total = m->prof_bytes;
+  m->prof_bytes = 0.0;
   m->ev_used = 0;
   m->prof_flops = 0.0;
   return FD_OK;

@@ -450,6 +450,179 @@ class FlowModel(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------
+# ScoreDec / regression baselines on the same backbone
+# ------------------------------------------------------------------------------------------------
+class OUVESDE:
+    """flowdec.sdes.OUVESDE (sdes.py:132-206): parameters + the closed forms the sampler needs (float32 like the reference)."""
+
+    def __init__(self, theta, sigma_min, sigma_max, N=1000, **ignored_kwargs):
+        self.theta, self.sigma_min, self.sigma_max, self.N = float(theta), float(sigma_min), float(sigma_max), int(N)
+        self.logsig = float(np.log(self.sigma_max / self.sigma_min))
+
+    def copy(self):
+        return OUVESDE(self.theta, self.sigma_min, self.sigma_max, N=self.N)
+
+    @property
+    def T(self):
+        return 1
+
+    def _std(self, t: torch.Tensor) -> torch.Tensor:                       # sdes.py:181-192
+        th, ls = self.theta, self.logsig
+        return torch.sqrt(self.sigma_min ** 2 * torch.exp(-2 * th * t) * (torch.exp(2 * (th + ls) * t) - 1) * ls / (th + ls))
+
+    def _mean(self, x0, t, y):                                            # sdes.py:176-179
+        e = torch.exp(-self.theta * t)[:, None, None, None]
+        return e * x0 + (1 - e) * y
+
+    def marginal_prob(self, x0, t, y):
+        return self._mean(x0, t, y), self._std(t)
+
+
+class _WaveModel(nn.Module):
+    """Shared waveform plumbing of the baselines (EnhancementModel._preprocess/_postprocess, model.py:129-190)."""
+    strict_loading = False
+
+    def __init__(self, backbone: NCSNpp, feature_extractor: AmplitudeCompressedComplexSTFT, sampling_rate: int = 48000,
+                 lr: float = 1e-4, normalize_mode: str = "noisy", **kwargs):
+        super().__init__()
+        if normalize_mode != "noisy":
+            raise NotImplementedError("flowdec_amd: normalize_mode='none' is not wired to the HIP front-end")
+        self.sampling_rate, self.normalize_mode, self.lr = sampling_rate, normalize_mode, lr
+        self.backbone, self.feature_extractor = backbone, feature_extractor
+        self._io, self._side_stream = {}, None
+
+    @property
+    def device(self):
+        return next(self.backbone.parameters()).device
+
+    def load_state_dict(self, state_dict, strict: bool = False, **kw):
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def _sync_native(self):
+        self.backbone._sigma_y = None
+        self.backbone._stft_cfg = self.feature_extractor._cfg()
+        return self.backbone.handle()
+
+    def _wave_call(self, y, n_draws, noise, generator, launch):
+        """launch(lib, h, y_dev [B, L], noise_dev [n_draws, B, 1, F, Tp] | None, out [B, L], ws) on a capture-safe side stream."""
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("flowdec_amd: move the model to the GPU first (`model.cuda()`)")
+        orig_device, squeeze_dims, y3 = y.device, 0, y
+        while y3.ndim < 3:
+            y3 = y3.unsqueeze(0); squeeze_dims += 1
+        if y3.ndim != 3 or y3.shape[1] != 1:
+            raise RuntimeError(f"enhance expects [L], [1, L] or [B, 1, L] waveforms (got {tuple(y.shape)})")
+        lib = L.load()
+        h = self._sync_native()
+        cfg = self.feature_extractor._cfg()
+        B, Lw = y3.shape[0], y3.shape[-1]
+        F = cfg["n_fft"] // 2 + 1
+        Tp = lib.fd_padded_frames(lib.fd_num_frames(Lw, cfg["hop"]))
+        with torch.cuda.device(dev):
+            key = (B, Lw, n_draws, str(dev))
+            io = self._io.get(key)
+            if io is None:
+                io = dict(y=torch.empty(B, Lw, dtype=torch.float32, device=dev), out=torch.empty(B, Lw, dtype=torch.float32, device=dev),
+                          noise=torch.empty(n_draws, B, 1, F, Tp, dtype=torch.complex64, device=dev) if n_draws else None)
+                self._io = {key: io}
+            io["y"].copy_(y3.reshape(B, Lw))
+            if n_draws:
+                if noise is not None:
+                    io["noise"].copy_(noise.to(dev, torch.complex64).reshape(io["noise"].shape))
+                else:
+                    io["noise"].copy_(torch.randn(io["noise"].shape, dtype=torch.complex64, device=dev, generator=generator))
+            need = lib.fd_enhance_workspace_bytes(h, B, Lw)
+            if need == 0:
+                raise RuntimeError("flowdec_hip: " + lib.fd_last_error().decode())
+            ws = self.backbone.workspace(("enh", B, Lw), need, dev)
+            cur = torch.cuda.current_stream(dev)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(dev)
+            side = self._side_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                launch(lib, h, io, B, Lw, ws)
+                x_hat = io["out"].reshape(B, 1, Lw).clone()
+            cur.wait_stream(side)
+        x_hat.record_stream(cur)
+        for _ in range(squeeze_dims):
+            x_hat = x_hat.squeeze(0)
+        return x_hat.to(orig_device)
+
+
+class ScoreModel(_WaveModel):
+    """Drop-in for flowdec.model.ScoreModel on the inference path (model.py:581-690): `forward` = score estimate,
+    `enhance` = predictor-corrector sampling (sampler_type='pc').  Extensions: noise= / generator= / use_graph=."""
+
+    def __init__(self, sde: OUVESDE, t_eps: float, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.sde, self.t_eps = sde, t_eps
+
+    def sde_std(self, t_batch):
+        return self.sde._std(t_batch)
+
+    def forward(self, xt, y, t_batch):
+        """-backbone(xt, y, t) / std(t)  (model.py:613-628)."""
+        if t_batch.ndim == 0:
+            t_batch = t_batch.unsqueeze(0)
+        self._sync_native()
+        std = self.sde_std(t_batch.float())
+        return -self.backbone(xt, y, t_batch) / std.reshape(-1, 1, 1, 1)
+
+    def num_draws(self, N=None, predictor="reverse_diffusion", corrector="ald", corrector_steps=1) -> int:
+        N = self.sde.N if N is None else N
+        return 1 + N * ((corrector_steps if corrector == "ald" else 0) + (1 if predictor != "none" else 0))
+
+    @torch.no_grad()
+    def enhance(self, y, sampler_type="pc", predictor="reverse_diffusion", corrector="ald", N=30, corrector_steps=1, snr=0.5,
+                return_preprocess_info=False, denoise=True, noise=None, generator=None, use_graph: bool = True, **kwargs):
+        if sampler_type != "pc":
+            if sampler_type == "ode":
+                raise NotImplementedError("flowdec_amd.ScoreModel: sampler_type='ode' (scipy solve_ivp black box) is out of scope")
+            raise ValueError(f"{sampler_type} is not a valid sampler type!")
+        if predictor not in L.PREDICTORS:
+            raise ValueError(f"unknown predictor {predictor!r}; supported: {sorted(L.PREDICTORS)}")
+        if corrector not in L.CORRECTORS:
+            raise ValueError(f"unknown corrector {corrector!r}; supported: {sorted(L.CORRECTORS)}")
+        if return_preprocess_info:
+            raise NotImplementedError("flowdec_amd.ScoreModel.enhance: return_preprocess_info is only wired for FlowModel")
+        N = self.sde.N if N is None else int(N)
+        cfg = L.FdScoreConfig(self.sde.theta, self.sde.sigma_min, self.sde.sigma_max, float(kwargs.get("eps", self.t_eps)), float(snr), N,
+                              L.PREDICTORS[predictor], L.CORRECTORS[corrector], int(corrector_steps), int(bool(denoise)))
+        n_draws = self.num_draws(N, predictor, corrector, corrector_steps)
+
+        def launch(lib, h, io, B, Lw, ws):
+            assert lib.fd_score_num_draws(C.byref(cfg)) == n_draws
+            L.check(lib.fd_score_enhance(h, L.ptr(io["y"]), L.ptr(torch.view_as_real(io["noise"])), C.byref(cfg), L.ptr(io["out"]), B, Lw,
+                                         L.ptr(ws), ws.numel(), int(use_graph), L.stream()))
+        return self._wave_call(y, n_draws, noise, generator, launch)
+
+
+class RegressionModel(_WaveModel):
+    """Drop-in for flowdec.model.RegressionModel.enhance (model.py:539-578): one backbone call with x_t = Y, t = 0."""
+
+    def __init__(self, *args, loss_type: str = "l2", **kwargs):
+        super().__init__(*args, **kwargs)
+        self.loss_type = loss_type
+
+    def forward(self, xt, y, t):
+        if t.ndim == 0:
+            t = t.unsqueeze(0)
+        self._sync_native()
+        return self.backbone(xt, y, t)
+
+    @torch.no_grad()
+    def enhance(self, y, return_preprocess_info=False, use_graph: bool = True, **kwargs):
+        if return_preprocess_info:
+            raise NotImplementedError("flowdec_amd.RegressionModel.enhance: return_preprocess_info is only wired for FlowModel")
+
+        def launch(lib, h, io, B, Lw, ws):
+            L.check(lib.fd_regression_enhance(h, L.ptr(io["y"]), L.ptr(io["out"]), B, Lw, L.ptr(ws), ws.numel(), int(use_graph), L.stream()))
+        return self._wave_call(y, 0, None, None, launch)
+
+
+# ------------------------------------------------------------------------------------------------
 # presets (replace hydra.compose('flowdec_75m' | 'flowdec_25s'), config/flowdec_75m.yaml etc.)
 # ------------------------------------------------------------------------------------------------
 BACKBONE_FINAL_NO_ATTN = dict(image_size=768, nonlinearity="swish", nf=64, ch_mult=(4, 4, 4, 2), num_res_blocks=1,
@@ -464,16 +637,25 @@ PRESETS = {
     "flowdec_25s": dict(sigma_file="flowdec_autoparams_25s.npy"),
     "flowdec_75m_globsigy": dict(sigma_file=None),
     "flowdec_25s_globsigy": dict(sigma_file=None),
+    # baselines (config/baseline_scoredec_75s.yaml -> model/score_model_final.yaml + sde/ouve_final.yaml; baseline_regression_75s.yaml)
+    "baseline_scoredec_75s": dict(kind="score", sde=dict(theta=1.5, sigma_min=0.05, sigma_max=0.82, N=30), t_eps=3e-2),
+    "baseline_regression_75s": dict(kind="regression"),
 }
 
 
-def from_preset(name: str = "flowdec_75m", precision: str = "bf16", **backbone_overrides) -> FlowModel:
+def from_preset(name: str = "flowdec_75m", precision: str = "bf16", **backbone_overrides):
     """Instantiate the model a reference user gets from `instantiate(compose(config_name=name)['model'])`."""
     if name not in PRESETS:
         raise KeyError(f"unknown preset {name!r}; available: {sorted(PRESETS)}")
     bb = dict(BACKBONE_FINAL_NO_ATTN); bb.update(backbone_overrides)
     backbone = NCSNpp(precision=precision, **bb)
     fe = AmplitudeCompressedComplexSTFT(window_fn="hann", n_fft=1534, n_hops=4, sampling_rate=48000, alpha=0.3, beta=0.33)
+    kind = PRESETS[name].get("kind", "flow")
+    if kind == "score":
+        return ScoreModel(sde=OUVESDE(**PRESETS[name]["sde"]), t_eps=PRESETS[name]["t_eps"], backbone=backbone, feature_extractor=fe,
+                          sampling_rate=48000).eval()
+    if kind == "regression":
+        return RegressionModel(backbone=backbone, feature_extractor=fe, sampling_rate=48000).eval()
     sf = PRESETS[name]["sigma_file"]
     sigma_y = sigma_y_from_file(sf, factor=1, kernel_bandwidth=3) if sf else 0.66
     return FlowModel(backbone=backbone, feature_extractor=fe, sampling_rate=48000, sigma_x=0.0, sigma_y=sigma_y).eval()

@@ -190,10 +190,38 @@ size_t fd_enhance_workspace_bytes(const fd_model* m, int B, int L);
 int fd_enhance(fd_model* m, const float* y, const float* noise, float sigma_fac, int N, int solver, float* x_hat, int B,
                int L, void* ws, size_t ws_bytes, int use_graph, void* stream);
 
+/* ---- ScoreDec / regression baselines on the same backbone -------------------------------
+ * ScoreModel.enhance (model.py:630-657) with the predictor-corrector sampler of sampling/__init__.py:32-72 on the OUVE
+ * SDE (sdes.py:132-206): predictors reverse_diffusion / euler_maruyama / none (sampling/predictors.py:48-83), correctors
+ * ald / none (sampling/correctors.py:42-80); the score is -backbone(x, y, t) / std(t) (model.py:613-628). */
+#define FD_PREDICTOR_REVERSE_DIFFUSION 0
+#define FD_PREDICTOR_EULER_MARUYAMA 1
+#define FD_PREDICTOR_NONE 2
+#define FD_CORRECTOR_ALD 0
+#define FD_CORRECTOR_NONE 1
+typedef struct fd_score_config {
+  float theta, sigma_min, sigma_max; /* OUVESDE(theta, sigma_min, sigma_max), config/model/sde/ouve_final.yaml */
+  float t_eps;                       /* ScoreModel.t_eps: timesteps = linspace(1, t_eps, N) */
+  float snr;                         /* corrector target SNR */
+  int N;                             /* reverse steps */
+  int predictor, corrector, corrector_steps;
+  int denoise;                       /* != 0: return the noise-free mean of the last predictor step */
+} fd_score_config;
+/* Number of Gaussian draws the sampler consumes: 1 (prior) + N * (corrector_steps [ald] + 1 [predictor != none]). */
+int fd_score_num_draws(const fd_score_config* cfg);
+/* y [B][L] f32 -> x_hat [B][L] f32.  noise = [fd_score_num_draws][B][n_freq][T_pad] complex64 standard normal, consumed in
+ * the order of the reference's randn_like calls.  Workspace: fd_enhance_workspace_bytes(m, B, L). */
+int fd_score_enhance(fd_model* m, const float* y, const float* noise, const fd_score_config* cfg, float* x_hat, int B, int L,
+                     void* ws, size_t ws_bytes, int use_graph, void* stream);
+/* RegressionModel.enhance (model.py:566-578): x_hat = iSTFT(backbone(Y, Y, t = 0)). */
+int fd_regression_enhance(fd_model* m, const float* y, float* x_hat, int B, int L, void* ws, size_t ws_bytes, int use_graph,
+                          void* stream);
+
 /* Per-launch timing of the dominant kernel (conv MFMA) measured with HIP events on the launch stream;
  * used by bench.py for the roofline object.  enable != 0 starts recording (forces eager launches). */
 int fd_profile_enable(fd_model* m, int enable);
-int fd_profile_read(fd_model* m, double* conv_ms_total, long long* conv_launches, double* conv_flops_total);
+int fd_profile_read(fd_model* m, double* conv_ms_total, long long* conv_launches, double* conv_flops_total,
+                    double* conv_bytes_total /* algorithmic HBM bytes: operands read once + output written once */);
 
 #ifdef __cplusplus
 }

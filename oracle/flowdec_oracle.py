@@ -628,3 +628,111 @@ def enhance(net: NCSNppOracle, y: np.ndarray, noise: np.ndarray, sigma_y, N: int
     if return_traj:
         return res, [postprocess(X, info, alpha, beta) for X in res]
     return postprocess(res, info, alpha, beta)
+
+
+# --------------------------------------------------------------------------------------
+# (f3) ScoreDec baseline: OUVE SDE + predictor-corrector sampler, and the regression baseline
+# (flowdec/sdes.py:132-206, sampling/__init__.py:32-72, sampling/predictors.py:48-71,
+#  sampling/correctors.py:42-66, model.py:566-578 (RegressionModel.enhance), :613-657
+#  (ScoreModel.forward / enhance)).  Pinned by tests/golden/g13_score_nf8.npz, produced by
+#  running the reference classes with torch.randn_like replaced by a seeded NumPy stream.
+# --------------------------------------------------------------------------------------
+def linspace_f32(start: float, end: float, steps: int) -> np.ndarray:
+    """torch.linspace(start, end, steps) in float32: step = (end-start)/(steps-1) in float32, first half
+    start + step*i, second half end - step*(steps-1-i), each one fused multiply-add."""
+    s, e = np.float32(start), np.float32(end)
+    if steps == 1:
+        return np.array([s], dtype=np.float32)
+    step = np.float64(np.float32((e - s) / np.float32(steps - 1)))
+    out = np.empty(steps, dtype=np.float32)
+    half = steps // 2
+    for i in range(steps):
+        out[i] = np.float32(np.float64(s) + step * i) if i < half else np.float32(np.float64(e) - step * (steps - 1 - i))
+    return out
+
+
+class OUVE:
+    """sdes.py:132-206.  Scalar (per-call) arithmetic is float32 like the reference's [B] tensors."""
+
+    def __init__(self, theta=1.5, sigma_min=0.05, sigma_max=0.5, N=30):
+        self.theta, self.sigma_min, self.sigma_max, self.N = theta, sigma_min, sigma_max, N
+        self.logsig = np.log(sigma_max / sigma_min)
+
+    def std(self, t) -> np.float32:                                        # sdes.py:181-192
+        t = np.float32(t)
+        th, ls = self.theta, self.logsig
+        num = (np.float32(self.sigma_min ** 2) * np.exp(np.float32(-2 * th) * t)
+               * (np.exp(np.float32(2 * (th + ls)) * t) - np.float32(1)) * np.float32(ls))
+        return np.float32(np.sqrt(np.float32(num / np.float32(th + ls))))
+
+    def diffusion(self, t) -> np.float32:                                  # sdes.py:168-172
+        sigma = np.float32(self.sigma_min) * np.float32(np.float32(self.sigma_max / self.sigma_min) ** np.float32(t))
+        return np.float32(sigma * np.float32(np.sqrt(2 * self.logsig)))
+
+
+def score_pc_sample(net: NCSNppOracle, Y: np.ndarray, noises, sde: OUVE, N: int, predictor="reverse_diffusion", corrector="ald",
+                    corrector_steps=1, snr=0.5, t_eps=3e-2, denoise=True):
+    """sampling/__init__.py:57-70.  `noises` = iterator of complex standard-normal arrays of Y's shape, consumed in the
+    reference's draw order: prior, then per step [corrector noise x n_steps], predictor noise.  -> (X, nfe)"""
+    noises = iter(noises)
+    c64 = np.complex64
+    score = lambda x, t: (-net.forward(x, Y, np.asarray([t], dtype=np.float32)) / sde.std(t)).astype(c64)   # model.py:613-628
+    x = (Y + next(noises) * sde.std(1.0)).astype(c64)                                                         # sdes.py:197-202
+    x_mean = x
+    ts = linspace_f32(1.0, t_eps, N)
+    nfe = 0
+    for i in range(N):
+        t = ts[i]
+        if corrector == "ald":                                                                                # correctors.py:52-66
+            std = sde.std(t)
+            for _ in range(corrector_steps):
+                grad = score(x, t); nfe += 1
+                z = next(noises)
+                step = np.float32(np.float32(np.float32(snr) * std) ** 2 * np.float32(2))
+                x_mean = (x + step * grad).astype(c64)
+                x = (x_mean + z * np.float32(np.sqrt(np.float32(step * np.float32(2))))).astype(c64)
+        elif corrector != "none":
+            raise ValueError(corrector)
+        if predictor == "reverse_diffusion":                                                                  # predictors.py:61-71, sdes.py:62-77,111-116
+            dt = 1.0 / N
+            f = (np.float32(sde.theta) * (Y - x) * np.float32(dt)).astype(c64)
+            G = np.float32(sde.diffusion(t) * np.float32(np.sqrt(np.float32(dt))))
+            rev_f = (f - np.float32(G ** 2) * score(x, t)).astype(c64); nfe += 1
+            z = next(noises)
+            x_mean = (x - rev_f).astype(c64)
+            x = (x_mean + G * z).astype(c64)
+        elif predictor == "euler_maruyama":                                                                   # predictors.py:48-58, sdes.py:93-109
+            dt = -1.0 / N
+            z = next(noises)
+            g = sde.diffusion(t)
+            drift = (np.float32(sde.theta) * (Y - x) - np.float32(g ** 2) * score(x, t)).astype(c64); nfe += 1
+            x_mean = (x + drift * np.float32(dt)).astype(c64)
+            x = (x_mean + np.float32(g * np.float32(np.sqrt(-dt))) * z).astype(c64)
+        elif predictor != "none":
+            raise ValueError(predictor)
+    if denoise == "both":
+        return (x_mean, x), nfe
+    return (x_mean if denoise else x), nfe
+
+
+def score_noise_count(N: int, predictor="reverse_diffusion", corrector="ald", corrector_steps=1) -> int:
+    return 1 + N * ((corrector_steps if corrector == "ald" else 0) + (1 if predictor != "none" else 0))
+
+
+def score_enhance(net: NCSNppOracle, y: np.ndarray, noises, sde: OUVE, N=30, alpha=ALPHA, beta=BETA, **kw) -> np.ndarray:
+    Y, info = preprocess(y, alpha, beta)
+    X, _ = score_pc_sample(net, Y, noises, sde, N, **kw)
+    return postprocess(X, info, alpha, beta)
+
+
+def regression_enhance(net: NCSNppOracle, y: np.ndarray, alpha=ALPHA, beta=BETA) -> np.ndarray:
+    """model.py:566-578: X_hat = backbone(Y, Y, t = 0)."""
+    Y, info = preprocess(y, alpha, beta)
+    return postprocess(net.forward(Y, Y, np.zeros(1, dtype=np.float32)), info, alpha, beta)
+
+
+def seeded_noises(seed: int, shape):
+    """The shared noise stream of the score-sampler fixtures: complex standard normal (var 1/2 per part)."""
+    rng = np.random.default_rng(seed)
+    while True:
+        yield ((rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) / np.sqrt(2.0)).astype(np.complex64)

@@ -1,0 +1,108 @@
+"""GPU parity tests of the ScoreDec (predictor-corrector sampler on the OUVE SDE) and regression baselines
+(fd_score_enhance / fd_regression_enhance) against golden vectors produced by the reference classes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import flowdec_oracle as O
+from test_hip_model import TOL_WAVE, cu
+from test_hip_ops import check
+from test_oracle_golden import SCORE_CASES
+
+pytestmark = pytest.mark.gpu
+_cache = {}
+
+
+def baseline(kind, prec):
+    key = (kind, prec)
+    if key not in _cache:
+        import flowdec_amd
+        g = load_golden("g13_score_nf8.npz")
+        m = flowdec_amd.from_preset("baseline_scoredec_75s" if kind == "score" else "baseline_regression_75s", precision=prec, nf=8)
+        if kind == "score":
+            m.sde = flowdec_amd.OUVESDE(*[float(v) for v in g["sde"]], N=30)      # the fixture uses ouve_sgmse.yaml's sigma_max
+            m.t_eps = float(g["t_eps"])
+        sd = O.random_state_dict(seed=int(g["weight_seed"]), nf=8)
+        sd["backbone.output_layer.weight"] = sd["backbone.output_layer.weight"] * np.float32(g["out_scale"])
+        res = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        assert not res.unexpected_keys and not [k for k in res.missing_keys if k.startswith("backbone.")]
+        _cache[key] = m.cuda()
+    return _cache[key]
+
+
+def golden_noise(g, n):
+    Tp = O.padded_frames(O.num_frames(g["y"].shape[-1]))
+    s = O.seeded_noises(int(g["noise_seed"]), (2, 1, 768, Tp))
+    return torch.from_numpy(np.stack([next(s) for _ in range(n)]))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", list(SCORE_CASES))
+def test_score_enhance_golden(case, prec):
+    g = load_golden("g13_score_nf8.npz")
+    m = baseline("score", prec)
+    kw = dict(SCORE_CASES[case])
+    n = m.num_draws(kw["N"], kw["predictor"], kw["corrector"], kw.get("corrector_steps", 1))
+    out = m.enhance(torch.from_numpy(g["y"]), noise=golden_noise(g, n), **kw)
+    assert out.shape == g[case].shape and out.device.type == "cpu"
+    check(f"score_{case}[{prec}]", out.numpy(), g[case], TOL_WAVE[prec])
+
+
+def test_score_graph_equals_eager_and_batch_independent():
+    g = load_golden("g13_score_nf8.npz")
+    m = baseline("score", "bf16")
+    kw = dict(SCORE_CASES["rd_ald_N3"])
+    nz = golden_noise(g, 7)
+    y = cu(g["y"])
+    a = m.enhance(y, noise=nz, use_graph=True, **kw)
+    b = m.enhance(y, noise=nz, use_graph=False, **kw)
+    a2 = m.enhance(y, noise=nz, use_graph=True, **kw)     # graph replay
+    assert torch.equal(a, b) and torch.equal(a, a2) and a.is_cuda
+    one = m.enhance(y[1:], noise=nz[:, 1:], **kw)          # batch items are independent end to end
+    assert torch.equal(one, a[1:])
+    s1 = m.enhance(y, generator=torch.Generator(device="cuda").manual_seed(5), **kw)
+    s2 = m.enhance(y, generator=torch.Generator(device="cuda").manual_seed(5), **kw)
+    assert torch.equal(s1, s2) and not torch.equal(s1, a)
+
+
+def test_score_forward_is_scaled_backbone():
+    g = load_golden("g13_score_nf8.npz")
+    m = baseline("score", "fp32")
+    x = torch.randn(2, 1, 768, 64, dtype=torch.complex64, device="cuda")
+    y = torch.randn(2, 1, 768, 64, dtype=torch.complex64, device="cuda")
+    t = torch.tensor([0.3, 0.8], device="cuda")
+    sde = O.OUVE(*[float(v) for v in g["sde"]])
+    ref = -m.backbone(x, y, t) / torch.tensor([sde.std(0.3), sde.std(0.8)], device="cuda").reshape(2, 1, 1, 1)
+    assert rel_err(m(x, y, t).cpu().numpy(), ref.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_regression_enhance_golden(prec):
+    g = load_golden("g13_score_nf8.npz")
+    m = baseline("regression", prec)
+    out = m.enhance(torch.from_numpy(g["y"]))
+    check(f"regression[{prec}]", out.numpy(), g["regression"], TOL_WAVE[prec])
+    assert torch.equal(m.enhance(torch.from_numpy(g["y"][0, 0])), out[0, 0])   # 1-D input path
+
+
+def test_score_errors():
+    from flowdec_amd import _lib as L
+    m = baseline("score", "bf16")
+    y = torch.zeros(1, 1, 4800)
+    with pytest.raises(ValueError):
+        m.enhance(y, predictor="bogus")
+    with pytest.raises(ValueError):
+        m.enhance(y, corrector="bogus")
+    with pytest.raises(ValueError):
+        m.enhance(y, sampler_type="bogus")
+    with pytest.raises(NotImplementedError):
+        m.enhance(y, sampler_type="ode")
+    lib = L.load()
+    bad = L.FdScoreConfig(1.5, 0.5, 0.05, 0.03, 0.5, 3, 0, 0, 1, 1)    # sigma_max < sigma_min
+    rc = lib.fd_score_enhance(m.backbone.handle(), C.c_void_p(8), C.c_void_p(8), C.byref(bad), C.c_void_p(8), 1, 4800, C.c_void_p(8), 1 << 40, 0, None)
+    assert rc != 0 and b"OUVE" in lib.fd_last_error()
+    cfg = L.FdScoreConfig(1.5, 0.05, 0.5, 0.03, 0.5, 30, 0, 0, 1, 1)
+    assert lib.fd_score_num_draws(C.byref(cfg)) == 61

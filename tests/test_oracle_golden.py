@@ -162,3 +162,52 @@ def test_enhance_traj_and_1d():
     assert rel_err(waves[-1], g["traj_last_wave"]) < 1e-4
     x1 = O.enhance(net, g["y"][0:1], g["noise"][0:1], g["sigma_y"], N=2, solver="euler")
     assert rel_err(x1[0, 0], g["euler_N2_1d"]) < 1e-4
+
+
+# ---- (f3) ScoreDec / regression baselines ---------------------------------------------------------------
+SCORE_CASES = {
+    "rd_ald_N3": dict(N=3, predictor="reverse_diffusion", corrector="ald", corrector_steps=1, snr=0.5),
+    "rd_none_N4": dict(N=4, predictor="reverse_diffusion", corrector="none"),
+    "em_ald2_N2": dict(N=2, predictor="euler_maruyama", corrector="ald", corrector_steps=2, snr=0.33),
+    "rd_ald_N3_nodenoise": dict(N=3, predictor="reverse_diffusion", corrector="ald", corrector_steps=1, snr=0.5, denoise=False),
+}
+
+
+def score_net(g):
+    sd = O.random_state_dict(seed=int(g["weight_seed"]), nf=8)
+    sd["backbone.output_layer.weight"] = sd["backbone.output_layer.weight"] * np.float32(g["out_scale"])
+    return O.NCSNppOracle(sd, nf=8), sd
+
+
+def test_ouve_closed_forms_and_timesteps():
+    g = load_golden("g13_score_nf8.npz")
+    sde = O.OUVE(*[float(v) for v in g["sde"]])
+    for t, s, d in zip(g["std_t"], g["std"], g["diffusion"]):
+        assert abs(sde.std(t) - s) <= 2e-7 * abs(s) + 1e-9
+        assert abs(sde.diffusion(t) - d) <= 2e-7 * abs(d)
+    assert np.array_equal(O.linspace_f32(1.0, 3e-2, 30), g["timesteps_N30"])        # bit-exact like t_span
+    assert np.array_equal(O.linspace_f32(0.0, 1.0, 7), O.t_span_linspace(6))
+
+
+@pytest.mark.parametrize("case,item", [("rd_ald_N3", 1), ("rd_none_N4", 0), ("em_ald2_N2", 1)])
+def test_score_sampler_matches_reference(case, item):
+    """One batch item per case keeps the CPU suite short (items are independent end to end); the GPU tests check both."""
+    g = load_golden("g13_score_nf8.npz")
+    net, _ = score_net(g)
+    y = g["y"][item:item + 1]
+    Tp = O.padded_frames(O.num_frames(y.shape[-1]))
+    sde = O.OUVE(*[float(v) for v in g["sde"]])
+    noises = (z[item:item + 1] for z in O.seeded_noises(int(g["noise_seed"]), (2, 1, 768, Tp)))
+    kw = dict(SCORE_CASES[case])
+    Y, info = O.preprocess(y)
+    (x_mean, x), nfe = O.score_pc_sample(net, Y, noises, sde, kw.pop("N"), t_eps=float(g["t_eps"]), denoise="both", **kw)
+    assert nfe == O.score_noise_count(SCORE_CASES[case]["N"], **{k: v for k, v in kw.items() if k != "snr"}) - 1
+    assert rel_err(O.postprocess(x_mean, info), g[case][item:item + 1]) < 2e-4
+    if case + "_nodenoise" in g:
+        assert rel_err(O.postprocess(x, info), g[case + "_nodenoise"][item:item + 1]) < 2e-4
+
+
+def test_regression_matches_reference():
+    g = load_golden("g13_score_nf8.npz")
+    net, _ = score_net(g)
+    assert rel_err(O.regression_enhance(net, g["y"][:1]), g["regression"][:1]) < 1e-4
