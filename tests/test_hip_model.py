@@ -6,7 +6,7 @@ import torch
 
 from conftest import load_golden, rel_err
 from oracle import flowdec_oracle as O
-from test_hip_ops import check, report
+from test_hip_ops import REPORT, check, report
 
 pytestmark = pytest.mark.gpu
 
@@ -80,6 +80,14 @@ def test_enhance_golden(solver, N, prec):
     x = m.enhance(y, N=N, solver=solver, noise=torch.from_numpy(g["noise"]))
     assert x.shape == (2, 1, 24000) and x.device.type == "cpu" and x.dtype == torch.float32
     check(f"enhance[{solver},N={N},{prec}]", x.numpy(), g[f"{solver}_N{N}"], TOL_WAVE[prec])
+    # the same difference in the reference's own evaluation units (eval/metrics.py): SI-SDR of the build's output against
+    # the reference's output, and the log-spectral MSE between them (dB^2)
+    from flowdec_amd import metrics
+    sdr = min(metrics.si_sdr(x[i].numpy(), g[f"{solver}_N{N}"][i]) for i in range(2))
+    lsm = max(metrics.logspec_mse(x[i].numpy(), g[f"{solver}_N{N}"][i]) for i in range(2))
+    with open(REPORT, "a") as f:
+        f.write(f"{f'enhance[{solver},N={N},{prec}] vs reference':60s} SI-SDR={sdr:.1f} dB  logspec-MSE={lsm:.3e} dB^2\n")
+    assert sdr > {"fp32": 80.0, "bf16": 15.0}[prec]
 
 
 def test_enhance_graph_equals_eager():

@@ -141,3 +141,16 @@ def test_batch_sharding_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert all("ok" in o for o in outs)
+
+
+def test_parity_metrics_match_reference():
+    """SI-SDR / SI-SIR / SI-SAR equal the reference's eval/metrics.py SISXR on the golden signals; logspec_mse properties."""
+    from conftest import load_golden
+    from flowdec_amd import metrics
+    g = load_golden("g14_metrics.npz")
+    for i in range(3):
+        got = metrics.si_sxr(g[f"xhat{i}"], g[f"x{i}"], g[f"y{i}"])
+        np.testing.assert_allclose(got, g[f"sisxr{i}"], rtol=0, atol=1e-4)
+    x = g["x0"]
+    assert metrics.si_sdr(0.5 * x, x) > 100 and abs(metrics.si_sdr(x + 0.1 * g["x1"], x) - 20.0) < 0.5
+    assert metrics.logspec_mse(x, x) == 0.0 and metrics.logspec_mse(2 * x, x) == pytest.approx((20 * np.log10(2)) ** 2, rel=1e-3)
