@@ -31,7 +31,10 @@ namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int ROWB = 80;   // LDS / packed-weight row pitch in bytes (64 B of data + 16 B pad)
+constexpr int ROWB = 80;   // halo row pitch in LDS (64 B of data + 16 B pad: conflict-free b128 reads at any tap offset)
+constexpr int WROWB = 64;  // weight row pitch, global (packed) and LDS: no padding -- the four 16-B columns of row r are
+                           // stored XOR-swizzled by (r >> 2) & 3, which makes the b128 fragment reads conflict-free too
+                           // and keeps the LDS-DMA traffic at exactly the useful bytes
 constexpr int PITCH = 24;  // halo row pitch in pixels
 
 struct Seg {
@@ -45,7 +48,7 @@ struct ConvArgs {
   Seg seg[4];
   int nseg;
   const float* affine; int affC;   // [B][affC][2]
-  const void* w;                   // packed [step][CoutPad][ROWB bytes]
+  const void* w;                   // packed [step][CoutPad][WROWB bytes]
   long long w_bytes;
   const float* bias; int bias_rows;
   const void* skip;
@@ -123,7 +126,7 @@ struct Geo {
   static constexpr int HH = TH + 2, HW = TW + 2;
   static constexpr int BN = WN * NT * 32;
   static constexpr int HALO_BYTES = HH * PITCH * ROWB;
-  static constexpr int W_BYTES = BN * ROWB;
+  static constexpr int W_BYTES = BN * WROWB;
   static constexpr int W_LDS = (W_BYTES + 1023) / 1024 * 1024;  // LDS size of one weight buffer (DMA granularity)
   // Weight slabs live in a ring of NWBUF LDS slots.  The large configurations process the 9 taps of a chunk as
   // (0,1)(2,3)(4,5)(6,7)(8) with ONE barrier per group (5 instead of 9 per chunk): the per-barrier cost (~800 cycles of
@@ -147,6 +150,7 @@ struct Geo {
   static constexpr int HITER = (HH * HW + PPP - 1) / PPP;
   static_assert(EP_PIX % PPASS == 0, "epilogue pass geometry");
   static_assert(HITER + HLAG <= 9, "halo slots must fit the 9-tap schedule");
+  static_assert(!PAIRS || HITER <= 3, "tap-pair schedule stores one halo slot before each of the barriers 3, 5, 7");
 };
 
 template <typename T, int WM, int WN, int MT, int NT>
@@ -230,12 +234,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     constexpr int NPIECE = G::W_LDS / 1024;
     constexpr int NW = G::NTH / 64;
     constexpr int PER_WAVE = G::DMA_PER_WAVE;
-    const char* src = reinterpret_cast<const char*>(p.w) + ((size_t)step * p.CoutPad + n0) * ROWB + (t & 63) * 16;
+    const char* src = reinterpret_cast<const char*>(p.w) + ((size_t)step * p.CoutPad + n0) * WROWB + (t & 63) * 16;
     char* dst = wbuf + buf * G::W_LDS;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
 #pragma unroll
     for (int k = 0; k < PER_WAVE; ++k) {
       const int pce = (wv + k * NW) % NPIECE;
+#ifdef FD_EXP_DMASAME   // experiment: every piece re-reads the first KiB of the buffer (cache-hot) -> isolates the memory-side cost
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(p.w) + (t & 63) * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + pce * 1024), 16, 0, 0);
+      continue;
+#endif
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pce * 1024),
                                        (__attribute__((address_space(3))) void*)(dst + pce * 1024), 16, 0, 0);
     }
@@ -252,9 +261,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     const int r = 4 * (pi >> 1) + (l31 >> 3), c = 8 * (pi & 1) + (l31 & 7);
     pbase[mi] = (r * PITCH + c) * ROWB + lh * 16;
   }
-  int wbase[NT];
+  int wbase[2][NT];  // [k-half][nj]: row = cout, 16-B column (2 * ks + lh) ^ swizzle(row)
 #pragma unroll
-  for (int nj = 0; nj < NT; ++nj) wbase[nj] = ((wn * NT + nj) * 32 + l31) * ROWB + lh * 16;
+  for (int nj = 0; nj < NT; ++nj) {
+    const int row = (wn * NT + nj) * 32 + l31, sw = (row >> 2) & 3;
+    wbase[0][nj] = row * WROWB + ((lh ^ sw) * 16);
+    wbase[1][nj] = row * WROWB + (((2 + lh) ^ sw) * 16);
+  }
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -292,40 +305,43 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #ifdef FD_TIMING
   unsigned long long tm_vm = 0, tm_bar = 0, tm_loop0 = 0, tm_n = 0;
 #endif
-  auto block_sync = [&](auto keep) {
-    constexpr int KEEP = decltype(keep)::value;
-    static_assert(KEEP >= 0 && KEEP <= 8, "vmcnt immediate");
+  // keep = number of this wave's vector-memory instructions that may stay in flight across the barrier.  Loads return
+  // in order, so `vmcnt(keep)` still guarantees that everything OLDER than the last `keep` instructions -- in particular
+  // the weight DMAs issued right after the previous barrier -- has landed; the halo loads issued since then (consumed
+  // HLAG taps later) keep flying instead of stalling the barrier on HBM latency.
+  auto block_sync = [&](int keep) {
 #ifdef FD_TIMING
     const unsigned long long t_a = __builtin_amdgcn_s_memtime();
 #endif
-    if constexpr (KEEP == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (KEEP == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if constexpr (KEEP == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (KEEP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (KEEP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (KEEP == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if constexpr (KEEP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (KEEP == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#ifdef FD_NO_VMKEEP
+    keep = 0;
+#endif
+    switch (keep) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    }
 #ifdef FD_TIMING
     const unsigned long long t_b = __builtin_amdgcn_s_memtime();
 #endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef FD_EXP_NOBARRIER
     __builtin_amdgcn_s_barrier();
+#endif
     asm volatile("" ::: "memory");
 #ifdef FD_TIMING
     const unsigned long long t_c = __builtin_amdgcn_s_memtime();
     tm_vm += t_b - t_a; tm_bar += t_c - t_b; ++tm_n;
 #endif
   };
-  using K0 = std::integral_constant<int, 0>;
 
   u32x4 wfA[NT], pfA[MT], wfB[NT], pfB[MT];
-  auto read_frags = [&](u32x4 (&wf)[NT], u32x4 (&pf)[MT], const char* hb, const char* wb, int off) {
+  auto read_frags = [&](u32x4 (&wf)[NT], u32x4 (&pf)[MT], const char* hb, const char* wb, int off, int ks) {
 #pragma unroll
-    for (int nj = 0; nj < NT; ++nj) wf[nj] = *reinterpret_cast<const u32x4*>(wb + wbase[nj]);
+    for (int nj = 0; nj < NT; ++nj) wf[nj] = *reinterpret_cast<const u32x4*>(wb + wbase[ks][nj]);
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi) pf[mi] = *reinterpret_cast<const u32x4*>(hb + pbase[mi] + off);
+    for (int mi = 0; mi < MT; ++mi) pf[mi] = *reinterpret_cast<const u32x4*>(hb + pbase[mi] + off + 32 * ks);
   };
   // All MFMAs of one k-half.  The caller has already issued (in program order) the non-MFMA work of the phase; the
   // instruction-group hints ask the scheduler to spread that work BETWEEN the MFMAs (a few instructions per gap run under
@@ -363,6 +379,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const int last_step = nsteps - 1;
   auto slot_of = [&](int i) { return wbuf + (i % G::NWBUF) * G::W_LDS; };
   auto fetch_slabs = [&](int n) {
+#ifdef FD_EXP_NODMA
+    if (fetch >= G::NWBUF) { fetch += n; return; }
+#endif
     for (int k = 0; k < n; ++k) { dma_w(fetch <= last_step ? fetch : last_step, fetch % G::NWBUF); ++fetch; }
   };
   next_chunk(0, 0);
@@ -371,8 +390,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   fetch_slabs(G::NWBUF);
 #pragma unroll
   for (int i = 0; i < G::HITER; ++i) store_halo_slot(i, 0);
-  block_sync(K0{});
-  read_frags(wfA, pfA, hbuf, wbuf, n9 > 0 ? 0 : CENTER);  // (the k-half ks = 1 is addressed by passing hb + 32 / wb + 32)
+  block_sync(0);
+  read_frags(wfA, pfA, hbuf, wbuf, n9 > 0 ? 0 : CENTER, 0);  // (the k-half ks = 1 is addressed by passing hb + 32 / wb + 32)
 
   int cs = 0, cch = 0;  // (segment, chunk) cursor
   auto advance = [&](int& s_, int& ch_) {
@@ -398,19 +417,43 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       const char* wb = slot_of(step);
       const char* wbn = slot_of(step + 1);
       // ---- phase A: [store halo slot] | read frags(s, ks=1) || MFMA(s, ks=0)
-      if (tap >= HLAG && tap - HLAG < G::HITER) store_halo_slot(tap - HLAG, hcur ^ 1);
-      read_frags(wfB, pfB, hb + 32, wb + 32, imm);
+      // Every wait of this loop is a full drain (the barriers' explicit vmcnt(0), and hipcc's own wait before the first
+      // use of a halo register is a vmcnt(0) as well as soon as LDS-DMAs are in flight), so the schedule keeps the
+      // YOUNGEST vector-memory instruction at every wait point about two taps old: with tap pairs all halo loads are
+      // issued together with the weight DMAs right after barrier 1 and converted / stored one slot at a time in the
+      // phase that ends with barriers 3, 5 and 7 (published long before the first read in phase B of tap 8).
+#ifdef FD_EXP_NOHALO
+      if (false) {}
+      else
+#endif
+      if constexpr (G::PAIRS) {
+        if (tap == 3 || tap == 5 || tap == 7) store_halo_slot((tap - 3) / 2, hcur ^ 1);
+      } else {
+        if (tap >= HLAG && tap - HLAG < G::HITER) store_halo_slot(tap - HLAG, hcur ^ 1);
+      }
+      read_frags(wfB, pfB, hb, wb, imm, 1);
       mma_all(wfA, pfA);
       if (barrier_here) {
         // everything issued after the previous barrier has landed and is published; all reads of the finished group's
         // slabs are complete, so their ring slots are refilled with the next slabs in K order
-        block_sync(K0{});
+        block_sync(0);
         fetch_slabs(!G::PAIRS ? 1 : (tap == 8 ? 1 : 2));
       }
       // ---- phase B: [load halo slot] | read frags(s+1, ks=0) || MFMA(s, ks=1)
-      if (tap < G::HITER) load_halo_slot(tap);
-      if (tap < 8) read_frags(wfA, pfA, hb, wbn, imm_next);
-      else read_frags(wfA, pfA, hbn, wbn, first_off_next);
+#ifdef FD_EXP_NOHALO
+      if (false) {}
+      else
+#endif
+      if constexpr (G::PAIRS) {
+        if (tap == 1) {
+#pragma unroll
+          for (int k = 0; k < G::HITER; ++k) load_halo_slot(k);
+        }
+      } else {
+        if (tap < G::HITER) load_halo_slot(tap);
+      }
+      if (tap < 8) read_frags(wfA, pfA, hb, wbn, imm_next, 0);
+      else read_frags(wfA, pfA, hbn, wbn, first_off_next, 0);
       mma_all(wfB, pfB);
       ++step;
     }
@@ -426,13 +469,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     // the next 1-tap chunk's halo: loaded and published within this step
 #pragma unroll
     for (int k = 0; k < G::HITER; ++k) load_halo_slot(k);
-    read_frags(wfB, pfB, hb + 32, wb + 32, CENTER);
+    read_frags(wfB, pfB, hb, wb, CENTER, 1);
     mma_all(wfA, pfA);
 #pragma unroll
     for (int k = 0; k < G::HITER; ++k) store_halo_slot(k, hcur ^ 1);
-    block_sync(K0{});
+    block_sync(0);
     fetch_slabs(1);
-    read_frags(wfA, pfA, hbn, wbn, CENTER);
+    read_frags(wfA, pfA, hbn, wbn, CENTER, 0);
     mma_all(wfB, pfB);
     ++step; hcur ^= 1;
   }
@@ -590,31 +633,33 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #endif
 }
 
-// ---- weight packing: [Cout][Cin][k][k] f32 -> [step][CoutPad][ROWB bytes] ------------------------------------------
-// steps enumerate (concat segment, 64-byte channel chunk, tap); the last 16 bytes of every row are padding.
+// ---- weight packing: [Cout][Cin][k][k] f32 -> [step][CoutPad][WROWB bytes] -----------------------------------------
+// steps enumerate (concat segment, 64-byte channel chunk, tap); inside a row the four 16-byte columns are XOR-swizzled by
+// (cout >> 2) & 3 (the LDS image of a slab is a plain byte copy of this layout, see WROWB).
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, char* __restrict__ dst, int Cout, int CoutPad, int C0, int C1,
                                     int taps, long long step0) {
-  constexpr int CK = 64 / sizeof(T);
-  constexpr int RE = ROWB / sizeof(T);  // elements per padded row
+  constexpr int CK = 64 / sizeof(T);    // channels per row
+  constexpr int EPC = 16 / sizeof(T);   // elements per 16-byte column
   const int nchunk0 = (C0 + CK - 1) / CK, nchunks = nchunk0 + (C1 + CK - 1) / CK;
-  const long long total = (long long)nchunks * taps * CoutPad * RE;
+  const long long total = (long long)nchunks * taps * CoutPad * CK;
   const int Cin = C0 + C1;
-  T* d = reinterpret_cast<T*>(dst + step0 * CoutPad * ROWB);
+  T* d = reinterpret_cast<T*>(dst + step0 * CoutPad * WROWB);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(i % RE);
-    long long r = i / RE;
+    const int k = (int)(i % CK);
+    long long r = i / CK;
     const int n = (int)(r % CoutPad); r /= CoutPad;
     const int tap = (int)(r % taps);
     const int chunk = (int)(r / taps);
     float v = 0.f;
-    if (k < CK && n < Cout) {
+    if (n < Cout) {
       int c;
       if (chunk < nchunk0) { c = chunk * CK + k; if (c >= C0) c = -1; }
       else { c = (chunk - nchunk0) * CK + k; c = (c < C1) ? C0 + c : -1; }
       if (c >= 0) v = w[((size_t)n * Cin + c) * taps + tap];
     }
-    d[i] = (T)v;
+    const int col = (k / EPC) ^ ((n >> 2) & 3);
+    d[(i - k) + col * EPC + (k % EPC)] = (T)v;
   }
 }
 
@@ -678,7 +723,7 @@ extern "C" int fd_conv_stats_tiles(int H, int W) { return fd_cdiv(H, 16) * fd_cd
 extern "C" long long fd_conv_packed_bytes(int Cout, int C0, int C1, int ksize, int S0, int S1, int wdtype) {
   const int CK = wdtype == FD_BF16 ? 32 : 16;
   // + 1 KiB slack: the DMA of a partial last 1-KiB piece (BN = 32 configuration) over-reads past the final slab
-  return (long long)(n_steps(C0, C1, ksize * ksize, CK) + n_steps(S0, S1, 1, CK)) * cout_pad(Cout) * ROWB + 1024;
+  return (long long)(n_steps(C0, C1, ksize * ksize, CK) + n_steps(S0, S1, 1, CK)) * cout_pad(Cout) * WROWB + 1024;
 }
 
 extern "C" int fd_conv_pack_weights(const float* w, const float* w_sc, void* packed, int Cout, int C0, int C1, int ksize, int S0,
@@ -690,7 +735,7 @@ extern "C" int fd_conv_pack_weights(const float* w, const float* w_sc, void* pac
   const int taps = ksize * ksize, CoutPad = cout_pad(Cout), CK = wdtype == FD_BF16 ? 32 : 16;
   hipStream_t st = fd_stream(stream);
   auto run = [&](const float* src, int c0, int c1, int tp, long long step0) {
-    const long long total = (long long)n_steps(c0, c1, tp, CK) * CoutPad * (ROWB / (wdtype == FD_BF16 ? 2 : 4));
+    const long long total = (long long)n_steps(c0, c1, tp, CK) * CoutPad * CK;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     if (wdtype == FD_BF16)
       hipLaunchKernelGGL(pack_weights_kernel<bf16>, dim3(blocks), dim3(256), 0, st, src, (char*)packed, Cout, CoutPad, c0, c1, tp, step0);

@@ -90,8 +90,9 @@ int fd_gn_finalize(const float* part0, int tiles0, int stride0, int C0, const fl
                    const float* gamma, const float* beta, float* affine, int B, int groups, long long hw, float eps,
                    void* stream);
 
-/* Packs PyTorch conv weights [Cout][Cin][k][k] float32 (device) into the MFMA layout [step][CoutPad][80 B]
- * (bf16: 32 channels, f32: 16 channels + 16 B pad per row; step = (concat segment, channel chunk, tap)).  Input channels
+/* Packs PyTorch conv weights [Cout][Cin][k][k] float32 (device) into the MFMA layout [step][CoutPad][64 B]
+ * (bf16: 32 channels, f32: 16 channels per row, the four 16-byte columns XOR-swizzled by (cout >> 2) & 3;
+ * step = (concat segment, channel chunk, tap)).  Input channels
  * are split at C0 into two chunk-padded segments (virtual concat).  `w_sc` (optional, [Cout][S0+S1][1][1]) is the
  * 1x1 shortcut conv of a ResnetBlock (Conv_2, layerspp.py:244-245) whose K steps are appended so that one launch
  * computes Conv_1(h) + Conv_2(x). */
