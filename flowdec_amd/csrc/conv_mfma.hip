@@ -217,7 +217,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     nc = nchan_ok ? c : 0;
     naff = sg.aff_off >= 0 ? (sg.aff_off + nc) * 8 : -1;  // byte offset of this slot's (a,d) pairs in the LDS table
   };
-  auto load_halo_slot = [&](int i) { hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(nsrd, (pixl[i] * nC + nc) * (int)sizeof(T), 0, 0); };
+#ifndef FD_HALO_AUX
+#define FD_HALO_AUX 0
+#endif
+  auto load_halo_slot = [&](int i) { hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(nsrd, (pixl[i] * nC + nc) * (int)sizeof(T), 0, FD_HALO_AUX); };
   auto store_halo_slot = [&](int i, int buf) {
     u32x4 v = hreg[i];
     if (naff >= 0) v = transform_slot<T, EPS>(v, afftab + naff);
@@ -582,6 +585,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         }
 #ifdef FD_EXP_NOSTORE
         if (v[0] == 1234.567f)
+#endif
+#ifdef FD_NT_STORE
+        if constexpr (sizeof(T) == 2) {
+          bf16x8 tv;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) tv[j] = (bf16)v[j];
+          __builtin_nontemporal_store(__builtin_bit_cast(u32x4, tv), reinterpret_cast<u32x4*>(out + o));
+        } else
 #endif
         fd_store_vec<T, 8>(out + o, v);
       } else {  // 4 valid channels (pyramid heads: Cout = 4)

@@ -19,6 +19,7 @@ struct fd_edge_args {
   const void* base = nullptr;  // output_update
   const void* kold = nullptr;
   void* ksave = nullptr;
+  float* stats = nullptr;      // combine: [B][fd_combine_tiles][Cout][2] GroupNorm partials of the output
   float coef = 1.f;
   const void* z = nullptr;     // score update: dst = cb*base + cy*y + coef*v + cz*z
   float cb = 1.f, cy = 0.f, cz = 0.f;
@@ -34,6 +35,7 @@ int fd_temb_bias_batched(const fd_temb_job* jobs_dev, int njobs, const float* te
 int fd_edge_op(int which, const fd_edge_args& a, int dtype, hipStream_t st);
 int fd_init_state(const float* Y, const float* noise, const double* sigma_dev, int sigma_n, float sigma_fac, float* x0, int B,
                   int F, int T, hipStream_t st);
+int fd_combine_tiles(int H, int W);
 int fd_caxpy(const float* a, const float* q, float cq, float* dst, long long n, hipStream_t st);
 // conv_mfma.hip
 int fd_conv_init_attributes();

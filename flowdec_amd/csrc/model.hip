@@ -364,8 +364,10 @@ struct Fwd {
         pyr_in = p2;
         const Mod& md = mods[mi++];
         Tens hc = talloc(md.cout, hd.H, hd.W);
+        hc.tiles = fd_combine_tiles(hd.H, hd.W); hc.stride = md.cout;     // the combine kernel emits the GroupNorm partials of hc
+        hc.sums = arena.alloc(sizeof(float) * 2 * (size_t)B * hc.tiles * hc.stride);
         if (!dry) { fd_edge_args a; a.x = ptr(pyr_in.off); a.y = ptr(hd.off); a.w = md.w_f32; a.bias = md.b_f32; a.out = ptr(hc.off);
-                    a.B = B; a.H = hd.H; a.W = hd.W; a.Cout = md.cout; FD_TRY(fd_edge_op(2, a, dt, st)); }
+                    a.stats = (float*)ptr(hc.sums); a.B = B; a.H = hd.H; a.W = hd.W; a.Cout = md.cout; FD_TRY(fd_edge_op(2, a, dt, st)); }
         tfree(hd);
         hs.push_back(hc);
       }
