@@ -61,11 +61,13 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   const int a0 = c_lo < C0 ? c_lo : C0, a1 = (c_lo + cpg) < C0 ? (c_lo + cpg) : C0;          // [a0, a1) in tensor 0
   const int b0 = (c_lo > C0 ? c_lo : C0) - C0, b1 = ((c_lo + cpg) > C0 ? (c_lo + cpg) : C0) - C0;  // [b0, b1) in tensor 1
   const int n0 = a1 - a0, n1 = b1 - b0;
+#pragma unroll 8   // independent loads in flight: the loop is latency-, not bandwidth-bound
   for (int i = threadIdx.x; i < n0 * tiles0; i += 256) {
     const int tl = i / n0, c = a0 + i % n0;
     const float2 v = *reinterpret_cast<const float2*>(p0 + (((size_t)b * tiles0 + tl) * stride0 + c) * 2);
     s += v.x; ss += v.y;
   }
+#pragma unroll 8
   for (int i = threadIdx.x; i < n1 * tiles1; i += 256) {
     const int tl = i / n1, c = b0 + i % n1;
     const float2 v = *reinterpret_cast<const float2*>(p1 + (((size_t)b * tiles1 + tl) * stride1 + c) * 2);
