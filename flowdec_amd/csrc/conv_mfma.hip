@@ -163,6 +163,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   char* const wbuf = smem + 2 * G::HALO_BYTES;
   char* const afftab = wbuf + G::NWBUF * G::W_LDS;
 
+#ifdef FD_TIMING2   // light phase timing (3 timestamps per wave, no waits added inside the loop)
+  const unsigned long long t2_entry = __builtin_amdgcn_s_memtime();
+#endif
   // ---- tile decode with XCD-aware remap: consecutive logical tiles share an XCD's L2 ------------------------
   const int bid = blockIdx.x, nblk = gridDim.x;
   int lid;
@@ -288,11 +291,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   //   phase A:  [store halo slot regs->LDS] | read frags(s, ks=1) || MFMA(s, ks=0)
   //   barrier   (w(s+1) DMA landed, halo slots published, all reads of w(s) done)
   //   phase B:  DMA w(s+2) -> buffer of w(s) | [load halo slot global->regs] | read frags(s+1, ks=0) || MFMA(s, ks=1)
-  if (p.affine) {  // stage the affine table of image b: [affC] x (a, d)
-    const float* ap = p.affine + (size_t)b * p.affC * 2;
-    for (int i = t; i < p.affC / 2; i += G::NTH) *reinterpret_cast<f32x4*>(afftab + i * 16) = *reinterpret_cast<const f32x4*>(ap + i * 4);
-    __syncthreads();
-  }
   int n9 = 0, n1 = 0;
   for (int s = 0; s < p.nseg; ++s) {
     const int nch = (p.seg[s].C + CK - 1) / CK;
@@ -387,13 +385,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #endif
     for (int k = 0; k < n; ++k) { dma_w(fetch <= last_step ? fetch : last_step, fetch % G::NWBUF); ++fetch; }
   };
+  // Prologue: all global traffic of the first step is issued at once (first halo, weight ring, affine table) so that the
+  // block pays ONE memory round trip before its first MFMA; the affine table (needed by the halo transform only) is
+  // staged while the halo loads and the DMAs are in flight.
   next_chunk(0, 0);
 #pragma unroll
   for (int i = 0; i < G::HITER; ++i) load_halo_slot(i);
   fetch_slabs(G::NWBUF);
+  if (p.affine) {  // affine table of image b: [affC] x (a, d)
+    const float* ap = p.affine + (size_t)b * p.affC * 2;
+    for (int i = t; i < p.affC / 2; i += G::NTH) *reinterpret_cast<f32x4*>(afftab + i * 16) = *reinterpret_cast<const f32x4*>(ap + i * 4);
+    __syncthreads();
+  }
 #pragma unroll
   for (int i = 0; i < G::HITER; ++i) store_halo_slot(i, 0);
   block_sync(0);
+#ifdef FD_TIMING2
+  const unsigned long long t2_first = __builtin_amdgcn_s_memtime();
+#endif
   read_frags(wfA, pfA, hbuf, wbuf, n9 > 0 ? 0 : CENTER, 0);  // (the k-half ks = 1 is addressed by passing hb + 32 / wb + 32)
 
   int cs = 0, cch = 0;  // (segment, chunk) cursor
@@ -488,6 +497,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const unsigned long long tm_loop1 = __builtin_amdgcn_s_memtime();
 #endif
 
+#ifdef FD_TIMING2
+  const unsigned long long t2_loop = __builtin_amdgcn_s_memtime();
+#endif
 #ifdef FD_EXP_NOEPI   // experiment: bound what a free epilogue would give (keeps the accumulators alive)
   {
     float sacc = 0.f;
@@ -631,6 +643,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         p.stats[(((size_t)b * p.tiles_h * p.tiles_w + tile) * p.CoutPad + n0) * 2 + o] = a;
     }
   }
+#ifdef FD_TIMING2
+  if (p.dbg && (t & 63) == 0) {
+    const unsigned long long t2_end = __builtin_amdgcn_s_memtime();
+    atomicAdd(&p.dbg[0], t2_first - t2_entry);   // prologue: tile decode, affine table, first halo + weight ring fill
+    atomicAdd(&p.dbg[1], t2_loop - t2_first);    // main loop
+    atomicAdd(&p.dbg[2], t2_end - t2_loop);      // epilogue
+    atomicAdd(&p.dbg[5], 1ull);
+  }
+#endif
 #ifdef FD_TIMING
   if (p.dbg && (t & 63) == 0) {
     const unsigned long long tm_end = __builtin_amdgcn_s_memtime();
