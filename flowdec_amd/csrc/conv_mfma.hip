@@ -223,7 +223,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #ifndef FD_HALO_AUX
 #define FD_HALO_AUX 0
 #endif
-  auto load_halo_slot = [&](int i) { hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(nsrd, (pixl[i] * nC + nc) * (int)sizeof(T), 0, FD_HALO_AUX); };
+  int npix_on = 1;   // 0: the prefetch target is unused (last chunk of the K loop) -> every lane re-reads pixel 0 (one cache line, no HBM traffic)
+  auto load_halo_slot = [&](int i) { hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(nsrd, (pixl[i] * npix_on * nC + nc) * (int)sizeof(T), 0, FD_HALO_AUX); };
   auto store_halo_slot = [&](int i, int buf) {
     u32x4 v = hreg[i];
     if (naff >= 0) v = transform_slot<T, EPS>(v, afftab + naff);
@@ -417,7 +418,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // last steps) is not branched around but redirected to harmless targets (re-load of the last slab / the current chunk).
   for (int i = 0; i < n9; ++i) {
     const bool last_chunk = (i == n9 - 1) && n1 == 0;
-    if (!last_chunk) { advance(cs, cch); next_chunk(cs, cch); }   // else: keep prefetching the current chunk (unused)
+    if (!last_chunk) { advance(cs, cch); next_chunk(cs, cch); }   // else: the prefetch of this chunk is unused
+    else npix_on = 0;
     const char* hb = hbuf + hcur * G::HALO_BYTES;
     const char* hbn = hbuf + (hcur ^ 1) * G::HALO_BYTES;
     const int first_off_next = (i == n9 - 1) ? CENTER : 0;
@@ -478,6 +480,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     const char* wb = slot_of(step);
     const char* wbn = slot_of(step + 1);
     if (m1) { advance(cs, cch); next_chunk(cs, cch); }
+    else npix_on = 0;
     // the next 1-tap chunk's halo: loaded and published within this step
 #pragma unroll
     for (int k = 0; k < G::HITER; ++k) load_halo_slot(k);
