@@ -56,7 +56,7 @@ struct ConvArgs {
   void* out;
   int Cout, CoutPad;
   float* stats;                    // [B][tiles_h*tiles_w][CoutPad][2] or null
-  unsigned long long* dbg;         // FD_TIMING builds only
+  unsigned long long* dbg;         // FD_TIMING2 builds only
   int B, H, W;
   int tiles_h, tiles_w, tiles_n;
 };
@@ -304,38 +304,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // global_load_lds across the loop back-edge (it emitted a bare lgkmcnt(0) before the first barrier of the unrolled
   // body), which let other waves read a weight piece that had not landed.  All vector-memory traffic is issued right
   // after a barrier and is needed (landed + published) at the next one.
-#ifdef FD_TIMING
-  unsigned long long tm_vm = 0, tm_bar = 0, tm_loop0 = 0, tm_n = 0;
-#endif
-  // keep = number of this wave's vector-memory instructions that may stay in flight across the barrier.  Loads return
-  // in order, so `vmcnt(keep)` still guarantees that everything OLDER than the last `keep` instructions -- in particular
-  // the weight DMAs issued right after the previous barrier -- has landed; the halo loads issued since then (consumed
-  // HLAG taps later) keep flying instead of stalling the barrier on HBM latency.
-  auto block_sync = [&](int keep) {
-#ifdef FD_TIMING
-    const unsigned long long t_a = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef FD_NO_VMKEEP
-    keep = 0;
-#endif
-    switch (keep) {
-      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    }
-#ifdef FD_TIMING
-    const unsigned long long t_b = __builtin_amdgcn_s_memtime();
-#endif
+  auto block_sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifndef FD_EXP_NOBARRIER
     __builtin_amdgcn_s_barrier();
 #endif
     asm volatile("" ::: "memory");
-#ifdef FD_TIMING
-    const unsigned long long t_c = __builtin_amdgcn_s_memtime();
-    tm_vm += t_b - t_a; tm_bar += t_c - t_b; ++tm_n;
-#endif
   };
 
   u32x4 wfA[NT], pfA[MT], wfB[NT], pfB[MT];
@@ -373,9 +348,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #endif
   };
 
-#ifdef FD_TIMING
-  tm_loop0 = __builtin_amdgcn_s_memtime();
-#endif
   int step = 0, hcur = 0;   // step = running (chunk, tap) index = index of the weight slab in K order
   int fetch = 0;            // next slab to DMA; slab i lives in ring slot i % NWBUF
   const int last_step = nsteps - 1;
@@ -400,7 +372,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   }
 #pragma unroll
   for (int i = 0; i < G::HITER; ++i) store_halo_slot(i, 0);
-  block_sync(0);
+  block_sync();
 #ifdef FD_TIMING2
   const unsigned long long t2_first = __builtin_amdgcn_s_memtime();
 #endif
@@ -450,7 +422,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       if (barrier_here) {
         // everything issued after the previous barrier has landed and is published; all reads of the finished group's
         // slabs are complete, so their ring slots are refilled with the next slabs in K order
-        block_sync(0);
+        block_sync();
         fetch_slabs(!G::PAIRS ? 1 : (tap == 8 ? 1 : 2));
       }
       // ---- phase B: [load halo slot] | read frags(s+1, ks=0) || MFMA(s, ks=1)
@@ -488,7 +460,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     mma_all(wfA, pfA);
 #pragma unroll
     for (int k = 0; k < G::HITER; ++k) store_halo_slot(k, hcur ^ 1);
-    block_sync(0);
+    block_sync();
     fetch_slabs(1);
     read_frags(wfA, pfA, hbn, wbn, CENTER, 0);
     mma_all(wfB, pfB);
@@ -496,9 +468,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // all fragment reads / DMA done before the epilogue reuses the LDS
-#ifdef FD_TIMING
-  const unsigned long long tm_loop1 = __builtin_amdgcn_s_memtime();
-#endif
 
 #ifdef FD_TIMING2
   const unsigned long long t2_loop = __builtin_amdgcn_s_memtime();
@@ -655,17 +624,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     atomicAdd(&p.dbg[5], 1ull);
   }
 #endif
-#ifdef FD_TIMING
-  if (p.dbg && (t & 63) == 0) {
-    const unsigned long long tm_end = __builtin_amdgcn_s_memtime();
-    atomicAdd(&p.dbg[0], tm_loop1 - tm_loop0);   // main loop (incl. prologue staging)
-    atomicAdd(&p.dbg[1], tm_vm);                 // time in s_waitcnt vmcnt at barriers
-    atomicAdd(&p.dbg[2], tm_bar);                // lgkmcnt wait + barrier
-    atomicAdd(&p.dbg[3], tm_end - tm_loop1);     // epilogue
-    atomicAdd(&p.dbg[4], tm_n);                  // barriers
-    atomicAdd(&p.dbg[5], 1ull);                  // waves
-  }
-#endif
 }
 
 // ---- weight packing: [Cout][Cin][k][k] f32 -> [step][CoutPad][WROWB bytes] -----------------------------------------
@@ -703,7 +661,7 @@ inline int cout_pad(int Cout) { return Cout <= 32 ? 32 : (Cout <= 128 ? 128 : pa
 inline int n_steps(int C0, int C1, int taps, int CK) { return (fd_cdiv(C0, CK) + fd_cdiv(C1, CK)) * taps; }
 
 int g_variant = 0;  // tuning hook: 0 = auto, 1 = force the BN=128 config
-unsigned long long* g_dbg = nullptr;  // FD_TIMING builds: device buffer of 8 counters
+unsigned long long* g_dbg = nullptr;  // FD_TIMING2 builds: device buffer of 8 counters (fd_debug_buffer)
 
 template <typename T, int WM, int WN, int MT, int NT>
 int set_attr() {
