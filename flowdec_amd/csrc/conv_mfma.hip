@@ -12,11 +12,14 @@
 //   * weights are the MFMA "A" operand, so every lane ends up with 4 consecutive couts of one pixel;
 //   * K walks 64-byte channel chunks (32 bf16 / 16 f32 channels).  Per chunk the 18x18 halo tile is staged
 //     once in LDS and reused by the 9 taps as shifted windows (ds_read immediates, taps fully unrolled);
-//   * per (chunk, tap) step a BN x 64 B weight slab is staged; weights/halo are register-prefetched one
-//     step / one chunk ahead through buffer (SRD) loads, one barrier per step;
+//   * per (chunk, tap) step a BN x 64 B weight slab is needed; slabs stream through a ring of LDS slots by direct-to-LDS
+//     DMA (global_load_lds_dwordx4, no VGPR staging) and the 9 taps of a chunk run as the groups (0,1)(2,3)(4,5)(6,7)(8)
+//     with one barrier per group; the next chunk's halo is loaded to registers right after barrier 1 and converted /
+//     stored one slot per group;
 //   * the operand load applies silu(a*x+d) (GroupNorm folded to a per-(b,c) affine), zero padding after it;
-//   * LDS rows are padded to 80 B (5 x 16 B, coprime with the 16 slots of a 256 B bank row) and the halo
-//     pitch is 24 pixels (= 8 mod 16): every ds_read_b128 lane group hits 16 distinct slots, no swizzle;
+//   * halo rows are padded to 80 B (5 x 16 B, coprime with the 16 slots of a 256 B bank row) with a 24-pixel pitch, weight
+//     rows are 64 B with the 16-byte columns XOR-swizzled by (row >> 2) & 3: every ds_read_b128 lane group hits 16
+//     distinct slots;
 //   * epilogue: accumulators are transposed through LDS so that global traffic (skip read, output write) is
 //     16 B per lane and fully coalesced; bias / skip / scale are applied there, and per-channel sum / sum of
 //     squares of the f32 result are reduced per tile for the consumer GroupNorm (deterministic, no atomics).
