@@ -116,10 +116,6 @@ __device__ __forceinline__ u32x4 transform_slot(u32x4 raw, const char* ad) {
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 constexpr int AFF_BYTES = 512 * 8;  // per-(b,c) (a,d) pairs of up to 512 activated input channels, staged in LDS
-#ifndef FD_HLAG
-#define FD_HLAG 3
-#endif
-constexpr int HLAG = FD_HLAG;             // a halo slot loaded in phase B of tap i is transformed + stored in phase A of tap i + HLAG
 
 template <int WM, int WN, int MT, int NT>
 struct Geo {
@@ -131,13 +127,11 @@ struct Geo {
   static constexpr int HALO_BYTES = HH * PITCH * ROWB;
   static constexpr int W_BYTES = BN * WROWB;
   static constexpr int W_LDS = (W_BYTES + 1023) / 1024 * 1024;  // LDS size of one weight buffer (DMA granularity)
-  // Weight slabs live in a ring of NWBUF LDS slots.  The large configurations process the 9 taps of a chunk as
-  // (0,1)(2,3)(4,5)(6,7)(8) with ONE barrier per group (5 instead of 9 per chunk): the per-barrier cost (~800 cycles of
-  // drain + skew) is then amortised over 32 instead of 16 MFMAs per wave.  After each barrier the slots freed by the
-  // finished group are refilled by DMA with the next slabs in K order.  The small configuration keeps 2 slots and a
-  // barrier per tap so that two workgroups fit a CU.
-  static constexpr bool PAIRS = BN > 32;
-  static constexpr int NWBUF = PAIRS ? 4 : 2;
+  // Weight slabs live in a ring of NWBUF = 4 LDS slots and the 9 taps of a chunk are processed as the groups
+  // (0,1)(2,3)(4,5)(6,7)(8) with ONE barrier per group (5 instead of 9 per chunk): the per-barrier cost (drain + skew) is
+  // amortised over twice as many MFMAs per wave.  After each barrier the slots freed by the finished group are refilled by
+  // DMA with the next slabs in K order.
+  static constexpr int NWBUF = 4;
   static constexpr int MAIN_BYTES = 2 * HALO_BYTES + NWBUF * W_LDS + AFF_BYTES;
   // epilogue staging: one M-tile row of the block (WM * 32 pixels) x BN floats (+16 B pad per pixel)
   static constexpr int EP_PIX = WM * 32;
@@ -152,8 +146,8 @@ struct Geo {
   static constexpr int PPP = NTH / 4;            // rows covered per loader pass (4 slots per row)
   static constexpr int HITER = (HH * HW + PPP - 1) / PPP;
   static_assert(EP_PIX % PPASS == 0, "epilogue pass geometry");
-  static_assert(HITER + HLAG <= 9, "halo slots must fit the 9-tap schedule");
-  static_assert(!PAIRS || HITER <= 3, "tap-pair schedule stores one halo slot before each of the barriers 3, 5, 7");
+  static constexpr int HPG = (HITER + 2) / 3;    // tap-pair schedule: halo slots converted before each of the barriers 3, 5, 7
+  static_assert(HITER <= 6, "the halo is converted in three groups of at most two slots");
 };
 
 template <typename T, int WM, int WN, int MT, int NT>
@@ -402,23 +396,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     for (int tap = 0; tap < 9; ++tap) {
       const int imm = ((tap / 3) * PITCH + (tap % 3)) * ROWB;
       const int imm_next = (((tap + 1) / 3) * PITCH + ((tap + 1) % 3)) * ROWB;
-      const bool barrier_here = !G::PAIRS || (tap & 1) || tap == 8;   // last tap of its group
+      const bool barrier_here = (tap & 1) || tap == 8;   // last tap of its group
       const char* wb = slot_of(step);
       const char* wbn = slot_of(step + 1);
       // ---- phase A: [store halo slot] | read frags(s, ks=1) || MFMA(s, ks=0)
       // Every wait of this loop is a full drain (the barriers' explicit vmcnt(0), and hipcc's own wait before the first
       // use of a halo register is a vmcnt(0) as well as soon as LDS-DMAs are in flight), so the schedule keeps the
-      // YOUNGEST vector-memory instruction at every wait point about two taps old: with tap pairs all halo loads are
-      // issued together with the weight DMAs right after barrier 1 and converted / stored one slot at a time in the
-      // phase that ends with barriers 3, 5 and 7 (published long before the first read in phase B of tap 8).
+      // YOUNGEST vector-memory instruction at every wait point about two taps old: all halo loads are issued together
+      // with the weight DMAs right after barrier 1 and converted / stored one group of slots at a time in the phases
+      // that end with barriers 3, 5 and 7 (published long before the first read in phase B of tap 8).
 #ifdef FD_EXP_NOHALO
       if (false) {}
       else
 #endif
-      if constexpr (G::PAIRS) {
-        if (tap == 3 || tap == 5 || tap == 7) store_halo_slot((tap - 3) / 2, hcur ^ 1);
-      } else {
-        if (tap >= HLAG && tap - HLAG < G::HITER) store_halo_slot(tap - HLAG, hcur ^ 1);
+      if (tap == 3 || tap == 5 || tap == 7) {
+#pragma unroll
+        for (int k = 0; k < G::HPG; ++k)
+          if ((tap - 3) / 2 * G::HPG + k < G::HITER) store_halo_slot((tap - 3) / 2 * G::HPG + k, hcur ^ 1);
       }
       read_frags(wfB, pfB, hb, wb, imm, 1);
       mma_all(wfA, pfA);
@@ -426,20 +420,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         // everything issued after the previous barrier has landed and is published; all reads of the finished group's
         // slabs are complete, so their ring slots are refilled with the next slabs in K order
         block_sync();
-        fetch_slabs(!G::PAIRS ? 1 : (tap == 8 ? 1 : 2));
+        fetch_slabs(tap == 8 ? 1 : 2);
       }
       // ---- phase B: [load halo slot] | read frags(s+1, ks=0) || MFMA(s, ks=1)
 #ifdef FD_EXP_NOHALO
       if (false) {}
       else
 #endif
-      if constexpr (G::PAIRS) {
-        if (tap == 1) {
+      if (tap == 1) {
 #pragma unroll
-          for (int k = 0; k < G::HITER; ++k) load_halo_slot(k);
-        }
-      } else {
-        if (tap < G::HITER) load_halo_slot(tap);
+        for (int k = 0; k < G::HITER; ++k) load_halo_slot(k);
       }
       if (tap < 8) read_frags(wfA, pfA, hb, wbn, imm_next, 0);
       else read_frags(wfA, pfA, hbn, wbn, first_off_next, 0);
