@@ -161,3 +161,29 @@ def test_full_size_properties():
     e = rel_err(v0.cpu().numpy(), v[:1].cpu().numpy())
     report("full_size_batch_independence", e, 1e-6)
     assert e < 1e-6
+
+
+def test_enhance_ragged_batch_and_global_sigma_vs_oracle():
+    """Odd clip length (not a multiple of the hop, T = 33 -> T_pad = 64), an odd batch of 3, a silent clip (the
+    normalisation guard, util/other.py:77-80) and the scalar sigma_y of the *_globsigy presets -- against the oracle."""
+    import flowdec_amd
+    L, B, N = 12345, 3, 2
+    rng = np.random.default_rng(77)
+    y = (0.05 * rng.standard_normal((B, 1, L))).astype(np.float32)
+    y[1] = 0.0                                            # silence: normfac falls back to 1
+    sd = O.random_state_dict(seed=8, nf=8)
+    m = flowdec_amd.from_preset("flowdec_75m_globsigy", precision="fp32", nf=8)
+    res = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not res.unexpected_keys and float(m.sigma_y) == pytest.approx(0.66)
+    m = m.cuda()
+    Tp = O.padded_frames(O.num_frames(L))
+    assert O.num_frames(L) == 33 and Tp == 64
+    noise = ((rng.standard_normal((B, 1, 768, Tp)) + 1j * rng.standard_normal((B, 1, 768, Tp))) / np.sqrt(2)).astype(np.complex64)
+    out = m.enhance(torch.from_numpy(y), N=N, solver="midpoint", noise=torch.from_numpy(noise))
+    assert out.shape == (B, 1, L)
+    ref = O.enhance(O.NCSNppOracle(sd, nf=8), y, noise, 0.66, N=N, solver="midpoint")
+    check("enhance_ragged_globsigy[fp32]", out.numpy(), ref, TOL_WAVE["fp32"])
+    assert torch.isfinite(out).all()
+    # each clip alone gives the same waveform (ragged batches can be split freely)
+    one = m.enhance(torch.from_numpy(y[2:]), N=N, solver="midpoint", noise=torch.from_numpy(noise[2:]))
+    assert torch.equal(one, out[2:])
