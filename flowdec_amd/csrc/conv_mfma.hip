@@ -749,7 +749,8 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   FD_REQUIRE(B > 0 && H > 0 && W > 0, "fd_conv2d: bad shape");
   FD_REQUIRE(bias == nullptr || bias_rows == 1 || bias_rows == B, "fd_conv2d: bias_rows must be 1 or B");
   int cm = C0; if (C1 > cm) cm = C1; if (S0 > cm) cm = S0; if (S1 > cm) cm = S1; if (Cout > cm) cm = Cout;
-  FD_REQUIRE((long long)H * W * cm * 4 < (1ll << 31), "fd_conv2d: one image exceeds 2 GiB (32-bit buffer offsets)");
+  FD_REQUIRE((long long)H * W * cm * (dtype == FD_BF16 ? 2 : 4) < (1ll << 31),
+             "fd_conv2d: one image of %d x %d x %d elements exceeds 2 GiB (32-bit buffer offsets; ~43 s of audio in bf16, ~21 s in f32)", H, W, cm);
   FD_TRY(fd_conv_init_attributes());
   const int taps = ksize * ksize;
   ConvArgs a{};

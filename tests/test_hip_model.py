@@ -187,3 +187,22 @@ def test_enhance_ragged_batch_and_global_sigma_vs_oracle():
     # each clip alone gives the same waveform (ragged batches can be split freely)
     one = m.enhance(torch.from_numpy(y[2:]), N=N, solver="midpoint", noise=torch.from_numpy(noise[2:]))
     assert torch.equal(one, out[2:])
+
+
+def test_longest_cli_clip_full_width():
+    """The reference driver enhances files of up to 30 s (enhance.py:115): one 30 s clip through the full-width bf16 model
+    (T = 3751 frames -> T_pad = 3776; 1.5 GB per activation tensor, 32-bit offsets inside one image) stays finite and
+    agrees with the same audio processed as the first clip of a batch of two."""
+    m = make_model(64, 64, "bf16")
+    L = 30 * 48000
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    y = 0.1 * torch.randn(2, 1, L, device="cuda", generator=gen)
+    from flowdec_amd import _lib as L_
+    lib = L_.load()
+    Tp = lib.fd_padded_frames(lib.fd_num_frames(L, 384))
+    assert Tp == 3776
+    nz = torch.randn(2, 1, 768, Tp, dtype=torch.complex64, device="cuda", generator=gen)
+    one = m.enhance(y[:1], N=1, solver="euler", noise=nz[:1])
+    assert one.shape == (1, 1, L) and torch.isfinite(one).all() and float(one.abs().max()) > 0
+    two = m.enhance(y, N=1, solver="euler", noise=nz)
+    assert torch.equal(two[:1], one)
