@@ -154,3 +154,21 @@ def test_parity_metrics_match_reference():
     x = g["x0"]
     assert metrics.si_sdr(0.5 * x, x) > 100 and abs(metrics.si_sdr(x + 0.1 * g["x1"], x) - 20.0) < 0.5
     assert metrics.logspec_mse(x, x) == 0.0 and metrics.logspec_mse(2 * x, x) == pytest.approx((20 * np.log10(2)) ** 2, rel=1e-3)
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """include/flowdec_hip.h is valid C99 and the library is usable from a plain C host (dlopen + dlsym), the way a
+    cgo / JNI / C++ integration of the reference would bind it."""
+    import subprocess
+    from flowdec_amd import _lib
+    _lib.load()
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "abi_check")
+    inc = os.path.join(here, "..", "include")
+    hdr_only = tmp_path / "hdr.c"
+    hdr_only.write_text('#include "flowdec_hip.h"\nint main(void) { fd_model_config c; fd_score_config s; (void)c; (void)s; return 0; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-I", inc, str(hdr_only)], check=True)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", inc, os.path.join(here, "c", "abi_check.c"), "-o", exe, "-ldl"], check=True)
+    r = subprocess.run([exe, _lib.LIB_PATH], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "c abi ok" in r.stdout
