@@ -137,7 +137,7 @@ def main():
     result = {
         "metric": "48 kHz audio-seconds/sec (RTF) for FlowDec-75m @ 6 ODE steps",
         "value": audio_seconds / elapsed, "unit": "audio-seconds/second", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_nfe": 1e3 * elapsed / args.steps / nfe, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic (0.1*randn waveforms, seeded random-init weights of the FlowDec-75m architecture)",
         "config": {"workload": f"{args.preset} enhance(): batch={B} x {args.seconds:g} s clips @48 kHz per GPU, {args.N}-step {args.solver} "
                                f"(NFE {nfe}), T_pad={Tp} frames, inputs resident in HBM", "global_batch": world * B, "nfe": nfe,

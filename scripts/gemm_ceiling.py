@@ -15,3 +15,14 @@ for dt in (torch.bfloat16, torch.float32):
     run(8192, 8192, 8192, dt)
     run(1572864, 256, 2304, dt)
     run(1572864, 256, 4608, dt)
+
+# HBM: device-to-device copy of 4 GiB (read + write) and a pure write (fill)
+n = 1 << 30
+a = torch.empty(n, dtype=torch.float32, device="cuda"); b = torch.empty_like(a)
+for name, fn, bytes_ in (("copy (r+w)", lambda: b.copy_(a), 8 * n), ("fill (w)", lambda: a.fill_(1.0), 4 * n)):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(10): fn()
+    e1.record(); torch.cuda.synchronize()
+    print(f"HBM {name}: {bytes_ * 10 / e0.elapsed_time(e1) / 1e9:.2f} TB/s")
