@@ -581,6 +581,10 @@ int run_maybe_graph(fd_model* m, const GraphKey& key, bool use_graph, hipStream_
   if (!use_graph || m->profiling) return enqueue();
   auto it = m->graphs.find(key);
   if (it == m->graphs.end()) {
+    if (m->graphs.size() >= 32) {   // the key holds raw buffer pointers: bound the cache for callers that keep changing them
+      for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
+      m->graphs.clear();
+    }
     hipGraph_t graph = nullptr;
     FD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     const int rc = enqueue();
