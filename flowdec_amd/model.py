@@ -204,10 +204,14 @@ class NCSNpp(nn.Module):
         return h
 
     def workspace(self, key, nbytes, device):
-        buf = self._ws.get(key)
-        if buf is None or buf.numel() < nbytes:
+        """One scratch buffer per call kind, grown on demand and reused (a file-by-file driver sees many clip lengths;
+        keeping one buffer per (batch, length) would pin every size ever seen)."""
+        kind = key[0]
+        buf = self._ws.get(kind)
+        if buf is None or buf.numel() < nbytes or buf.device != torch.device(device):
+            self._ws.pop(kind, None)
             buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-            self._ws[key] = buf
+            self._ws[kind] = buf
         return buf
 
     # -- reference API -----------------------------------------------------------------------------
