@@ -150,7 +150,7 @@ struct Geo {
   static_assert(HITER <= 6, "the halo is converted in three groups of at most two slots");
 };
 
-template <typename T, int WM, int WN, int MT, int NT>
+template <typename T, int WM, int WN, int MT, int NT, bool SKIP>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) {
   using G = Geo<WM, WN, MT, NT>;
   constexpr int EPS = Math<T>::EPS;
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // MT rounds; in round mi every wave stages its acc[mi][*] (32 pixels x NT*32 couts, f32) to LDS as
   // [pixel (wm*32 + l31)][cout], then all threads sweep the WM*32 pixels with 8 couts (16/32 B) per lane.
   T* out = reinterpret_cast<T*>(p.out);
-  const T* skip = reinterpret_cast<const T*>(p.skip);
+  const T* skip = SKIP ? reinterpret_cast<const T*>(p.skip) : nullptr;   // residual input (compile-time: see the sweep below)
   const int oct = t % G::OCT, prow_e = t / G::OCT;
   const int n_e = n0 + oct * 8;
   const bool n_ok = n_e < p.Cout;
@@ -516,10 +516,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       const int gh = h0 + 4 * (pi >> 1) + ((pp & 31) >> 3), gw = w0 + 8 * (pi & 1) + (pp & 7);
       ovalid[ps] = n_ok && gh < H && gw < W;
       oaddr[ps] = ovalid[ps] ? (((size_t)b * H + gh) * W + gw) * p.Cout + n_e : (size_t)0;
-      if (skip && n_cnt == 8) {
-        const u32x4* sp = reinterpret_cast<const u32x4*>(skip + oaddr[ps]);
-        skraw[ps][0] = sp[0];
-        if constexpr (sizeof(T) == 4) skraw[ps][1] = sp[1];
+      if constexpr (SKIP) {
+        if (n_cnt == 8) {
+          const u32x4* sp = reinterpret_cast<const u32x4*>(skip + oaddr[ps]);
+          skraw[ps][0] = sp[0];
+          if constexpr (sizeof(T) == 4) skraw[ps][1] = sp[1];
+        } else if (ovalid[ps]) {   // 4 channels (pyramid heads): 8 / 16 bytes
+          if constexpr (sizeof(T) == 2) { const uint2 q2 = *reinterpret_cast<const uint2*>(skip + oaddr[ps]); skraw[ps][0] = u32x4{q2.x, q2.y, 0u, 0u}; }
+          else skraw[ps][0] = *reinterpret_cast<const u32x4*>(skip + oaddr[ps]);
+        }
       }
     }
     // (b) stage this wave's acc[mi][*] as [pixel][cout] f32
@@ -534,58 +539,64 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         }
     }
     __syncthreads();
-    // (c) sweep: 8 couts (16 / 32 B) per lane, fully coalesced
+    // (c) sweep: 8 couts (16 / 32 B) per lane, fully coalesced.  All passes of the round are computed into registers
+    // first and their stores are issued back to back afterwards: vmcnt counts loads AND stores, so any wait between two
+    // stores (hipcc puts a vmcnt(0) in front of the first use of a residual value) would drain the previous store at full
+    // memory latency.  For the same reason the residual input is a compile-time property of the kernel (SKIP): launches
+    // without it have no load, hence no wait, anywhere in the epilogue.
+    u32x4 packed[G::NPASS][sizeof(T) == 2 ? 1 : 2];
 #pragma unroll
     for (int ps = 0; ps < G::NPASS; ++ps) {
-      if (!ovalid[ps]) continue;
       const int pp = prow_e + ps * G::PPASS;
       const float* sp = reinterpret_cast<const float*>(stage + pp * G::EP_ROWB) + oct * 8;
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      const size_t o = oaddr[ps];
-      if (n_cnt == 8) {
-        if (skip) {
-          if constexpr (sizeof(T) == 2) {
-            const bf16x8 sk = __builtin_bit_cast(bf16x8, skraw[ps][0]);
+      if constexpr (SKIP) {
+        if constexpr (sizeof(T) == 2) {
+          const bf16x8 sk = __builtin_bit_cast(bf16x8, skraw[ps][0]);   // (the upper 4 lanes are zero in the 4-channel case)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += (float)sk[j];
-          } else {
-            const f32x4 s0 = __builtin_bit_cast(f32x4, skraw[ps][0]), s1 = __builtin_bit_cast(f32x4, skraw[ps][1]);
+          for (int j = 0; j < 8; ++j) v[j] += (float)sk[j];
+        } else {
+          const f32x4 s0 = __builtin_bit_cast(f32x4, skraw[ps][0]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] += s0[j]; v[4 + j] += s1[j]; }
+          for (int j = 0; j < 4; ++j) v[j] += s0[j];
+          if (n_cnt == 8) {
+            const f32x4 s1 = __builtin_bit_cast(f32x4, skraw[ps][1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 + j] += s1[j];
           }
         }
+      }
+      const float keep = ovalid[ps] ? 1.f : 0.f;   // pixels outside the image do not enter the statistics
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          v[j] = (v[j] + bv[j]) * p.scale;
-          ssum[j] += v[j]; ssq[j] = fmaf(v[j], v[j], ssq[j]);
-        }
+      for (int j = 0; j < 8; ++j) {
+        v[j] = (v[j] + bv[j]) * p.scale;
+        const float w = j < n_cnt ? v[j] * keep : 0.f;
+        ssum[j] += w; ssq[j] = fmaf(w, w, ssq[j]);
+      }
+      if constexpr (sizeof(T) == 2) {
+        bf16x8 tv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tv[j] = (bf16)v[j];
+        packed[ps][0] = __builtin_bit_cast(u32x4, tv);
+      } else {
+        packed[ps][0] = __builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]});
+        packed[ps][1] = __builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]});
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < G::NPASS; ++ps) {
+      if (!ovalid[ps]) continue;
+      T* op = out + oaddr[ps];
 #ifdef FD_EXP_NOSTORE
-        if (v[0] == 1234.567f)
+      if (packed[ps][0][0] == 0x12345678u)
 #endif
-#ifdef FD_NT_STORE
-        if constexpr (sizeof(T) == 2) {
-          bf16x8 tv;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) tv[j] = (bf16)v[j];
-          __builtin_nontemporal_store(__builtin_bit_cast(u32x4, tv), reinterpret_cast<u32x4*>(out + o));
-        } else
-#endif
-        fd_store_vec<T, 8>(out + o, v);
-      } else {  // 4 valid channels (pyramid heads: Cout = 4)
-        float w4[4] = {v[0], v[1], v[2], v[3]};
-        if (skip) {
-          float sk[4];
-          fd_load_vec<T, 4>(skip + o, sk);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) w4[j] += sk[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          w4[j] = (w4[j] + bv[j]) * p.scale;
-          ssum[j] += w4[j]; ssq[j] = fmaf(w4[j], w4[j], ssq[j]);
-        }
-        fd_store_vec<T, 4>(out + o, w4);
+      if (n_cnt == 8) {
+        *reinterpret_cast<u32x4*>(op) = packed[ps][0];
+        if constexpr (sizeof(T) == 4) *(reinterpret_cast<u32x4*>(op) + 1) = packed[ps][1];
+      } else {   // 4 valid channels (pyramid heads: Cout = 4)
+        if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(op) = uint2{packed[ps][0][0], packed[ps][0][1]};
+        else *reinterpret_cast<u32x4*>(op) = packed[ps][0];
       }
     }
   }
@@ -659,7 +670,9 @@ unsigned long long* g_dbg = nullptr;  // FD_TIMING2 builds: device buffer of 8 c
 template <typename T, int WM, int WN, int MT, int NT>
 int set_attr() {
   using G = Geo<WM, WN, MT, NT>;
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, WM, WN, MT, NT>),
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, WM, WN, MT, NT, false>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, WM, WN, MT, NT, true>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
   return FD_OK;
 }
@@ -672,7 +685,8 @@ int launch_conv(ConvArgs a, hipStream_t st) {
   a.tiles_n = fd_cdiv(a.Cout, G::BN);
   const long long nblk = (long long)a.B * a.tiles_h * a.tiles_w * a.tiles_n;
   FD_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
-  hipLaunchKernelGGL((conv_mfma_kernel<T, WM, WN, MT, NT>), dim3((unsigned)nblk), dim3(G::NTH), G::LDS_BYTES, st, a);
+  if (a.skip) hipLaunchKernelGGL((conv_mfma_kernel<T, WM, WN, MT, NT, true>), dim3((unsigned)nblk), dim3(G::NTH), G::LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((conv_mfma_kernel<T, WM, WN, MT, NT, false>), dim3((unsigned)nblk), dim3(G::NTH), G::LDS_BYTES, st, a);
   FD_LAUNCH_CHECK();
   return FD_OK;
 }
