@@ -140,7 +140,7 @@ struct Geo {
   static constexpr int OCT = BN / 8;             // 8-channel groups per pixel
   static constexpr int PPASS = NTH / OCT;        // pixels per epilogue pass
   static constexpr int NPASS = EP_PIX / PPASS;
-  static constexpr int ST_BYTES = PPASS * BN * 2 * 4;
+  static constexpr int ST_BYTES = PPASS * OCT * 80;   // statistics staging: 80-byte records (see the end of the kernel)
   static constexpr int LDS_BYTES = cmax(MAIN_BYTES, cmax(2 * EP_BYTES, ST_BYTES));   // epilogue staging is double-buffered
   static constexpr int DMA_PER_WAVE = (W_LDS / 1024 + NTH / 64 - 1) / (NTH / 64);  // DMA instructions per wave per slab
   static constexpr int PPP = NTH / 4;            // rows covered per loader pass (4 slots per row)
@@ -307,6 +307,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #ifndef FD_EXP_NOBARRIER
     __builtin_amdgcn_s_barrier();
 #endif
+    asm volatile("" ::: "memory");
+  };
+  // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence as well: it waits for vmcnt(0), i.e. for
+  // every global STORE issued so far to be acknowledged, which in the epilogue exposes a full memory round trip per
+  // staging round (the output stores of the previous round) for no reason -- nothing read here depends on them.
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
 
@@ -499,6 +507,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #pragma unroll
   for (int j = 0; j < 8; ++j) ssum[j] = ssq[j] = 0.f;
 
+#ifdef FD_TIMING2
+  unsigned long long t2_e1 = 0, t2_e2 = 0, t2_e3 = 0;
+#endif
   // MT rounds, staging double-buffered (one barrier per round: the writes of round r+1 go to the other buffer, and
   // every wave has finished reading round r-1 from it before it arrived at barrier r).  The skip values of a round are
   // prefetched into registers BEFORE the staging of that round so that their latency hides behind the LDS round trip.
@@ -538,7 +549,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
           *reinterpret_cast<f32x4*>(dst + (nj * 32 + 8 * qd) * 4) = v;
         }
     }
-    __syncthreads();
+    lds_barrier();
+#ifdef FD_TIMING2
+    if (mi == 0) t2_e1 = __builtin_amdgcn_s_memtime();
+#endif
     // (c) sweep: 8 couts (16 / 32 B) per lane, fully coalesced.  All passes of the round are computed into registers
     // first and their stores are issued back to back afterwards: vmcnt counts loads AND stores, so any wait between two
     // stores (hipcc puts a vmcnt(0) in front of the first use of a residual value) would drain the previous store at full
@@ -599,33 +613,44 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         else *reinterpret_cast<u32x4*>(op) = packed[ps][0];
       }
     }
+#ifdef FD_TIMING2
+    if (mi == 0) t2_e2 = __builtin_amdgcn_s_memtime();
+    if (mi == MT - 1) t2_e3 = __builtin_amdgcn_s_memtime();
+#endif
   }
-  __syncthreads();
+  lds_barrier();
 
   if (p.stats) {  // per-tile partial sums of the output, reduced over the PPASS threads that share an octet
-    float* stg = reinterpret_cast<float*>(smem);  // [PPASS][BN][2]
+    // staging [PPASS][OCT] records of {sum, sumsq} x 8 channels = 64 B, padded to 80 B so that the four 16-byte writes of
+    // the 8 lanes of a ds_write_b128 group land in distinct bank slots
+    constexpr int SREC = 80;
+    char* const stg = smem;
+    char* rec = stg + (prow_e * G::OCT + oct) * SREC;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      stg[((prow_e * G::BN) + oct * 8 + j) * 2] = ssum[j];
-      stg[((prow_e * G::BN) + oct * 8 + j) * 2 + 1] = ssq[j];
-    }
-    __syncthreads();
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(rec + 16 * j) = f32x4{ssum[2 * j], ssq[2 * j], ssum[2 * j + 1], ssq[2 * j + 1]};
+    lds_barrier();
     const int tile = th_i * p.tiles_w + tw_i;
-    for (int o = t; o < 2 * G::BN; o += G::NTH) {
+    for (int o = t; o < 2 * G::BN; o += G::NTH) {   // o = 2 * channel + which
+      const char* src = stg + (o >> 4) * SREC + (o & 15) * 4;
       float a = 0.f;
-#pragma unroll 4
-      for (int r = 0; r < G::PPASS; ++r) a += stg[r * G::BN * 2 + o];
+#pragma unroll
+      for (int r = 0; r < G::PPASS; ++r) a += *reinterpret_cast<const float*>(src + r * G::OCT * SREC);
       if (n0 + (o >> 1) < p.CoutPad)
         p.stats[(((size_t)b * p.tiles_h * p.tiles_w + tile) * p.CoutPad + n0) * 2 + o] = a;
     }
   }
 #ifdef FD_TIMING2
-  if (p.dbg && (t & 63) == 0) {
+  if (p.dbg && t == 0 && bid < 8192) {   // per-workgroup record, no atomics (they would perturb the epilogue being measured)
     const unsigned long long t2_end = __builtin_amdgcn_s_memtime();
-    atomicAdd(&p.dbg[0], t2_first - t2_entry);   // prologue: tile decode, affine table, first halo + weight ring fill
-    atomicAdd(&p.dbg[1], t2_loop - t2_first);    // main loop
-    atomicAdd(&p.dbg[2], t2_end - t2_loop);      // epilogue
-    atomicAdd(&p.dbg[5], 1ull);
+    unsigned long long* d = p.dbg + (size_t)bid * 8;
+    d[0] = t2_first - t2_entry;   // prologue: tile decode, first halo + weight ring fill, affine table
+    d[1] = t2_loop - t2_first;    // main loop
+    d[2] = t2_end - t2_loop;      // epilogue
+    d[3] = t2_e1 - t2_loop;       // epilogue: start -> barrier of round 0 (bias load, address math, first staging)
+    d[4] = t2_e2 - t2_e1;         // sweep of round 0
+    d[5] = t2_e3 - t2_e2;         // rounds 1..MT-1
+    d[6] = t2_end - t2_e3;        // final barrier + statistics
   }
 #endif
 }

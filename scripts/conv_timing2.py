@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from flowdec_amd import ops, _lib as L
 lib = L.load()
 lib.fd_debug_buffer.argtypes = [C.c_void_p]; lib.fd_debug_buffer.restype = C.c_int
-dbg = torch.zeros(8, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(8192 * 8, dtype=torch.int64, device="cuda")
 lib.fd_debug_buffer(C.c_void_p(dbg.data_ptr()))
 g = torch.Generator(device="cuda").manual_seed(0)
 dt = torch.bfloat16
@@ -19,10 +19,12 @@ for name, C0, C1, aff, skip in [("plain 256", 256, 0, 0, 0), ("cat aff 512", 256
     f(); torch.cuda.synchronize(); dbg.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); f(); e1.record(); torch.cuda.synchronize()
-    d = dbg.cpu().tolist(); nw = max(d[5], 1)
+    d = dbg.cpu().reshape(8192, 8).double()
+    nblk = min(8192, B * (H // 16) * (W // 16))
+    d = d[:nblk]
     ms = e0.elapsed_time(e1)
-    tot = (d[0] + d[1] + d[2]) / nw
-    blocks = B * (H // 16) * (W // 16)
-    # wall cycles per block slot: kernel time * clock / (blocks / 256 CUs)
-    print(f"{name:14s} {ms:.3f} ms | per wave: prologue {d[0]/nw:8.0f}  loop {d[1]/nw:9.0f}  epilogue {d[2]/nw:8.0f}  sum {tot:9.0f} ticks | "
-          f"kernel/rounds = {ms * 1e-3 / (blocks / 256) * 1e6:.2f} us per block slot")
+    pro, loop, epi = d[:, 0].mean().item(), d[:, 1].mean().item(), d[:, 2].mean().item()
+    tot = pro + loop + epi
+    e = [d[:, k].mean().item() for k in (3, 4, 5, 6)]
+    print(f"{name:14s} {ms:.3f} ms | per workgroup: prologue {pro:7.0f} ({100*pro/tot:4.1f}%)  loop {loop:8.0f} ({100*loop/tot:4.1f}%)  epilogue {epi:7.0f} ({100*epi/tot:4.1f}%) ticks;"
+          f" epilogue split: to-barrier0 {e[0]:.0f}, sweep0 {e[1]:.0f}, rounds1-3 {e[2]:.0f}, final+stats {e[3]:.0f}")
