@@ -72,6 +72,7 @@ SIGNATURES = {
     "fd_enhance": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "fd_score_num_draws": (c_int, [C.POINTER(FdScoreConfig)]),
     "fd_score_enhance": (c_int, [_P, _P, _P, C.POINTER(FdScoreConfig), _P, c_int, c_int, _P, c_size_t, c_int, _P]),
+    "fd_score_eval": (c_int, [_P, _P, _P, c_float, C.POINTER(FdScoreConfig), c_int, _P, c_int, c_int, _P, c_size_t, _P]),
     "fd_regression_enhance": (c_int, [_P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "fd_profile_enable": (c_int, [_P, c_int]),
     "fd_profile_read": (c_int, [_P, C.POINTER(C.c_double), C.POINTER(c_ll), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -876,6 +876,30 @@ extern "C" int fd_score_enhance(fd_model* m, const float* y, const float* noise,
                         });
 }
 
+// One evaluation of the score network combined into what the black-box ODE sampler of the reference needs
+// (sampling/__init__.py:75-146): the probability-flow drift rsde.sde(x, t, y)[0] (sdes.py:93-109) or the noise-free
+// reverse-diffusion predictor step used for the final denoising (predictors.py:61-71 with t = eps).
+extern "C" int fd_score_eval(fd_model* m, const float* x, const float* Y, float t, const fd_score_config* c, int mode, float* out, int B,
+                             int T_pad, void* ws, size_t ws_bytes, void* stream) {
+  FD_TRY(check_ready(m));
+  FD_REQUIRE(x && Y && c && out && ws, "fd_score_eval: null pointer");
+  FD_REQUIRE(mode >= FD_SCORE_DRIFT_PF && mode <= FD_SCORE_DENOISE, "fd_score_eval: unknown mode %d", mode);
+  FD_REQUIRE(c->sigma_min > 0.f && c->sigma_max > c->sigma_min && c->theta > 0.f, "fd_score_eval: bad OUVE parameters");
+  FD_REQUIRE(mode != FD_SCORE_DENOISE || c->N >= 1, "fd_score_eval: the denoising step needs N >= 1");
+  FD_TRY(check_shape(m, B, T_pad));
+  const size_t need = forward_ws_bytes(m, B, T_pad);
+  if (ws_bytes < need) return fd_set_error(FD_ENOMEM, "fd_score_eval: workspace %zu < required %zu bytes", ws_bytes, need);
+  const float std_t = ouve_std(*c, t), g = ouve_diffusion(*c, t);
+  OutSpec os; os.score = true; os.base = x; os.yv = Y; os.dst = out;
+  if (mode == FD_SCORE_DENOISE) {   // x_mean = x - (theta (y - x) dt - G^2 score), G = g sqrt(dt), score = -net / std
+    const float dt = 1.f / (float)c->N, G = g * sqrtf(dt);
+    os.cb = 1.f + c->theta * dt; os.cy = -c->theta * dt; os.coef = -(G * G) / std_t;
+  } else {                          // drift = theta (y - x) - g^2 score * (0.5 | 1)
+    os.cb = -c->theta; os.cy = c->theta; os.coef = (mode == FD_SCORE_DRIFT_PF ? 0.5f : 1.f) * g * g / std_t;
+  }
+  return forward_call(m, x, Y, nullptr, t, 1, os, B, T_pad, ws, ws_bytes, fd_stream(stream));
+}
+
 extern "C" int fd_regression_enhance(fd_model* m, const float* y, float* x_hat, int B, int L, void* ws, size_t ws_bytes, int use_graph,
                                      void* stream) {
   GraphKey key{}; key.kind = 4;

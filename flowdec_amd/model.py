@@ -581,9 +581,11 @@ class ScoreModel(_WaveModel):
     @torch.no_grad()
     def enhance(self, y, sampler_type="pc", predictor="reverse_diffusion", corrector="ald", N=30, corrector_steps=1, snr=0.5,
                 return_preprocess_info=False, denoise=True, noise=None, generator=None, use_graph: bool = True, **kwargs):
+        if sampler_type == "ode":
+            if return_preprocess_info:
+                raise NotImplementedError("flowdec_amd.ScoreModel.enhance: return_preprocess_info is only wired for FlowModel")
+            return self._enhance_ode(y, N=N, denoise=denoise, noise=noise, generator=generator, **kwargs)
         if sampler_type != "pc":
-            if sampler_type == "ode":
-                raise NotImplementedError("flowdec_amd.ScoreModel: sampler_type='ode' (scipy solve_ivp black box) is out of scope")
             raise ValueError(f"{sampler_type} is not a valid sampler type!")
         if predictor not in L.PREDICTORS:
             raise ValueError(f"unknown predictor {predictor!r}; supported: {sorted(L.PREDICTORS)}")
@@ -601,6 +603,58 @@ class ScoreModel(_WaveModel):
             L.check(lib.fd_score_enhance(h, L.ptr(io["y"]), L.ptr(torch.view_as_real(io["noise"])), C.byref(cfg), L.ptr(io["out"]), B, Lw,
                                          L.ptr(ws), ws.numel(), int(use_graph), L.stream()))
         return self._wave_call(y, n_draws, noise, generator, launch)
+
+
+    def _enhance_ode(self, y, N=None, denoise=True, noise=None, generator=None, rtol=1e-5, atol=1e-5, method="RK45", eps=None,
+                     return_nfe: bool = False, **ignored):
+        """sampler_type='ode' (sampling/__init__.py:75-146): the probability-flow ODE integrated by scipy.integrate.solve_ivp
+        on the host, exactly like the reference; every drift evaluation is one fd_score_eval (backbone + fused update) on
+        the GPU, the STFT / iSTFT run in libflowdec_hip.so.  Host-driven and slow by construction (the state crosses PCIe
+        twice per evaluation) -- it exists for API parity with ScoreModel.enhance."""
+        from scipy import integrate
+        from . import ops
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("flowdec_amd: move the model to the GPU first (`model.cuda()`)")
+        orig_device, squeeze_dims, y3 = y.device, 0, y
+        while y3.ndim < 3:
+            y3 = y3.unsqueeze(0); squeeze_dims += 1
+        if y3.ndim != 3 or y3.shape[1] != 1:
+            raise RuntimeError(f"enhance expects [L], [1, L] or [B, 1, L] waveforms (got {tuple(y.shape)})")
+        N = self.sde.N if N is None else int(N)
+        t_eps = float(self.t_eps if eps is None else eps)
+        lib = L.load()
+        h = self._sync_native()
+        cfg = self.feature_extractor._cfg()
+        B, Lw = y3.shape[0], y3.shape[-1]
+        sc = L.FdScoreConfig(self.sde.theta, self.sde.sigma_min, self.sde.sigma_max, t_eps, 0.0, N, 0, 1, 0, int(bool(denoise)))
+        with torch.cuda.device(dev):
+            Y, normfac, T = ops.stft_compress(y3.reshape(B, Lw).to(dev, torch.float32), normalize=True, **cfg)
+            Tp = Y.shape[-1]
+            if noise is None:
+                noise = torch.randn(Y.shape, dtype=torch.complex64, device=dev, generator=generator)
+            std1 = float(self.sde._std(torch.ones(1))[0])
+            # prior sample x_T = Y + std(1) * z (sdes.py:197-202), formed on the host where scipy keeps the state anyway
+            x0 = (Y.cpu().numpy() + noise.to("cpu", torch.complex64).reshape(Y.shape).numpy() * np.float32(std1)).astype(np.complex64)
+            ws = self.backbone.workspace(("fwd", B, Tp), lib.fd_model_workspace_bytes(h, B, Tp), dev)
+            xin, out = torch.empty_like(Y), torch.empty_like(Y)
+
+            def evaluate(x_host, t, mode):
+                xin.copy_(torch.from_numpy(np.ascontiguousarray(x_host.reshape(Y.shape).astype(np.complex64))))
+                L.check(lib.fd_score_eval(h, L.ptr(torch.view_as_real(xin)), L.ptr(torch.view_as_real(Y)), float(np.float32(t)), C.byref(sc), mode,
+                                          L.ptr(torch.view_as_real(out)), B, Tp, L.ptr(ws), ws.numel(), L.stream()))
+                return out.cpu().numpy().reshape(-1)
+
+            sol = integrate.solve_ivp(lambda t, xf: evaluate(xf, t, 0), (1.0, t_eps), x0.reshape(-1), rtol=rtol, atol=atol, method=method)
+            x = sol.y[:, -1]
+            if denoise:
+                x = evaluate(x, t_eps, 2)
+            X = torch.from_numpy(np.ascontiguousarray(x.reshape(Y.shape).astype(np.complex64))).to(dev)
+            x_hat = ops.decompress_istft(X, T, Lw, normfac, **cfg).reshape(B, 1, Lw)
+        for _ in range(squeeze_dims):
+            x_hat = x_hat.squeeze(0)
+        x_hat = x_hat.to(orig_device)
+        return (x_hat, int(sol.nfev)) if return_nfe else x_hat
 
 
 class RegressionModel(_WaveModel):

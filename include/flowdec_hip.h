@@ -214,6 +214,16 @@ int fd_score_num_draws(const fd_score_config* cfg);
  * the order of the reference's randn_like calls.  Workspace: fd_enhance_workspace_bytes(m, B, L). */
 int fd_score_enhance(fd_model* m, const float* y, const float* noise, const fd_score_config* cfg, float* x_hat, int B, int L,
                      void* ws, size_t ws_bytes, int use_graph, void* stream);
+/* One score-network evaluation in the form the black-box ODE sampler needs (sampling/__init__.py:75-146, which drives
+ * scipy.integrate.solve_ivp on the host): x, Y, out = complex64 [B][1][n_freq][T_pad]; workspace fd_model_workspace_bytes.
+ *   FD_SCORE_DRIFT_PF : out = theta (Y - x) - 0.5 g(t)^2 score(x, Y, t)     (probability-flow drift, sdes.py:93-109)
+ *   FD_SCORE_DRIFT    : out = theta (Y - x) -     g(t)^2 score(x, Y, t)     (reverse-SDE drift)
+ *   FD_SCORE_DENOISE  : out = mean of one reverse-diffusion predictor step at t (predictors.py:61-71), dt = 1 / cfg->N */
+#define FD_SCORE_DRIFT_PF 0
+#define FD_SCORE_DRIFT 1
+#define FD_SCORE_DENOISE 2
+int fd_score_eval(fd_model* m, const float* x, const float* Y, float t, const fd_score_config* cfg, int mode, float* out, int B,
+                  int T_pad, void* ws, size_t ws_bytes, void* stream);
 /* RegressionModel.enhance (model.py:566-578): x_hat = iSTFT(backbone(Y, Y, t = 0)). */
 int fd_regression_enhance(fd_model* m, const float* y, float* x_hat, int B, int L, void* ws, size_t ws_bytes, int use_graph,
                           void* stream);

@@ -736,3 +736,36 @@ def seeded_noises(seed: int, shape):
     rng = np.random.default_rng(seed)
     while True:
         yield ((rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) / np.sqrt(2.0)).astype(np.complex64)
+
+
+def score_ode_sample(net: NCSNppOracle, Y: np.ndarray, prior_noise: np.ndarray, sde: OUVE, N: int, t_eps=3e-2, rtol=1e-5, atol=1e-5,
+                     method="RK45", denoise=True):
+    """sampling/__init__.py:75-146: probability-flow ODE integrated by scipy.integrate.solve_ivp on the flattened complex64
+    state from t = 1 to t_eps, then one noise-free reverse-diffusion predictor step (dt = 1/N).  -> (X, nfe)"""
+    from scipy import integrate
+    c64 = np.complex64
+    score = lambda x, t: (-net.forward(x, Y, np.asarray([t], dtype=np.float32)) / sde.std(t)).astype(c64)
+    x0 = (Y + prior_noise * sde.std(1.0)).astype(c64)
+
+    def ode_func(t, xf):
+        x = xf.reshape(Y.shape).astype(c64)
+        t32 = np.float32(t)
+        g = sde.diffusion(t32)
+        drift = (np.float32(sde.theta) * (Y - x) - np.float32(g ** 2) * score(x, t32) * np.float32(0.5)).astype(c64)
+        return drift.reshape(-1)
+
+    sol = integrate.solve_ivp(ode_func, (1.0, t_eps), x0.reshape(-1), rtol=rtol, atol=atol, method=method)
+    x = sol.y[:, -1].reshape(Y.shape).astype(c64)
+    if denoise:                                                             # predictors.py:61-71 at t = eps, no noise
+        t = np.float32(t_eps)
+        dt = 1.0 / N
+        f = (np.float32(sde.theta) * (Y - x) * np.float32(dt)).astype(c64)
+        G = np.float32(sde.diffusion(t) * np.float32(np.sqrt(np.float32(dt))))
+        x = (x - (f - np.float32(G ** 2) * score(x, t))).astype(c64)
+    return x, int(sol.nfev)
+
+
+def score_ode_enhance(net: NCSNppOracle, y: np.ndarray, prior_noise: np.ndarray, sde: OUVE, N=30, alpha=ALPHA, beta=BETA, **kw):
+    Y, info = preprocess(y, alpha, beta)
+    X, nfe = score_ode_sample(net, Y, prior_noise, sde, N, **kw)
+    return postprocess(X, info, alpha, beta), nfe

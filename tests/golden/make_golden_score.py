@@ -76,6 +76,30 @@ def main():
     out["std_t"] = ts.numpy(); out["std"] = sm.sde._std(ts).numpy()
     out["diffusion"] = sm.sde.sde(torch.zeros(4, 1, 1, 1), ts, torch.zeros(4, 1, 1, 1))[1].numpy()
     out["timesteps_N30"] = torch.linspace(1, 3e-2, 30).numpy()
+    # black-box ODE sampler (sampling/__init__.py:75-146; scipy RK45 on the host), one clip, loose tolerance to keep it short
+    stream = O.seeded_noises(NOISE_SEED, (1, 1, 768, Tp))
+    torch.randn_like = lambda x, *a, **k: torch.from_numpy(next(stream))
+    try:
+        sm.eval()
+        import flowdec.sampling as S
+        nfe_box = {}
+        orig = S.get_ode_sampler
+
+        def wrapped(*a, **k):
+            sampler = orig(*a, **k)
+
+            def run(*aa, **kk):
+                x, nfe = sampler(*aa, **kk)
+                nfe_box["nfe"] = nfe
+                return x, nfe
+            return run
+        S.get_ode_sampler = wrapped
+        out["ode_rk45"] = sm.enhance(torch.from_numpy(y[:1]), sampler_type="ode", N=30, device="cpu", rtol=1e-3, atol=1e-3).numpy()
+        out["ode_rk45_nfe"] = np.int64(nfe_box["nfe"])
+        print("ode_rk45 nfe", nfe_box["nfe"], "rms", float(np.sqrt(np.mean(out["ode_rk45"] ** 2))))
+    finally:
+        torch.randn_like = real_randn_like
+        S.get_ode_sampler = orig
     rm = RegressionModel(loss_type="l2", **{**common, "backbone": sm.backbone}).eval()
     out["regression"] = rm.enhance(torch.from_numpy(y)).numpy()
     np.savez_compressed(os.path.join(HERE, "g13_score_nf8.npz"), **out)

@@ -99,10 +99,36 @@ def test_score_errors():
     with pytest.raises(ValueError):
         m.enhance(y, sampler_type="bogus")
     with pytest.raises(NotImplementedError):
-        m.enhance(y, sampler_type="ode")
+        m.enhance(y, sampler_type="ode", return_preprocess_info=True)
     lib = L.load()
     bad = L.FdScoreConfig(1.5, 0.5, 0.05, 0.03, 0.5, 3, 0, 0, 1, 1)    # sigma_max < sigma_min
     rc = lib.fd_score_enhance(m.backbone.handle(), C.c_void_p(8), C.c_void_p(8), C.byref(bad), C.c_void_p(8), 1, 4800, C.c_void_p(8), 1 << 40, 0, None)
     assert rc != 0 and b"OUVE" in lib.fd_last_error()
     cfg = L.FdScoreConfig(1.5, 0.05, 0.5, 0.03, 0.5, 30, 0, 0, 1, 1)
     assert lib.fd_score_num_draws(C.byref(cfg)) == 61
+
+
+def test_score_ode_sampler_golden():
+    """sampler_type='ode': scipy RK45 on the host around fd_score_eval, against the reference's own ODE sampler."""
+    g = load_golden("g13_score_nf8.npz")
+    m = baseline("score", "fp32")
+    Tp = O.padded_frames(O.num_frames(g["y"].shape[-1]))
+    z0 = torch.from_numpy(next(O.seeded_noises(int(g["noise_seed"]), (1, 1, 768, Tp))))   # the fixture's single-clip stream
+    out, nfe = m.enhance(torch.from_numpy(g["y"][:1]), sampler_type="ode", N=30, rtol=1e-3, atol=1e-3, noise=z0, return_nfe=True)
+    assert out.shape == g["ode_rk45"].shape and nfe == int(g["ode_rk45_nfe"])
+    check("score_ode_rk45[fp32]", out.numpy(), g["ode_rk45"], 2e-3)
+    # the drift entry point against its definition: theta (y - x) - 0.5 g^2 score
+    from flowdec_amd import _lib as L
+    lib = L.load()
+    x = torch.randn(1, 1, 768, 64, dtype=torch.complex64, device="cuda")
+    y = torch.randn(1, 1, 768, 64, dtype=torch.complex64, device="cuda")
+    t = 0.4
+    sde = O.OUVE(*[float(v) for v in g["sde"]])
+    sc = L.FdScoreConfig(sde.theta, sde.sigma_min, sde.sigma_max, 0.03, 0.0, 30, 0, 1, 0, 1)
+    h = m.backbone.handle()
+    ws = torch.empty(lib.fd_model_workspace_bytes(h, 1, 64), dtype=torch.uint8, device="cuda")
+    out2 = torch.empty_like(x)
+    L.check(lib.fd_score_eval(h, L.ptr(torch.view_as_real(x)), L.ptr(torch.view_as_real(y)), t, C.byref(sc), 0, L.ptr(torch.view_as_real(out2)),
+                              1, 64, L.ptr(ws), ws.numel(), L.stream()))
+    ref = sde.theta * (y - x) - 0.5 * float(sde.diffusion(t)) ** 2 * m(x, y, torch.tensor([t], device="cuda"))
+    assert rel_err(out2.cpu().numpy(), ref.cpu().numpy()) < 1e-5

@@ -211,3 +211,16 @@ def test_regression_matches_reference():
     g = load_golden("g13_score_nf8.npz")
     net, _ = score_net(g)
     assert rel_err(O.regression_enhance(net, g["y"][:1]), g["regression"][:1]) < 1e-4
+
+
+def test_score_ode_sampler_matches_reference():
+    """Black-box probability-flow sampler (scipy RK45 on the host) incl. the final denoising step and the NFE count."""
+    g = load_golden("g13_score_nf8.npz")
+    net, _ = score_net(g)
+    y = g["y"][:1]
+    Tp = O.padded_frames(O.num_frames(y.shape[-1]))
+    sde = O.OUVE(*[float(v) for v in g["sde"]])
+    z0 = next(O.seeded_noises(int(g["noise_seed"]), (1, 1, 768, Tp)))
+    out, nfe = O.score_ode_enhance(net, y, z0, sde, N=30, t_eps=float(g["t_eps"]), rtol=1e-3, atol=1e-3)
+    assert nfe == int(g["ode_rk45_nfe"])
+    assert rel_err(out, g["ode_rk45"]) < 1e-3
