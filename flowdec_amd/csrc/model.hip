@@ -582,6 +582,7 @@ int run_maybe_graph(fd_model* m, const GraphKey& key, bool use_graph, hipStream_
   auto it = m->graphs.find(key);
   if (it == m->graphs.end()) {
     if (m->graphs.size() >= 32) {   // the key holds raw buffer pointers: bound the cache for callers that keep changing them
+      FD_HIP(hipStreamSynchronize(st));   // (rare path) nothing captured earlier may still be in flight when it is destroyed
       for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
       m->graphs.clear();
     }
