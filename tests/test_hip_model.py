@@ -206,3 +206,21 @@ def test_longest_cli_clip_full_width():
     assert one.shape == (1, 1, L) and torch.isfinite(one).all() and float(one.abs().max()) > 0
     two = m.enhance(y, N=1, solver="euler", noise=nz)
     assert torch.equal(two[:1], one)
+
+
+def test_many_clip_lengths_graph_cache():
+    """A file-by-file driver sees many clip lengths: more distinct captured graphs than the cache holds (32) must keep
+    working, and a length seen before gives the same waveform again."""
+    g = load_golden("g9_enhance_nf8.npz")
+    m = make_model(8, int(g["seed"]), "bf16")
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    y = 0.1 * torch.randn(1, 1, 40000, device="cuda", generator=gen)
+    nz = torch.randn(1, 1, 768, 128, dtype=torch.complex64, device="cuda", generator=gen)
+    first = m.enhance(y[..., :9000], N=1, noise=nz[..., :64])
+    for k in range(40):
+        L = 9000 + 700 * (k + 1)                                    # T_pad 64 or 128
+        Tp = 64 if 1 + L // 384 <= 64 else 128
+        out = m.enhance(y[..., :L], N=1, noise=nz[..., :Tp])
+        assert out.shape == (1, 1, L) and torch.isfinite(out).all()
+    again = m.enhance(y[..., :9000], N=1, noise=nz[..., :64])
+    assert torch.equal(first, again)
