@@ -15,6 +15,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_library():
+    """The built .so is kept out of git; build it in-tree when a fresh checkout has none (hipcc cross-compiles without a GPU)."""
+    from flowdec_amd import build as _build
+    if not os.path.exists(_build.LIB):
+        _build.build(verbose=False)
+    yield
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name))
 
