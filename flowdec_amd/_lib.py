@@ -68,6 +68,8 @@ SIGNATURES = {
     "fd_model_workspace_bytes": (c_size_t, [_P, c_int, c_int]),
     "fd_ncsnpp_forward": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, _P, c_size_t, _P]),
     "fd_ode_solve": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
+    "fd_ode_adaptive_workspace_bytes": (c_size_t, [_P, c_int, c_int]),
+    "fd_ode_solve_adaptive": (c_int, [_P, _P, _P, c_float, c_int, c_float, c_float, _P, _P, C.POINTER(c_int), c_int, c_int, _P, c_size_t, _P]),
     "fd_enhance_workspace_bytes": (c_size_t, [_P, c_int, c_int]),
     "fd_enhance": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "fd_score_num_draws": (c_int, [C.POINTER(FdScoreConfig)]),

@@ -512,6 +512,37 @@ __global__ void caxpy_kernel(const float2* __restrict__ a, const float2* __restr
   }
 }
 
+// ---- adaptive Dormand-Prince driver helpers (model.hip: fd_ode_solve_adaptive) ------------------------------------
+struct fd_lincomb_args { const float2* k[7]; float c[7]; };
+// dst = cx * x + dt * sum_i c[i] * k[i]   (null k[i] / zero c[i] are skipped by the host)
+__global__ void ode_lincomb_kernel(const float2* __restrict__ x, float cx, float dt, fd_lincomb_args a, int nk, float2* __restrict__ dst, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float sx = 0.f, sy = 0.f;
+    for (int j = 0; j < nk; ++j) { const float2 kv = a.k[j][i]; sx = fmaf(a.c[j], kv.x, sx); sy = fmaf(a.c[j], kv.y, sy); }
+    float2 o = {dt * sx, dt * sy};
+    if (cx != 0.f) { const float2 xv = x[i]; o.x = fmaf(cx, xv.x, o.x); o.y = fmaf(cx, xv.y, o.y); }
+    dst[i] = o;
+  }
+}
+// partial[block] = sum over the block's elements of |p - q|^2 / (atol + rtol * max(|r|, |s|))^2   (complex moduli; q may be null)
+__global__ __launch_bounds__(256) void ode_scaled_sq_kernel(const float2* __restrict__ p, const float2* __restrict__ q, const float2* __restrict__ r,
+                                                            const float2* __restrict__ s, float atol, float rtol, double* __restrict__ partial, long long n) {
+  double acc = 0.0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float2 d = p[i];
+    if (q) { const float2 qv = q[i]; d.x -= qv.x; d.y -= qv.y; }
+    const float2 rv = r[i], sv = s[i];
+    const float m = fmaxf(sqrtf(rv.x * rv.x + rv.y * rv.y), sqrtf(sv.x * sv.x + sv.y * sv.y));
+    const float sc = atol + rtol * m;
+    acc += (double)((d.x * d.x + d.y * d.y) / (sc * sc));
+  }
+  acc = fd_wave_sum(acc);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
 inline int grid_for(long long n, int per_block = 256, int cap = 1 << 20) {
   long long g = (n + per_block - 1) / per_block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -706,6 +737,25 @@ int fd_init_state(const float* Y, const float* noise, const double* sigma_dev, i
 
 int fd_caxpy(const float* a, const float* q, float cq, float* dst, long long n, hipStream_t st) {
   hipLaunchKernelGGL(caxpy_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, (const float2*)a, (const float2*)q, cq, (float2*)dst, n);
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}
+
+int fd_ode_lincomb(const float* x, float cx, float dt, const float* const* k, const float* c, int nk, float* dst, long long n, hipStream_t st) {
+  fd_lincomb_args a;
+  int m = 0;
+  for (int j = 0; j < nk && j < 7; ++j)
+    if (k[j] && c[j] != 0.f) { a.k[m] = (const float2*)k[j]; a.c[m] = c[j]; ++m; }
+  for (int j = m; j < 7; ++j) { a.k[j] = nullptr; a.c[j] = 0.f; }
+  hipLaunchKernelGGL(ode_lincomb_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, (const float2*)x, cx, dt, a, m, (float2*)dst, n);
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}
+
+int fd_ode_scaled_sq(const float* p, const float* q, const float* r, const float* s, float atol, float rtol, double* partial, int nblocks,
+                     long long n, hipStream_t st) {
+  hipLaunchKernelGGL(ode_scaled_sq_kernel, dim3(nblocks), dim3(256), 0, st, (const float2*)p, (const float2*)q, (const float2*)r, (const float2*)s,
+                     atol, rtol, partial, n);
   FD_LAUNCH_CHECK();
   return FD_OK;
 }

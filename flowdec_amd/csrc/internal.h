@@ -36,6 +36,10 @@ int fd_edge_op(int which, const fd_edge_args& a, int dtype, hipStream_t st);
 int fd_init_state(const float* Y, const float* noise, const double* sigma_dev, int sigma_n, float sigma_fac, float* x0, int B,
                   int F, int T, hipStream_t st);
 int fd_combine_tiles(int H, int W);
+// adaptive solver helpers: dst = cx * x + dt * sum c[i] k[i];  partial[b] = sum |p - q|^2 / (atol + rtol max(|r|, |s|))^2
+int fd_ode_lincomb(const float* x, float cx, float dt, const float* const* k, const float* c, int nk, float* dst, long long n, hipStream_t st);
+int fd_ode_scaled_sq(const float* p, const float* q, const float* r, const float* s, float atol, float rtol, double* partial, int nblocks,
+                     long long n, hipStream_t st);
 int fd_caxpy(const float* a, const float* q, float cq, float* dst, long long n, hipStream_t st);
 // conv_mfma.hip
 int fd_conv_init_attributes();

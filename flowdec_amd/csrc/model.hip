@@ -792,6 +792,128 @@ extern "C" int fd_ode_solve(fd_model* m, const float* Y, const float* noise, flo
   return run_maybe_graph(m, key, use_graph != 0, st, [&]() { return ode_enqueue(m, Y, noise, sigma_fac, N, solver, X_out, traj, B, T_pad, ws, ws_bytes, st); });
 }
 
+// ---- adaptive Dormand-Prince 5(4) (torchdyn 'dopri5' semantics restated, see oracle odeint_dopri5; host-driven: one
+// synchronisation per attempted step for the error ratio) --------------------------------------------------------------
+namespace {
+constexpr int DP_NORM_BLOCKS = 512;
+const double DP_C[7] = {0.0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0};
+const double DP_A[7][6] = {{0}, {1.0 / 5}, {3.0 / 40, 9.0 / 40}, {44.0 / 45, -56.0 / 15, 32.0 / 9},
+                           {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729},
+                           {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656},
+                           {35.0 / 384, 0.0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84}};
+// error weights b5 - b4 (the 5th-order weights b5 are the last row of DP_A; its 7th entry is 0)
+const double DP_E[7] = {35.0 / 384 - 5179.0 / 57600, 0.0, 500.0 / 1113 - 7571.0 / 16695, 125.0 / 192 - 393.0 / 640,
+                        -2187.0 / 6784 + 92097.0 / 339200, 11.0 / 84 - 187.0 / 2100, -1.0 / 40};
+size_t adaptive_ws_bytes(const fd_model* m, int B, int T) {
+  const size_t state = fd_align(sizeof(float) * 2 * (size_t)B * m->n_freq * T);
+  return 10 * state + fd_align(sizeof(double) * DP_NORM_BLOCKS) + forward_ws_bytes(m, B, T);
+}
+}  // namespace
+
+extern "C" size_t fd_ode_adaptive_workspace_bytes(const fd_model* m, int B, int T_pad) {
+  if (!m || check_shape(m, B, T_pad) != FD_OK) return 0;
+  return adaptive_ws_bytes(m, B, T_pad);
+}
+
+extern "C" int fd_ode_solve_adaptive(fd_model* m, const float* Y, const float* noise, float sigma_fac, int N, float atol, float rtol, float* X_out,
+                                     float* traj, int* nfe_out, int B, int T_pad, void* ws, size_t ws_bytes, void* stream) {
+  FD_TRY(check_ready(m));
+  FD_REQUIRE(Y && noise && X_out && ws, "fd_ode_solve_adaptive: null pointer");
+  FD_REQUIRE(N >= 1 && atol > 0.f && rtol >= 0.f, "fd_ode_solve_adaptive: need N >= 1, atol > 0, rtol >= 0");
+  FD_TRY(check_shape(m, B, T_pad));
+  const size_t need = adaptive_ws_bytes(m, B, T_pad);
+  if (ws_bytes < need) return fd_set_error(FD_ENOMEM, "fd_ode_solve_adaptive: workspace %zu < required %zu bytes", ws_bytes, need);
+  hipStream_t st = fd_stream(stream);
+  const size_t nstate = (size_t)B * m->n_freq * T_pad;
+  const size_t state = fd_align(sizeof(float) * 2 * nstate);
+  char* base = (char*)ws;
+  float* x = (float*)base; float* x_new = (float*)(base + state); float* err = (float*)(base + 2 * state);
+  float* k[7];
+  for (int i = 0; i < 7; ++i) k[i] = (float*)(base + (3 + i) * state);
+  double* partial = (double*)(base + 10 * state);
+  void* fws = base + 10 * state + fd_align(sizeof(double) * DP_NORM_BLOCKS);
+  const size_t fws_bytes = ws_bytes - (10 * state + fd_align(sizeof(double) * DP_NORM_BLOCKS));
+  std::vector<double> host_partial(DP_NORM_BLOCKS);
+  int nfe = 0;
+  auto eval = [&](const float* xin, float t, float* kout) {
+    OutSpec os; os.dst = kout; os.coef = 1.f;
+    ++nfe;
+    return forward_call(m, xin, Y, nullptr, t, 1, os, B, T_pad, fws, fws_bytes, st);
+  };
+  // Hairer norm of (p - q) / (atol + rtol max(|r|, |s|)): sqrt(mean |.|^2) over the complex elements
+  auto norm = [&](const float* p_, const float* q_, const float* r_, const float* s_, double* out) {
+    FD_TRY(fd_ode_scaled_sq(p_, q_, r_, s_, atol, rtol, partial, DP_NORM_BLOCKS, (long long)nstate, st));
+    FD_HIP(hipMemcpyAsync(host_partial.data(), partial, sizeof(double) * DP_NORM_BLOCKS, hipMemcpyDeviceToHost, st));
+    FD_HIP(hipStreamSynchronize(st));
+    double acc = 0.0;
+    for (double v : host_partial) acc += v;
+    *out = sqrt(acc / (double)nstate);
+    return FD_OK;
+  };
+  FD_TRY(fd_init_state(Y, noise, m->sigma_dev, m->sigma_n, sigma_fac, x, B, m->n_freq, T_pad, st));
+  if (traj) FD_HIP(hipMemcpyAsync(traj, x, sizeof(float) * 2 * nstate, hipMemcpyDeviceToDevice, st));
+  const std::vector<float> ts = t_span_linspace(N);
+  float t = ts[0];
+  const float T = ts[N];
+  FD_TRY(eval(x, t, k[0]));
+  // initial step (Hairer): h0 = 0.01 d0 / d1, one explicit Euler probe, h1 = (0.01 / max(d1, d2))^(1/6)
+  double d0, d1, d2;
+  FD_TRY(norm(x, nullptr, x, x, &d0));
+  FD_TRY(norm(k[0], nullptr, x, x, &d1));
+  const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+  {
+    const float* kk[1] = {k[0]}; const float cc[1] = {1.f};
+    FD_TRY(fd_ode_lincomb(x, 1.f, (float)h0, kk, cc, 1, x_new, (long long)nstate, st));
+    FD_TRY(eval(x_new, t + (float)h0, k[1]));
+    FD_TRY(norm(k[1], k[0], x, x, &d2));
+    d2 /= h0;
+  }
+  const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / fmax(d1, d2), 1.0 / 6.0);
+  float dt = (float)fmin(100.0 * h0, h1);
+  int ckpt = 0, steps = 0;
+  while (t < T) {
+    if (++steps > 100000) return fd_set_error(FD_ERUNTIME, "fd_ode_solve_adaptive: step limit reached (dt = %g at t = %g)", (double)dt, (double)t);
+    if (t + dt > T) dt = T - t;
+    bool flag = false;
+    float dt_old = dt;
+    if (ckpt < N && t + dt > ts[ckpt + 1]) { dt_old = dt; flag = true; dt = ts[ckpt + 1] - t; }
+    for (int s = 1; s < 7; ++s) {                                    // stages 2..7; stage 7 is evaluated at the 5th-order solution (FSAL)
+      const float* kk[6]; float cc[6];
+      for (int j = 0; j < s; ++j) { kk[j] = k[j]; cc[j] = (float)DP_A[s][j]; }
+      float* xs = s == 6 ? x_new : err;                              // `err` doubles as the stage input buffer
+      FD_TRY(fd_ode_lincomb(x, 1.f, dt, kk, cc, s, xs, (long long)nstate, st));
+      FD_TRY(eval(xs, t + (float)DP_C[s] * dt, k[s]));
+    }
+    {
+      const float* kk[7]; float cc[7];
+      for (int j = 0; j < 7; ++j) { kk[j] = k[j]; cc[j] = (float)DP_E[j]; }
+      FD_TRY(fd_ode_lincomb(x, 0.f, dt, kk, cc, 7, err, (long long)nstate, st));
+    }
+    double ratio;
+    FD_TRY(norm(err, nullptr, x, x_new, &ratio));
+    if (ratio <= 1.0) {
+      t = t + dt;
+      std::swap(x, x_new);
+      std::swap(k[0], k[6]);
+      if (ckpt < N && fabs((double)t - (double)ts[ckpt + 1]) <= 1e-7) {
+        t = ts[ckpt + 1];
+        ++ckpt;
+        if (traj) FD_HIP(hipMemcpyAsync(traj + 2 * nstate * ckpt, x, sizeof(float) * 2 * nstate, hipMemcpyDeviceToDevice, st));
+      }
+    }
+    if (flag) dt = dt_old - dt;
+    if (ratio == 0.0) dt = dt * 10.f;
+    else {
+      const double minf = ratio < 1.0 ? 1.0 : 0.2;
+      dt = (float)((double)dt * fmin(10.0, fmax(0.9 / pow(ratio, 1.0 / 5.0), minf)));
+    }
+  }
+  FD_HIP(hipMemcpyAsync(X_out, x, sizeof(float) * 2 * nstate, hipMemcpyDeviceToDevice, st));
+  FD_HIP(hipStreamSynchronize(st));
+  if (nfe_out) *nfe_out = nfe;
+  return FD_OK;
+}
+
 extern "C" size_t fd_enhance_workspace_bytes(const fd_model* m, int B, int L) {
   if (!m || B <= 0 || L <= 0) return 0;
   const int T = 1 + L / m->cfg.hop, Tp = fd_padded_frames(T);

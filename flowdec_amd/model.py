@@ -371,8 +371,9 @@ class FlowModel(nn.Module):
         """Enhances a coded/noisy waveform y (model.py:476-528).  y: [L], [1, L] or [B, 1, L]."""
         if with_grad:
             raise NotImplementedError("flowdec_amd.FlowModel.enhance: with_grad=True (backprop through the solver) is out of scope")
-        if solver not in L.SOLVERS:
-            raise ValueError(f"unknown solver {solver!r}; supported: {sorted(L.SOLVERS)}")
+        adaptive = solver == "dopri5"
+        if not adaptive and solver not in L.SOLVERS:
+            raise ValueError(f"unknown solver {solver!r}; supported: {sorted(L.SOLVERS) + ['dopri5']}")
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("flowdec_amd: move the model to the GPU first (`model.cuda()`)")
@@ -401,8 +402,12 @@ class FlowModel(nn.Module):
             side = self._side_stream
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                res = self._enhance_native(lib, h, cfg, io, B, Lw, F, T, Tp, N, solver, sigma_fac, return_traj,
-                                           return_preprocess_info, squeeze_dims, use_graph, dev)
+                if adaptive:
+                    res = self._enhance_adaptive(lib, h, cfg, io, B, Lw, F, T, Tp, N, sigma_fac, return_traj, squeeze_dims, dev,
+                                                 float(kwargs.get("atol", 1e-4)), float(kwargs.get("rtol", 1e-4)))
+                else:
+                    res = self._enhance_native(lib, h, cfg, io, B, Lw, F, T, Tp, N, solver, sigma_fac, return_traj,
+                                               return_preprocess_info, squeeze_dims, use_graph, dev)
             cur.wait_stream(side)
         if return_traj:
             res[0].record_stream(cur)
@@ -415,6 +420,32 @@ class FlowModel(nn.Module):
             x_hat = x_hat.squeeze(0)
         x_hat = x_hat.to(orig_device)
         return (x_hat, info) if return_preprocess_info else x_hat
+
+    def _enhance_adaptive(self, lib, h, cfg, io, B, Lw, F, T, Tp, N, sigma_fac, return_traj, squeeze_dims, dev, atol, rtol):
+        """solver='dopri5': adaptive Dormand-Prince over t_span = linspace(0, 1, N+1) (torchdyn semantics restated, unpinned);
+        host-driven (one read-back per attempted step), so no hipGraph.  The realised NFE is left in `self.last_nfe`."""
+        from . import ops
+        Y, normfac, _ = ops.stft_compress(io["y"], normalize=True, **cfg)
+        traj = torch.empty(N + 1, B, 1, F, Tp, dtype=torch.complex64, device=dev) if return_traj else None
+        X = torch.empty_like(Y)
+        need = lib.fd_ode_adaptive_workspace_bytes(h, B, Tp)
+        ws = self.backbone.workspace(("ode", B, Tp), need, dev)
+        nfe = C.c_int(0)
+        L.check(lib.fd_ode_solve_adaptive(h, L.ptr(torch.view_as_real(Y)), L.ptr(torch.view_as_real(io["noise"])), float(sigma_fac), int(N),
+                                          atol, rtol, L.ptr(torch.view_as_real(X)), L.ptr(torch.view_as_real(traj)) if return_traj else None,
+                                          C.byref(nfe), B, Tp, L.ptr(ws), ws.numel(), L.stream()))
+        self.last_nfe = int(nfe.value)
+        if return_traj:
+            x_hats = []
+            for i in range(N + 1):
+                xh = ops.decompress_istft(traj[i], T, Lw, normfac, **cfg).reshape(B, 1, Lw)
+                for _ in range(squeeze_dims):
+                    xh = xh.squeeze(0)
+                x_hats.append(xh)
+            return traj, x_hats
+        x_hat = ops.decompress_istft(X, T, Lw, normfac, **cfg).reshape(B, 1, Lw)
+        info = dict(orig_length=Lw, normfac=normfac.reshape(B, 1, 1), undo_pad_fn=(lambda Y_, T=T: Y_[..., :T]), squeeze_dims=squeeze_dims)
+        return x_hat, info
 
     def _enhance_native(self, lib, h, cfg, io, B, Lw, F, T, Tp, N, solver, sigma_fac, return_traj, return_preprocess_info,
                         squeeze_dims, use_graph, dev):

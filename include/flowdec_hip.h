@@ -186,6 +186,13 @@ int fd_ncsnpp_forward(fd_model* m, const float* x, const float* y, const float* 
  * (B, T_pad, N, solver) and replays it. */
 int fd_ode_solve(fd_model* m, const float* Y, const float* noise, float sigma_fac, int N, int solver, float* X_out,
                  float* traj, int B, int T_pad, void* ws, size_t ws_bytes, int use_graph, void* stream);
+/* Adaptive Dormand-Prince 5(4) over t_span = linspace(0, 1, N+1) (solver='dopri5' of the reference's torchdyn NeuralODE,
+ * model.py:487-514; controller semantics restated, see oracle/).  Host-driven: the error ratio of every attempted step is
+ * read back, so the call synchronises `stream` and cannot be graph-captured.  traj (optional) receives the N+1 states at
+ * the t_span checkpoints, *nfe_out the number of vector-field evaluations. */
+size_t fd_ode_adaptive_workspace_bytes(const fd_model* m, int B, int T_pad);
+int fd_ode_solve_adaptive(fd_model* m, const float* Y, const float* noise, float sigma_fac, int N, float atol, float rtol,
+                          float* X_out, float* traj, int* nfe_out, int B, int T_pad, void* ws, size_t ws_bytes, void* stream);
 size_t fd_enhance_workspace_bytes(const fd_model* m, int B, int L);
 /* FlowModel.enhance (model.py:476-528) end to end on device buffers: y [B][L] f32 -> x_hat [B][L] f32. */
 int fd_enhance(fd_model* m, const float* y, const float* noise, float sigma_fac, int N, int solver, float* x_hat, int B,

@@ -224,3 +224,23 @@ def test_many_clip_lengths_graph_cache():
         assert out.shape == (1, 1, L) and torch.isfinite(out).all()
     again = m.enhance(y[..., :9000], N=1, noise=nz[..., :64])
     assert torch.equal(first, again)
+
+
+def test_enhance_dopri5_adaptive_vs_oracle():
+    """solver='dopri5' (adaptive Dormand-Prince, torchdyn semantics restated -- unpinned): the HIP driver against the NumPy
+    restatement of the same controller (fixture g16, produced by tests/golden/make_golden_dopri5.py from the oracle)."""
+    g = load_golden("g9_enhance_nf8.npz")
+    ref = load_golden("g16_dopri5_oracle_nf8.npz")
+    m = make_model(8, int(g["seed"]), "fp32")
+    y, nz = torch.from_numpy(g["y"][:1]), torch.from_numpy(g["noise"][:1])
+    out = m.enhance(y, N=2, solver="dopri5", noise=nz, atol=1e-3, rtol=1e-3)
+    nfe, nfe_ref = m.last_nfe, int(ref["nfe_tol1e-3"])
+    assert out.shape == (1, 1, 24000) and (nfe - 2) % 6 == 0 and abs(nfe - nfe_ref) <= 12, (nfe, nfe_ref)
+    check("enhance_dopri5[fp32]", out.numpy(), ref["wave_tol1e-3"], 5e-3)
+    # trajectory checkpoints: t_span = [0, 0.5, 1] -> 3 states, the last one is the result
+    traj, waves = m.enhance(y, N=2, solver="dopri5", noise=nz, atol=1e-3, rtol=1e-3, return_traj=True)
+    assert traj.shape[0] == 3 and torch.equal(waves[-1].cpu(), out)
+    assert abs(float(torch.view_as_real(traj[1]).double().pow(2).sum().sqrt()) / float(ref["mid_feat_norm"]) - 1) < 1e-3
+    # a tighter tolerance costs more evaluations (the random-weight field is too stiff for the two answers to be compared)
+    tight = m.enhance(y, N=2, solver="dopri5", noise=nz, atol=1e-5, rtol=1e-5)
+    assert m.last_nfe > nfe and torch.isfinite(tight).all()
