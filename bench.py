@@ -109,7 +109,7 @@ def main():
     lib = L.load()
     T = lib.fd_num_frames(Lw, 384); Tp = lib.fd_padded_frames(T)
     noise = torch.randn(B, 1, 768, Tp, dtype=torch.complex64, device=dev, generator=gen)
-    nfe = {"euler": args.N, "midpoint": 2 * args.N, "heun2": 2 * args.N, "heun2_eulerlast": 2 * args.N - 1}[args.solver]
+    nfe = {"euler": args.N, "midpoint": 2 * args.N, "heun2": 2 * args.N, "heun2_eulerlast": 2 * args.N - 1, "dopri5": None}[args.solver]
 
     def step():
         return model.enhance(y, N=args.N, solver=args.solver, noise=noise, use_graph=not args.no_graph)
@@ -128,6 +128,8 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     assert torch.isfinite(out).all()
+    if nfe is None:
+        nfe = model.last_nfe   # adaptive solver: realised number of vector-field evaluations of the last step
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
