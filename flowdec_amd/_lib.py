@@ -23,6 +23,12 @@ class FdModelConfig(C.Structure):
                 ("n_fft", c_int), ("hop", c_int), ("alpha", c_float), ("beta", c_float), ("act_dtype", c_int)]
 
 
+class FdResblockDesc(C.Structure):
+    _fields_ = [("cin0", c_int), ("cin1", c_int), ("cout", c_int), ("up", c_int), ("down", c_int), ("has_conv2", c_int),
+                ("gn0_gamma", c_void_p), ("gn0_beta", c_void_p), ("gn1_gamma", c_void_p), ("gn1_beta", c_void_p),
+                ("w0", c_void_p), ("bias0", c_void_p), ("bias0_rows", c_int), ("w1", c_void_p), ("bias1", c_void_p)]
+
+
 class FdScoreConfig(C.Structure):
     _fields_ = [("theta", c_float), ("sigma_min", c_float), ("sigma_max", c_float), ("t_eps", c_float), ("snr", c_float),
                 ("N", c_int), ("predictor", c_int), ("corrector", c_int), ("corrector_steps", c_int), ("denoise", c_int)]
@@ -43,6 +49,9 @@ SIGNATURES = {
     "fd_fir_resample": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "fd_channel_sums_tiles": (c_int, [c_int, c_int]),
     "fd_channel_sums": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "fd_gn_silu_apply": (c_int, [_P, _P, _P, c_int, c_ll, c_int, c_int, _P]),
+    "fd_resblock_workspace_bytes": (c_size_t, [C.POINTER(FdResblockDesc), c_int, c_int, c_int, c_int]),
+    "fd_resblock": (c_int, [C.POINTER(FdResblockDesc), _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "fd_gn_finalize": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_ll, c_float, _P]),
     "fd_conv_packed_bytes": (c_ll, [c_int] * 7),
     "fd_conv_pack_weights": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -96,6 +96,23 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
+// silu(a*x + d), per-(b,c) affine: act(GroupNorm(x)) as a stand-alone pass (operator-level parity; fused on the hot path)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_silu_apply_kernel(const T* __restrict__ x, const float* __restrict__ affine, T* __restrict__ out,
+                                                            long long hw, int C, long long nvec) {
+  const int cv = C >> 3;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+    const int c8 = (int)(i % cv) * 8;
+    const long long b = i / cv / hw;
+    float v[8];
+    fd_load_vec<T, 8>(x + i * 8, v);
+    const float* ad = affine + ((size_t)b * C + c8) * 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fd_silu(fmaf(v[j], ad[2 * j], ad[2 * j + 1]));
+    fd_store_vec<T, 8>(out + i * 8, v);
+  }
+}
+
 // =====================================================================================================
 // FIR [1,3,3,1] x2 resampling, polyphase form (up_or_down_sampling.py:220-282 via op/upfirdn2d.py)
 //   down: out[n]   = (x[2n-1] + 3 x[2n] + 3 x[2n+1] + x[2n+2]) / 8     per axis, zeros outside
@@ -568,6 +585,18 @@ extern "C" int fd_channel_sums(const void* x, float* part, int B, int H, int W, 
     hipLaunchKernelGGL(channel_sums_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, part, HW, C, ppb);
   else
     hipLaunchKernelGGL(channel_sums_kernel<float>, grid, dim3(256), 0, st, (const float*)x, part, HW, C, ppb);
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}
+
+extern "C" int fd_gn_silu_apply(const void* x, const float* affine, void* out, int B, long long hw, int C, int dtype, void* stream) {
+  FD_REQUIRE(x && affine && out, "fd_gn_silu_apply: null pointer");
+  FD_REQUIRE(B > 0 && hw > 0 && C > 0 && C % 8 == 0, "fd_gn_silu_apply: C must be a multiple of 8");
+  FD_REQUIRE(dtype == FD_F32 || dtype == FD_BF16, "fd_gn_silu_apply: bad dtype");
+  const long long nvec = (long long)B * hw * (C / 8);
+  const dim3 grid(grid_for(nvec, 256, 1 << 16));
+  if (dtype == FD_BF16) hipLaunchKernelGGL(gn_silu_apply_kernel<bf16>, grid, dim3(256), 0, fd_stream(stream), (const bf16*)x, affine, (bf16*)out, hw, C, nvec);
+  else hipLaunchKernelGGL(gn_silu_apply_kernel<float>, grid, dim3(256), 0, fd_stream(stream), (const float*)x, affine, (float*)out, hw, C, nvec);
   FD_LAUNCH_CHECK();
   return FD_OK;
 }

@@ -270,7 +270,7 @@ struct Fwd {
       out.sums = arena.alloc(sizeof(float) * 2 * (size_t)B * out.tiles * out.stride);
     }
     if (dry) return FD_OK;
-    if (m->profiling) {
+    if (m && m->profiling) {
       if (m->ev_used == m->ev.size()) {
         hipEvent_t e0, e1;
         FD_HIP(hipEventCreate(&e0)); FD_HIP(hipEventCreate(&e1));
@@ -282,7 +282,7 @@ struct Fwd {
                              s0 ? ptr(s0->off) : nullptr, s0 ? s0->C : 0, s1 ? ptr(s1->off) : nullptr, s1 ? s1->C : 0, w, bias, bias_rows,
                              skip ? ptr(skip->off) : nullptr, scale, ptr(out.off), out.C, want_stats ? (float*)ptr(out.sums) : nullptr, B,
                              out.H, out.W, ks, dt, st);
-    if (m->profiling) {
+    if (m && m->profiling) {
       FD_HIP(hipEventRecord(m->ev[m->ev_used].second, st));
       ++m->ev_used;
       m->prof_flops += 2.0 * B * out.H * out.W * (double)out.C *
@@ -293,7 +293,7 @@ struct Fwd {
     return rc;
   }
 
-  int resblock(const Mod& md, Tens& x0, Tens* x1, int nt, Tens& out) {
+  int resblock(const Mod& md, Tens& x0, Tens* x1, int nt, Tens& out, bool out_given = false) {
     const float rs2 = 0.70710678118654752440f;
     size_t aff0;
     FD_TRY(gn_affine(x0, x1, md.gn0_g, md.gn0_b, &aff0));
@@ -312,7 +312,8 @@ struct Fwd {
     arena.release(aff0);
     size_t aff1;
     FD_TRY(gn_affine(h1, nullptr, md.gn1_g, md.gn1_b, &aff1));
-    out = talloc(md.cout, OH, OW);
+    if (!out_given) out = talloc(md.cout, OH, OW);
+    else { out.C = md.cout; out.H = OH; out.W = OW; out.sums = (size_t)-1; }   // fd_resblock: the caller's output tensor
     if (md.has_c2) {  // Conv_1(act(GN1(h))) + Conv_2(x) in one launch (shortcut conv folded in as extra K steps)
       if (md.up || md.down) FD_TRY(conv(h1, nullptr, aff1, &xr, nullptr, md.w1, md.b1, 1, nullptr, rs2, out, 3, true));
       else FD_TRY(conv(h1, nullptr, aff1, &x0, x1, md.w1, md.b1, 1, nullptr, rs2, out, 3, true));
@@ -1031,6 +1032,54 @@ extern "C" int fd_regression_enhance(fd_model* m, const float* y, float* x_hat, 
                           OutSpec os; os.dst = X; os.coef = 1.f;                                 // X_hat = backbone(Y, Y, t = 0), model.py:566-578
                           return forward_call(m, Y, Y, nullptr, 0.f, 1, os, B, Tp, rest, rest_bytes, st);
                         });
+}
+
+// ---- one ResnetBlockBigGANpp as a stand-alone call (layerspp.py:252-284; the fusion unit of SURVEY 8(a13)) -----------
+namespace {
+int resblock_run(const fd_resblock_desc& d, const void* x0, const void* x1, void* out, int B, int H, int W, int dtype, bool dry, void* ws,
+                 hipStream_t st, size_t* peak) {
+  Mod md; md.kind = M_RB; md.cin = d.cin0 + d.cin1; md.c0 = d.cin0; md.c1 = d.cin1; md.cout = d.cout;
+  md.up = d.up != 0; md.down = d.down != 0; md.has_c2 = d.has_conv2 != 0;
+  md.w0 = const_cast<void*>(d.w0); md.w1 = const_cast<void*>(d.w1);
+  md.gn0_g = const_cast<float*>(d.gn0_gamma); md.gn0_b = const_cast<float*>(d.gn0_beta);
+  md.gn1_g = const_cast<float*>(d.gn1_gamma); md.gn1_b = const_cast<float*>(d.gn1_beta);
+  md.bias0_eff = const_cast<float*>(d.bias0); md.b1 = const_cast<float*>(d.bias1);
+  Fwd f{nullptr, dry, (char*)ws, Arena(), st, B, 0, 0, dtype, (int)fd_dtype_size(dtype)};
+  // tensors that live outside the workspace are addressed relative to it (never released to the arena)
+  auto external = [&](const void* p, int C, int h, int w) { Tens t; t.off = (size_t)((const char*)p - (const char*)ws); t.C = C; t.H = h; t.W = w; return t; };
+  Tens a = external(dry ? ws : x0, d.cin0, H, W), b, o = external(dry ? ws : out, d.cout, 0, 0);
+  if (d.cin1) b = external(dry ? ws : x1, d.cin1, H, W);
+  const int rc = f.resblock(md, a, d.cin1 ? &b : nullptr, d.bias0_rows, o, true);
+  if (peak) *peak = f.arena.peak() + 256;
+  return rc;
+}
+int check_resblock(const fd_resblock_desc* d, int B, int H, int W, int dtype) {
+  FD_REQUIRE(d, "fd_resblock: null descriptor");
+  FD_REQUIRE(d->cin0 > 0 && d->cin0 % 8 == 0 && d->cin1 >= 0 && d->cin1 % 8 == 0 && d->cout > 0 && d->cout % 8 == 0, "fd_resblock: channel counts must be multiples of 8");
+  FD_REQUIRE(!(d->up && d->down) && (!(d->up || d->down) || d->cin1 == 0), "fd_resblock: up / down blocks take a single input tensor");
+  FD_REQUIRE(d->has_conv2 || d->cin0 + d->cin1 == d->cout, "fd_resblock: identity shortcut needs Cin == Cout");
+  FD_REQUIRE(B > 0 && H > 0 && W > 0 && (!d->down || (H % 2 == 0 && W % 2 == 0)), "fd_resblock: bad shape");
+  FD_REQUIRE(dtype == FD_BF16 || dtype == FD_F32, "fd_resblock: bad dtype");
+  return FD_OK;
+}
+}  // namespace
+
+extern "C" size_t fd_resblock_workspace_bytes(const fd_resblock_desc* d, int B, int H, int W, int dtype) {
+  if (check_resblock(d, B, H, W, dtype) != FD_OK) return 0;
+  size_t peak = 0;
+  if (resblock_run(*d, nullptr, nullptr, nullptr, B, H, W, dtype, true, nullptr, nullptr, &peak) != FD_OK) return 0;
+  return peak;
+}
+
+extern "C" int fd_resblock(const fd_resblock_desc* d, const void* x0, const void* x1, void* out, int B, int H, int W, int dtype, void* ws,
+                           size_t ws_bytes, void* stream) {
+  FD_TRY(check_resblock(d, B, H, W, dtype));
+  FD_REQUIRE(x0 && out && ws && (d->cin1 == 0) == (x1 == nullptr), "fd_resblock: null pointer / x1 mismatch");
+  FD_REQUIRE(d->w0 && d->w1 && d->gn0_gamma && d->gn0_beta && d->gn1_gamma && d->gn1_beta && d->bias0 && d->bias1, "fd_resblock: incomplete descriptor");
+  FD_REQUIRE(d->bias0_rows == 1 || d->bias0_rows == B, "fd_resblock: bias0_rows must be 1 or B");
+  const size_t need = fd_resblock_workspace_bytes(d, B, H, W, dtype);
+  if (ws_bytes < need) return fd_set_error(FD_ENOMEM, "fd_resblock: workspace %zu < required %zu bytes", ws_bytes, need);
+  return resblock_run(*d, x0, x1, out, B, H, W, dtype, false, ws, fd_stream(stream), nullptr);
 }
 
 extern "C" int fd_profile_enable(fd_model* m, int enable) {

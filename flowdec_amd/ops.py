@@ -167,3 +167,39 @@ def fused_bias_act(x, bias, act=3, alpha=0.2, scale=math.sqrt(2.0)):
     L.check(L.load().fd_fused_bias_act(L.ptr(x), L.ptr(None if bias is None else bias.contiguous().float()), L.ptr(out), x.numel(),
                                        step_b, size_b, act, alpha, scale, L.stream()))
     return out
+
+
+def gn_silu_apply(x, affine):
+    """silu(a * x + d) with per-(b, c) affine pairs [B, C, 2] on an NHWC tensor (stand-alone; fused on the hot path)."""
+    B, H, W, Cc = _nhwc(x)
+    L.require_cuda(affine)
+    out = torch.empty_like(x)
+    L.check(L.load().fd_gn_silu_apply(L.ptr(x), L.ptr(affine.contiguous()), L.ptr(out), B, H * W, Cc, L.dtype_id(x.dtype), L.stream()))
+    return out
+
+
+def resblock(x0, x1, params, temb, up=False, down=False):
+    """One ResnetBlockBigGANpp (layerspp.py:252-284) through fd_resblock.  x0 / x1: NHWC (virtual concat); params: the
+    module's state_dict entries (GroupNorm_0/1, Conv_0/1[/2], Dense_0) as float32 GPU tensors; temb [nt, temb_dim]."""
+    import ctypes as C
+    B, H, W, C0 = _nhwc(x0)
+    C1 = 0 if x1 is None else x1.shape[3]
+    Cout = params["Conv_0.weight"].shape[0]
+    has_c2 = "Conv_2.weight" in params
+    dt = x0.dtype
+    w0 = pack_conv_weight(params["Conv_0.weight"], C0=C0, dtype=dt)
+    w1 = pack_conv_weight(params["Conv_1.weight"], C0=Cout, dtype=dt, w_sc=params.get("Conv_2.weight"), S0=C0 if has_c2 else None)
+    bias0 = temb_bias(temb.float().contiguous(), params["Dense_0.weight"], params["Dense_0.bias"], params["Conv_0.bias"])
+    bias1 = (params["Conv_1.bias"] + (params["Conv_2.bias"] if has_c2 else 0)).float().contiguous()
+    keep = [t.float().contiguous() for t in (params["GroupNorm_0.weight"], params["GroupNorm_0.bias"], params["GroupNorm_1.weight"], params["GroupNorm_1.bias"])]
+    d = L.FdResblockDesc(C0, C1, Cout, int(up), int(down), int(has_c2), keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(),
+                         w0.data_ptr(), bias0.data_ptr(), bias0.shape[0], w1.data_ptr(), bias1.data_ptr())
+    lib = L.load()
+    OH, OW = (2 * H, 2 * W) if up else ((H // 2, W // 2) if down else (H, W))
+    out = torch.empty(B, OH, OW, Cout, dtype=dt, device=x0.device)
+    need = lib.fd_resblock_workspace_bytes(C.byref(d), B, H, W, L.dtype_id(dt))
+    if need == 0:
+        raise RuntimeError("flowdec_hip: " + lib.fd_last_error().decode())
+    ws = torch.empty(need, dtype=torch.uint8, device=x0.device)
+    L.check(lib.fd_resblock(C.byref(d), L.ptr(x0), L.ptr(x1), L.ptr(out), B, H, W, L.dtype_id(dt), L.ptr(ws), need, L.stream()))
+    return out

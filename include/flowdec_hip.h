@@ -125,6 +125,27 @@ int fd_time_embedding(const float* t, int nt, const float* gfp_w, int nf, const 
 int fd_temb_bias(const float* temb, int nt, int temb_dim, const float* dense_w, const float* dense_b,
                  const float* conv_bias, int Cout, float* out, void* stream);
 
+/* silu(a*x + d) with per-(b,c) affine pairs = act(GroupNorm(x)) as a stand-alone pass (layerspp.py:253,274); on the hot
+ * path this is fused into the consumer's operand load, the entry point exists for operator-level parity. */
+int fd_gn_silu_apply(const void* x, const float* affine, void* out, int B, long long hw, int C, int dtype, void* stream);
+
+/* One ResnetBlockBigGANpp.forward (layerspp.py:252-284): GroupNorm_0 + SiLU [+ FIR up/down of h and x] -> Conv_0 + time
+ * bias -> GroupNorm_1 + SiLU -> Conv_1 [+ Conv_2(x) folded in] (+ x) -> / sqrt(2), as the launches the model uses
+ * (2 convs, 2 finalize, optional FIR).  x0 / x1 = NHWC input (virtual concat), out = NHWC [B][H'][W'][cout].
+ *   w0    = fd_conv_pack_weights(Conv_0.weight, NULL, cout, cin0, cin1, 3, 0, 0)  (up/down blocks: cin1 = 0)
+ *   w1    = fd_conv_pack_weights(Conv_1.weight, Conv_2.weight or NULL, cout, cout, 0, 3, S0, S1) with (S0, S1) = the input
+ *           split (cin0, cin1) when has_conv2 -- the shortcut conv runs as extra K steps on x (resampled for up/down)
+ *   bias0 = [bias0_rows][cout] from fd_temb_bias (Conv_0.bias + Dense_0(silu(temb))),  bias1 = Conv_1.bias (+ Conv_2.bias) */
+typedef struct fd_resblock_desc {
+  int cin0, cin1, cout, up, down, has_conv2;
+  const float *gn0_gamma, *gn0_beta, *gn1_gamma, *gn1_beta;
+  const void* w0; const float* bias0; int bias0_rows;
+  const void* w1; const float* bias1;
+} fd_resblock_desc;
+size_t fd_resblock_workspace_bytes(const fd_resblock_desc* d, int B, int H, int W, int dtype);
+int fd_resblock(const fd_resblock_desc* d, const void* x0, const void* x1, void* out, int B, int H, int W, int dtype, void* ws,
+                size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Front / back end
  * ---------------------------------------------------------------------------------------------- */

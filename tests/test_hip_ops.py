@@ -316,3 +316,30 @@ def test_stft_roundtrip_full_size(ops):
     e = float((yr - y).norm() / y.norm())
     report("stft_roundtrip_8x96000", e, 2e-4)
     assert e < 2e-4
+
+
+# ---- one ResnetBlockBigGANpp through fd_resblock against the reference golden G6 --------------------
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", list(O.RESBLOCK_CASES))
+def test_resblock_golden(ops, name, prec):
+    g = load_golden("g6_resblock.npz")
+    seed, ci, co, up, down = O.RESBLOCK_CASES[name]
+    p = {k: dev(v) for k, v in O.random_resblock_params(seed, ci, co, has_conv2=(ci != co or up or down)).items()}
+    x = nhwc(g[f"{name}_x"], DT[prec])
+    x0, x1 = (x[..., :256].contiguous(), x[..., 256:].contiguous()) if name == "cat" else (x, None)    # virtual concat 256 + 64
+    out = ops.resblock(x0, x1, p, dev(g[f"{name}_temb"]), up=up, down=down)
+    assert tuple(out.shape) == (2, g[f"{name}_out"].shape[2], g[f"{name}_out"].shape[3], co)
+    check(f"resblock[{name},{prec}]", from_nhwc(out), g[f"{name}_out"], 1e-4 if prec == "fp32" else 3e-2)
+
+
+def test_gn_silu_apply_golden(ops):
+    g = load_golden("g5_groupnorm_silu.npz")
+    x = nhwc(g["x64"], torch.float32)
+    aff = ops.gn_affine(x, None, dev(g["gamma64"]), dev(g["beta64"]))
+    check("gn_silu_apply[64]", from_nhwc(ops.gn_silu_apply(x, aff)), g["out64"], 2e-5)
+    # GroupNorm(32, 320) over the virtual concat 256 + 64 (ncsnpp.py:337): one statistics pass, applied per tensor
+    x = nhwc(g["x320"], torch.float32)
+    x0, x1 = x[..., :256].contiguous(), x[..., 256:].contiguous()
+    aff = ops.gn_affine(x0, x1, dev(g["gamma320"]), dev(g["beta320"]))
+    out = torch.cat([ops.gn_silu_apply(x0, aff[:, :256].contiguous()), ops.gn_silu_apply(x1, aff[:, 256:].contiguous())], dim=-1)
+    check("gn_silu_apply[256+64]", from_nhwc(out), g["out320"], 2e-5)
