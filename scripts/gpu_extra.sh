@@ -10,4 +10,3 @@ run fp32 --precision fp32 --steps 2 --warmup 1
 run cfg3 --preset flowdec_25s --batch 32 --solver midpoint --N 3 --steps 2 --warmup 1
 run b1 --batch 1 --seconds 1 --steps 10 --warmup 3
 run cfg5like --precision fp32 --batch 8 --seconds 4 --N 32 --steps 1 --warmup 1 --no-roofline
-run cfg5dopri5 --precision fp32 --batch 2 --seconds 4 --N 32 --solver dopri5 --steps 1 --warmup 0 --no-roofline
