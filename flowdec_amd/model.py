@@ -449,38 +449,36 @@ class FlowModel(nn.Module):
 
     def _enhance_native(self, lib, h, cfg, io, B, Lw, F, T, Tp, N, solver, sigma_fac, return_traj, return_preprocess_info,
                         squeeze_dims, use_graph, dev):
-        if True:
-            if not return_traj:
-                need = lib.fd_enhance_workspace_bytes(h, B, Lw)
-                if need == 0:
-                    raise RuntimeError("flowdec_hip: " + lib.fd_last_error().decode())
-                ws = self.backbone.workspace(("enh", B, Lw), need, dev)
-                L.check(lib.fd_enhance(h, L.ptr(io["y"]), L.ptr(torch.view_as_real(io["noise"])), float(sigma_fac), int(N),
-                                       L.SOLVERS[solver], L.ptr(io["out"]), B, Lw, L.ptr(ws), ws.numel(), int(use_graph), L.stream()))
-                x_hat = io["out"].reshape(B, 1, Lw).clone()
-                info = None
-                if return_preprocess_info:
-                    # normfac was computed by the HIP front-end; it lives right after the two state buffers of the workspace
-                    state = (8 * B * F * Tp + 255) // 256 * 256
-                    normfac = ws[2 * state:2 * state + 4 * B].view(torch.float32).clone().reshape(B, 1, 1)
-                    info = dict(orig_length=Lw, normfac=normfac, undo_pad_fn=(lambda Y_, T=T: Y_[..., :T]), squeeze_dims=squeeze_dims)
-            else:
-                from . import ops
-                Y, normfac, _ = ops.stft_compress(io["y"], normalize=True, **cfg)
-                traj = torch.empty(N + 1, B, 1, F, Tp, dtype=torch.complex64, device=dev)
-                X = torch.empty_like(Y)
-                need = lib.fd_model_workspace_bytes(h, B, Tp)
-                ws = self.backbone.workspace(("ode", B, Tp), need, dev)
-                L.check(lib.fd_ode_solve(h, L.ptr(torch.view_as_real(Y)), L.ptr(torch.view_as_real(io["noise"])), float(sigma_fac), int(N),
-                                         L.SOLVERS[solver], L.ptr(torch.view_as_real(X)), L.ptr(torch.view_as_real(traj)), B, Tp,
-                                         L.ptr(ws), ws.numel(), 0, L.stream()))
-                x_hats = []
-                for i in range(N + 1):
-                    xh = ops.decompress_istft(traj[i], T, Lw, normfac, **cfg).reshape(B, 1, Lw)
-                    for _ in range(squeeze_dims):
-                        xh = xh.squeeze(0)
-                    x_hats.append(xh)
-                return traj, x_hats
+        if return_traj:   # every solver state is needed: front end, solver and back end as separate native calls
+            from . import ops
+            Y, normfac, _ = ops.stft_compress(io["y"], normalize=True, **cfg)
+            traj = torch.empty(N + 1, B, 1, F, Tp, dtype=torch.complex64, device=dev)
+            X = torch.empty_like(Y)
+            need = lib.fd_model_workspace_bytes(h, B, Tp)
+            ws = self.backbone.workspace(("ode", B, Tp), need, dev)
+            L.check(lib.fd_ode_solve(h, L.ptr(torch.view_as_real(Y)), L.ptr(torch.view_as_real(io["noise"])), float(sigma_fac), int(N),
+                                     L.SOLVERS[solver], L.ptr(torch.view_as_real(X)), L.ptr(torch.view_as_real(traj)), B, Tp,
+                                     L.ptr(ws), ws.numel(), 0, L.stream()))
+            x_hats = []
+            for i in range(N + 1):
+                xh = ops.decompress_istft(traj[i], T, Lw, normfac, **cfg).reshape(B, 1, Lw)
+                for _ in range(squeeze_dims):
+                    xh = xh.squeeze(0)
+                x_hats.append(xh)
+            return traj, x_hats
+        need = lib.fd_enhance_workspace_bytes(h, B, Lw)
+        if need == 0:
+            raise RuntimeError("flowdec_hip: " + lib.fd_last_error().decode())
+        ws = self.backbone.workspace(("enh", B, Lw), need, dev)
+        L.check(lib.fd_enhance(h, L.ptr(io["y"]), L.ptr(torch.view_as_real(io["noise"])), float(sigma_fac), int(N),
+                               L.SOLVERS[solver], L.ptr(io["out"]), B, Lw, L.ptr(ws), ws.numel(), int(use_graph), L.stream()))
+        x_hat = io["out"].reshape(B, 1, Lw).clone()
+        info = None
+        if return_preprocess_info:
+            # normfac was computed by the HIP front-end; it lives right after the two state buffers of the workspace
+            state = (8 * B * F * Tp + 255) // 256 * 256
+            normfac = ws[2 * state:2 * state + 4 * B].view(torch.float32).clone().reshape(B, 1, 1)
+            info = dict(orig_length=Lw, normfac=normfac, undo_pad_fn=(lambda Y_, T=T: Y_[..., :T]), squeeze_dims=squeeze_dims)
         return x_hat, info
 
 
