@@ -25,29 +25,29 @@ TRAFFIC_FILE = "r01_conv_traffic.json"
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """Times the NumPy oracle (a port of the reference's fp32 CPU path) on a bounded sample of the same
-    workload: ONE vector-field evaluation of the full-width FlowDec-75m NCSN++ on a 0.512 s clip
-    (B=1, 768 x 64 frames), extrapolated to the 6 NFE of the benchmark config (the STFT/iSTFT are <0.1 %)."""
+def cpu_baseline():
+    """Times the NumPy oracle (a port of the reference's fp32 CPU path) on a bounded sample of the same workload: ONE
+    vector-field evaluation of the full-width FlowDec-75m NCSN++ on the shape of BASELINE config 1 (one 1 s clip = 126
+    frames padded to 768 x 128), extrapolated to the 6 NFE of the benchmark config (the STFT/iSTFT are < 0.1 %)."""
     import numpy as np
     from oracle import flowdec_oracle as O
     rng = np.random.default_rng(0)
     net = O.NCSNppOracle(O.random_state_dict(seed=64, nf=64), nf=64)
-    shape = (1, 1, 768, 64)
+    shape = (1, 1, 768, 128)
     x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
     y = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
     t0 = time.perf_counter()
     net.forward(x, y, np.array([0.5], np.float32))
     dt = time.perf_counter() - t0
-    audio_s = 64 * 384 / 48000.0
+    audio_s = 1.0
     try:
         from threadpoolctl import threadpool_info
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
         threads = os.cpu_count() or 1
     return {"value": audio_s / (6 * dt), "unit": "audio-seconds/second", "cores": int(threads), "kind": "port",
-            "sample": "oracle (NumPy/OpenBLAS fp32 port of the reference CPU path): 1 NFE of full-width NCSN++ on one 0.512 s clip "
-                      f"(768x64 frames) took {dt:.2f} s; x6 NFE extrapolated to the Euler N=6 config"}
+            "sample": "oracle (NumPy/OpenBLAS fp32 port of the reference CPU path): 1 NFE of full-width NCSN++ on one 1 s clip "
+                      f"(BASELINE config 1 shape, 768x128 frames) took {dt:.2f} s; x6 NFE extrapolated to the Euler N=6 config"}
 
 
 def main():

@@ -213,15 +213,14 @@ def conv2d(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray], operand_round=
     else:
         xp = np.pad(x, ((0, 0), (0, 0), (ph, ph), (pw, pw)))
         out = np.zeros((B, Co, H, W), dtype=np.result_type(x.dtype, w.dtype))
+        # one GEMM per tap on the shifted window (no im2col matrix: 9x less memory traffic than gathering all taps first)
+        wt = np.ascontiguousarray(w.transpose(2, 3, 0, 1))          # [kh][kw][Co][Ci]
         for b_ in range(B):
-            cols = np.empty((Ci * kh * kw, H * W), dtype=x.dtype)
-            r = 0
-            for c in range(Ci):
-                for dy in range(kh):
-                    for dx in range(kw):
-                        cols[r] = xp[b_, c, dy:dy + H, dx:dx + W].reshape(-1)
-                        r += 1
-            out[b_] = (w.reshape(Co, -1) @ cols).reshape(Co, H, W)
+            acc = np.zeros((Co, H * W), dtype=out.dtype)
+            for dy in range(kh):
+                for dx in range(kw):
+                    acc += wt[dy, dx] @ np.ascontiguousarray(xp[b_, :, dy:dy + H, dx:dx + W]).reshape(Ci, -1)
+            out[b_] = acc.reshape(Co, H, W)
     if b is not None:
         out = out + b[None, :, None, None]
     return out
