@@ -1,0 +1,51 @@
+// conv_common.h -- definitions shared by the two MFMA convolution kernels (conv_mfma.hip: direct implicit GEMM,
+// conv_wino.hip: Winograd F(2,3) along W) of libflowdec_hip.so.
+#pragma once
+#include "common.h"
+#include "internal.h"
+
+namespace fdconv {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ROWB = 80;   // halo row pitch in LDS (64 B of data + 16 B pad: conflict-free b128 reads at any tap offset)
+constexpr int WROWB = 64;  // weight row pitch, global (packed) and LDS: no padding -- the four 16-B columns of row r are
+                           // stored XOR-swizzled by (r >> 2) & 3, which makes the b128 fragment reads conflict-free too
+                           // and keeps the LDS-DMA traffic at exactly the useful bytes
+constexpr int PITCH = 24;  // halo row pitch in pixels
+
+struct Seg {
+  const void* src;
+  int C;         // channels of this tensor
+  int aff_off;   // channel offset into the affine table, or -1 (no activation)
+  int taps;      // 9 or 1
+};
+
+struct ConvArgs {
+  Seg seg[4];
+  int nseg;
+  const float* affine; int affC;   // [B][affC][2]
+  const void* w;                   // packed [step][CoutPad][WROWB bytes]
+  long long w_bytes;
+  const float* bias; int bias_rows;
+  const void* skip;
+  float scale;
+  void* out;
+  int Cout, CoutPad;
+  float* stats;                    // [B][tiles_h*tiles_w][CoutPad][2] or null
+  unsigned long long* dbg;         // FD_TIMING2 builds only
+  int B, H, W;
+  int tiles_h, tiles_w, tiles_n;
+};
+
+
+constexpr int AFF_BYTES = 512 * 8;  // per-(b,c) (a,d) pairs of up to 512 activated input channels, staged in LDS
+
+}  // namespace fdconv
+
+// conv_wino.hip
+long long fd_wino_packed_bytes(int Cout, int C0, int C1, int S0, int S1);
+int fd_wino_pack_weights(const float* w, const float* w_sc, void* packed, int Cout, int C0, int C1, int S0, int S1, hipStream_t st);
+int fd_wino_launch(fdconv::ConvArgs a, hipStream_t st);
+int fd_wino_init_attributes();
+bool fd_wino_supported(int Cout, int C0, int C1, int S0, int S1, int ksize);

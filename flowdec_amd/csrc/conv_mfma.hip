@@ -27,42 +27,11 @@
 
 #include <type_traits>
 
-#include "common.h"
-#include "internal.h"
+#include "conv_common.h"
 
 namespace {
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int ROWB = 80;   // halo row pitch in LDS (64 B of data + 16 B pad: conflict-free b128 reads at any tap offset)
-constexpr int WROWB = 64;  // weight row pitch, global (packed) and LDS: no padding -- the four 16-B columns of row r are
-                           // stored XOR-swizzled by (r >> 2) & 3, which makes the b128 fragment reads conflict-free too
-                           // and keeps the LDS-DMA traffic at exactly the useful bytes
-constexpr int PITCH = 24;  // halo row pitch in pixels
-
-struct Seg {
-  const void* src;
-  int C;         // channels of this tensor
-  int aff_off;   // channel offset into the affine table, or -1 (no activation)
-  int taps;      // 9 or 1
-};
-
-struct ConvArgs {
-  Seg seg[4];
-  int nseg;
-  const float* affine; int affC;   // [B][affC][2]
-  const void* w;                   // packed [step][CoutPad][WROWB bytes]
-  long long w_bytes;
-  const float* bias; int bias_rows;
-  const void* skip;
-  float scale;
-  void* out;
-  int Cout, CoutPad;
-  float* stats;                    // [B][tiles_h*tiles_w][CoutPad][2] or null
-  unsigned long long* dbg;         // FD_TIMING2 builds only
-  int B, H, W;
-  int tiles_h, tiles_w, tiles_n;
-};
+using namespace fdconv;
 
 template <typename T>
 struct Math;
@@ -115,7 +84,6 @@ __device__ __forceinline__ u32x4 transform_slot(u32x4 raw, const char* ad) {
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-constexpr int AFF_BYTES = 512 * 8;  // per-(b,c) (a,d) pairs of up to 512 activated input channels, staged in LDS
 
 template <int WM, int WN, int MT, int NT>
 struct Geo {
@@ -730,6 +698,7 @@ int fd_conv_init_attributes() {
   if (done) return FD_OK;
   FD_TRY((set_attr<bf16, 4, 1, 2, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2>()));
   FD_TRY((set_attr<float, 4, 1, 2, 1>())); FD_TRY((set_attr<float, 4, 2, 2, 2>())); FD_TRY((set_attr<float, 2, 4, 4, 2>()));
+  FD_TRY(fd_wino_init_attributes());
   done = true;
   return FD_OK;
 }
@@ -746,6 +715,7 @@ extern "C" int fd_conv_cout_pad(int Cout) { return cout_pad(Cout); }
 extern "C" int fd_conv_stats_tiles(int H, int W) { return fd_cdiv(H, 16) * fd_cdiv(W, 16); }
 
 extern "C" long long fd_conv_packed_bytes(int Cout, int C0, int C1, int ksize, int S0, int S1, int wdtype) {
+  if (wdtype & FD_WINOGRAD) return fd_wino_supported(Cout, C0, C1, S0, S1, ksize) && (wdtype & 0xff) == FD_BF16 ? fd_wino_packed_bytes(Cout, C0, C1, S0, S1) : 0;
   const int CK = wdtype == FD_BF16 ? 32 : 16;
   // + 1 KiB slack: the DMA of a partial last 1-KiB piece (BN = 32 configuration) over-reads past the final slab
   return (long long)(n_steps(C0, C1, ksize * ksize, CK) + n_steps(S0, S1, 1, CK)) * cout_pad(Cout) * WROWB + 1024;
@@ -755,8 +725,13 @@ extern "C" int fd_conv_pack_weights(const float* w, const float* w_sc, void* pac
                                     int S1, int wdtype, void* stream) {
   FD_REQUIRE(w && packed, "fd_conv_pack_weights: null pointer");
   FD_REQUIRE(ksize == 1 || ksize == 3, "fd_conv_pack_weights: ksize must be 1 or 3");
-  FD_REQUIRE(wdtype == FD_BF16 || wdtype == FD_F32, "fd_conv_pack_weights: bad dtype");
   FD_REQUIRE((S0 + S1 == 0) == (w_sc == nullptr), "fd_conv_pack_weights: shortcut weight / channel mismatch");
+  if (wdtype & FD_WINOGRAD) {
+    FD_REQUIRE((wdtype & 0xff) == FD_BF16 && fd_wino_supported(Cout, C0, C1, S0, S1, ksize),
+               "fd_conv_pack_weights: FD_WINOGRAD needs bf16 storage, ksize 3, Cout %% 128 == 0 and channel counts %% 32 == 0");
+    return fd_wino_pack_weights(w, w_sc, packed, Cout, C0, C1, S0, S1, fd_stream(stream));
+  }
+  FD_REQUIRE(wdtype == FD_BF16 || wdtype == FD_F32, "fd_conv_pack_weights: bad dtype");
   const int taps = ksize * ksize, CoutPad = cout_pad(Cout), CK = wdtype == FD_BF16 ? 32 : 16;
   hipStream_t st = fd_stream(stream);
   auto run = [&](const float* src, int c0, int c1, int tp, long long step0) {
@@ -778,6 +753,10 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
                          float scale, void* out, int Cout, float* stats, int B, int H, int W, int ksize, int dtype, void* stream) {
   FD_REQUIRE(in0 && packed_w && out, "fd_conv2d: null pointer");
   FD_REQUIRE(ksize == 1 || ksize == 3, "fd_conv2d: ksize must be 1 or 3 (got %d)", ksize);
+  const bool wino = (dtype & FD_WINOGRAD) != 0;
+  dtype &= 0xff;
+  FD_REQUIRE(!wino || (dtype == FD_BF16 && fd_wino_supported(Cout, C0, C1, S0, S1, ksize)),
+             "fd_conv2d: FD_WINOGRAD needs bf16 storage, ksize 3, Cout %% 128 == 0 and channel counts %% 32 == 0");
   FD_REQUIRE(dtype == FD_BF16 || dtype == FD_F32, "fd_conv2d: dtype must be FD_BF16 (bf16 MFMA) or FD_F32 (f32 MFMA)");
   FD_REQUIRE(C0 > 0 && C0 % 8 == 0 && C1 >= 0 && C1 % 8 == 0, "fd_conv2d: input channels must be multiples of 8 (C0=%d C1=%d)", C0, C1);
   FD_REQUIRE(S0 >= 0 && S0 % 8 == 0 && S1 >= 0 && S1 % 8 == 0, "fd_conv2d: shortcut channels must be multiples of 8 (S0=%d S1=%d)", S0, S1);
@@ -800,11 +779,12 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   if (S1) a.seg[ns++] = Seg{sc1, S1, -1, 1};
   a.nseg = ns;
   a.affine = affine; a.affC = C0 + C1;
-  a.w = packed_w; a.w_bytes = fd_conv_packed_bytes(Cout, C0, C1, ksize, S0, S1, dtype);
+  a.w = packed_w; a.w_bytes = fd_conv_packed_bytes(Cout, C0, C1, ksize, S0, S1, dtype | (wino ? FD_WINOGRAD : 0));
   a.bias = bias; a.bias_rows = bias_rows; a.skip = skip; a.scale = scale; a.out = out; a.Cout = Cout; a.CoutPad = cout_pad(Cout);
   a.stats = stats; a.B = B; a.H = H; a.W = W; a.dbg = g_dbg;
   FD_REQUIRE(a.w_bytes < (1ll << 31), "fd_conv2d: packed weights exceed 2 GiB");
   FD_REQUIRE(affine == nullptr || (C0 + C1) * 8 <= AFF_BYTES, "fd_conv2d: at most %d activated input channels", AFF_BYTES / 8);
+  if (wino) return fd_wino_launch(a, fd_stream(stream));
   if (dtype == FD_BF16) return dispatch_conv<bf16>(a, fd_stream(stream));
   return dispatch_conv<float>(a, fd_stream(stream));
 }

@@ -33,6 +33,11 @@ extern "C" {
 
 #define FD_F32 0
 #define FD_BF16 1
+/* Algorithm flag, OR-ed into the `dtype` / `wdtype` / `act_dtype` arguments that select a convolution (storage type =
+ * value & 0xff): 3x3 convolutions with Cout % 128 == 0 and all channel counts % 32 == 0 run as Winograd F(2,3) along W
+ * (1.5x fewer MFMAs; bf16 storage, fp16 MFMA operands, f32 accumulation; conv_wino.hip).  The packed weights of the two
+ * algorithms differ: pack and launch with the same flag. */
+#define FD_WINOGRAD 0x100
 
 /* solver ids (flowdec/model.py:487 'euler'/'midpoint' via torchdyn; sampling/solvers.py:15-57) */
 #define FD_SOLVER_EULER 0

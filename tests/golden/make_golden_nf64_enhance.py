@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""G17: the REAL reference `FlowModel.enhance` at full width (nf = 64, FlowDec-75m topology) on one 0.5 s clip, for the
+headline solver settings (Euler N=6, midpoint N=3 = NFE 6).  Runs only in the build container (imports /root/reference
+through the stub recipe of make_golden.py); only the arrays travel.  Weights are re-derived in the tests from
+`oracle.flowdec_oracle.random_state_dict(seed=64, nf=64)`.
+
+    python tests/golden/make_golden_nf64_enhance.py      # ~1-2 min of CPU, writes tests/golden/g17_enhance_nf64.npz
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as MG  # noqa: E402
+from oracle import flowdec_oracle as O  # noqa: E402
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+    MG._install_stubs()
+    from flowdec.backbones.ncsnpp import NCSNpp
+    from flowdec.data.feature_extractors import AmplitudeCompressedComplexSTFT
+    from flowdec.data import sigma_models
+    from flowdec.model import FlowModel
+
+    bb_kw = dict(nonlinearity="swish", ch_mult=(4, 4, 4, 2), num_res_blocks=1, attn_resolutions=[], resamp_with_conv=True,
+                 conditional=True, fir=True, fir_kernel=[1, 3, 3, 1], skip_rescale=True, resblock_type="biggan",
+                 progressive="output_skip", progressive_input="input_skip", progressive_combine="sum", init_scale=0.0,
+                 fourier_scale=16, image_size=768, embedding_type="fourier", dropout=0.0, num_channels=4,
+                 output_layer_kwargs=dict(kernel_size=1, bias=False, padding="same", padding_mode="zeros"),
+                 bottleneck_attn=False)
+    fe = AmplitudeCompressedComplexSTFT(window_fn="hann", n_fft=1534, n_hops=4, sampling_rate=48000, alpha=0.3, beta=0.33)
+    sig = sigma_models.from_file(os.path.join(MG.REF, "data", "flowdec_autoparams_75m.npy"), factor=1, kernel_bandwidth=3)
+    fm = FlowModel(flow_matcher=None, sigma_x=0.0, sigma_y=sig, backbone=NCSNpp(nf=64, **bb_kw), feature_extractor=fe,
+                   sampling_rate=48000, lr=1e-4, full_config={}).eval()
+    sd = O.random_state_dict(seed=64, nf=64)
+    fm.backbone.load_state_dict(MG.to_t(MG.strip(sd, "backbone.")))
+    rng = np.random.default_rng(1764)
+    L = 24000
+    y = (0.1 * rng.standard_normal((1, 1, L))).astype(np.float32)
+    Tp = O.padded_frames(O.num_frames(L))
+    noise = MG.crandn(rng, (1, 1, 768, Tp))
+    noise_t = torch.from_numpy(noise)
+    fm._get_noise = lambda x, sigma: (sigma * noise_t[:x.shape[0]]).type(x.dtype)  # same arithmetic as model.py:536
+    g = dict(y=y, noise=noise, sigma_y=sig.numpy(), seed=np.int64(64))
+    for solver, N in (("euler", 6), ("midpoint", 3)):
+        t0 = time.time()
+        xh = fm.enhance(torch.from_numpy(y), N=N, solver=solver)
+        print(f"{solver} N={N}: {time.time() - t0:.1f} s on {torch.get_num_threads()} threads", flush=True)
+        g[f"{solver}_N{N}"] = xh.numpy()
+    np.savez_compressed(os.path.join(HERE, "g17_enhance_nf64.npz"), **g)
+    print("g17_enhance_nf64.npz", os.path.getsize(os.path.join(HERE, "g17_enhance_nf64.npz")) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
