@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflowdec_hip.so")
+LIB_PATH = os.environ.get("FLOWDEC_HIP_LIB") or os.path.join(_HERE, "libflowdec_hip.so")  # (env: kernel-variant A/B runs)
 
 FD_F32, FD_BF16 = 0, 1
 FD_WINOGRAD = 0x100  # algorithm flag OR-ed into a dtype argument (include/flowdec_hip.h)

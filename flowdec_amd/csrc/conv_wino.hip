@@ -91,6 +91,71 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+
+// ---- the MFMA cluster of one phase, hand-placed (inline asm): 8 MFMAs (2 patches x 4 cout tiles of one k-half) with the 8
+// operand reads of the NEXT phase between them.  hipcc's scheduler otherwise pairs every MFMA with a wait for the read it
+// has just issued; here nothing in the cluster waits, and the two waves of a SIMD take turns: one runs its cluster on the
+// matrix pipe (s_setprio 1) while the other does its VALU segment (Winograd transform, halo conversion).
+// The reads are invisible to hipcc's counters: wait_ops() is the matching s_waitcnt and (re)defines the registers for it.
+__device__ __forceinline__ void wait_ops(u32x4 (&wf)[4], u32x4 (&ra)[2], u32x4 (&rb)[2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]), "+v"(rb[1])
+               :: "memory");
+}
+// wb / pa / pb: LDS byte addresses of the lane's first weight row / of its pixel in patch 0 for the two transform operands;
+// WOFF, HOFF: compile-time offsets (ring slot; halo row, k-half).  Cout tiles are 2048 B apart (the swizzle does not depend on
+// the tile), the second patch is 4 halo rows further.
+template <int WOFF, int HOFF>
+__device__ __forceinline__ void mma_cluster(f32x16 (&acc)[2][4], const u32x4 (&wf)[4], const u32x4 (&pf)[2], u32x4 (&nwf)[4],
+                                            u32x4 (&nra)[2], u32x4 (&nrb)[2], int wb, int pa, int pb) {
+  constexpr int P1 = 4 * WP * ROWB;
+  asm volatile(
+      "s_nop 1\n\t"
+      "s_setprio 1\n\t"
+      "v_mfma_f32_32x32x16_f16 %[a00], %[w0], %[p0], %[a00]\n\t"
+      "ds_read_b128 %[nw0], %[wb] offset:%[o0]\n\t"
+      "ds_read_b128 %[nw1], %[wb] offset:%[o1]\n\t"
+      "v_mfma_f32_32x32x16_f16 %[a10], %[w0], %[p1], %[a10]\n\t"
+      "ds_read_b128 %[nw2], %[wb] offset:%[o2]\n\t"
+      "ds_read_b128 %[nw3], %[wb] offset:%[o3]\n\t"
+      "v_mfma_f32_32x32x16_f16 %[a01], %[w1], %[p0], %[a01]\n\t"
+      "ds_read_b128 %[na0], %[pa] offset:%[h0]\n\t"
+      "ds_read_b128 %[nb0], %[pb] offset:%[h0]\n\t"
+      "v_mfma_f32_32x32x16_f16 %[a11], %[w1], %[p1], %[a11]\n\t"
+      "ds_read_b128 %[na1], %[pa] offset:%[h1]\n\t"
+      "ds_read_b128 %[nb1], %[pb] offset:%[h1]\n\t"
+      "v_mfma_f32_32x32x16_f16 %[a02], %[w2], %[p0], %[a02]\n\t"
+      "v_mfma_f32_32x32x16_f16 %[a12], %[w2], %[p1], %[a12]\n\t"
+      "v_mfma_f32_32x32x16_f16 %[a03], %[w3], %[p0], %[a03]\n\t"
+      "v_mfma_f32_32x32x16_f16 %[a13], %[w3], %[p1], %[a13]\n\t"
+      "s_setprio 0"
+      : [a00] "+v"(acc[0][0]), [a10] "+v"(acc[1][0]), [a01] "+v"(acc[0][1]), [a11] "+v"(acc[1][1]), [a02] "+v"(acc[0][2]),
+        [a12] "+v"(acc[1][2]), [a03] "+v"(acc[0][3]), [a13] "+v"(acc[1][3]), [nw0] "=&v"(nwf[0]), [nw1] "=&v"(nwf[1]),
+        [nw2] "=&v"(nwf[2]), [nw3] "=&v"(nwf[3]), [na0] "=&v"(nra[0]), [na1] "=&v"(nra[1]), [nb0] "=&v"(nrb[0]), [nb1] "=&v"(nrb[1])
+      : [w0] "v"(wf[0]), [w1] "v"(wf[1]), [w2] "v"(wf[2]), [w3] "v"(wf[3]), [p0] "v"(pf[0]), [p1] "v"(pf[1]), [wb] "v"(wb), [pa] "v"(pa),
+        [pb] "v"(pb), [o0] "i"(WOFF), [o1] "i"(WOFF + 2048), [o2] "i"(WOFF + 4096), [o3] "i"(WOFF + 6144), [h0] "i"(HOFF), [h1] "i"(HOFF + P1)
+      : "memory");
+}
+// the same reads without MFMAs (prologue)
+template <int WOFF, int HOFF>
+__device__ __forceinline__ void read_cluster(u32x4 (&nwf)[4], u32x4 (&nra)[2], u32x4 (&nrb)[2], int wb, int pa, int pb) {
+  constexpr int P1 = 4 * WP * ROWB;
+  asm volatile(
+      "ds_read_b128 %[nw0], %[wb] offset:%[o0]\n\t"
+      "ds_read_b128 %[nw1], %[wb] offset:%[o1]\n\t"
+      "ds_read_b128 %[nw2], %[wb] offset:%[o2]\n\t"
+      "ds_read_b128 %[nw3], %[wb] offset:%[o3]\n\t"
+      "ds_read_b128 %[na0], %[pa] offset:%[h0]\n\t"
+      "ds_read_b128 %[nb0], %[pb] offset:%[h0]\n\t"
+      "ds_read_b128 %[na1], %[pa] offset:%[h1]\n\t"
+      "ds_read_b128 %[nb1], %[pb] offset:%[h1]"
+      : [nw0] "=&v"(nwf[0]), [nw1] "=&v"(nwf[1]), [nw2] "=&v"(nwf[2]), [nw3] "=&v"(nwf[3]), [na0] "=&v"(nra[0]), [na1] "=&v"(nra[1]),
+        [nb0] "=&v"(nrb[0]), [nb1] "=&v"(nrb[1])
+      : [wb] "v"(wb), [pa] "v"(pa), [pb] "v"(pb), [o0] "i"(WOFF), [o1] "i"(WOFF + 2048), [o2] "i"(WOFF + 4096), [o3] "i"(WOFF + 6144),
+        [h0] "i"(HOFF), [h1] "i"(HOFF + P1)
+      : "memory");
+}
+
 template <bool ACT, bool SKIP>
 __global__ __launch_bounds__(NTH, 2) void conv_wino_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -216,24 +281,18 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino_kernel(ConvArgs p) {
   int al = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
   int be = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
   float sg = xi == 1 ? 1.f : -1.f;
-  int pa0[2], pb0[2];   // halo buffer 0
+  int pa0, pb0;   // patch 0 of this wave in halo buffer 0 (patch 1 = 4 halo rows further)
   auto set_pixel_bases = [&](int koff) {
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int base = HALO_OFF + ((4 * (2 * ph + mi) + pr) * WP + 2 * pj) * ROWB + lh * 16 + koff;
-      pa0[mi] = base + al * ROWB;
-      pb0[mi] = base + be * ROWB;
-    }
+    const int base = HALO_OFF + ((4 * (2 * ph) + pr) * WP + 2 * pj) * ROWB + lh * 16 + koff;
+    pa0 = base + al * ROWB;
+    pb0 = base + be * ROWB;
   };
   set_pixel_bases(0);
   f16x2 sig2 = {(f16)sg, (f16)sg};
-  int wb0[4], wb1[4];   // [k-half][nj]: slabs of xi, row = cout, 16-B column (2 * ks + lh) ^ swizzle(row)
-#pragma unroll
-  for (int nj = 0; nj < 4; ++nj) {
-    const int row = nj * 32 + l31, sw = (row >> 2) & 3;
-    wb0[nj] = xi * NRING * SLAB + row * WROWB + ((lh ^ sw) * 16);
-    wb1[nj] = xi * NRING * SLAB + row * WROWB + (((2 + lh) ^ sw) * 16);
-  }
+  // [k-half]: slabs of xi, row = cout (tile nj = + nj * 2048), 16-B column (2 * ks + lh) ^ swizzle(row)
+  const int wsw = (l31 >> 2) & 3;
+  int wb0 = xi * NRING * SLAB + l31 * WROWB + ((lh ^ wsw) * 16);
+  const int wb1 = xi * NRING * SLAB + l31 * WROWB + (((2 + lh) ^ wsw) * 16);
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -275,16 +334,6 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino_kernel(ConvArgs p) {
   using K0 = std::integral_constant<int, 0>;
 
   u32x4 wfA[4], wfB[4], raA[2], rbA[2], raB[2], rbB[2], pfA[2], pfB[2];
-  // operand fragments: `hoff` = byte offset of the halo buffer + row / k-half immediates, `woff` = slot * SLAB
-  auto read_ops = [&](u32x4 (&wf)[4], u32x4 (&ra)[2], u32x4 (&rb)[2], const int (&wbx)[4], int woff, int hoff) {
-#pragma unroll
-    for (int nj = 0; nj < 4; ++nj) wf[nj] = *reinterpret_cast<const u32x4*>(smem + wbx[nj] + woff);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      ra[mi] = *reinterpret_cast<const u32x4*>(smem + pa0[mi] + hoff);
-      rb[mi] = *reinterpret_cast<const u32x4*>(smem + pb0[mi] + hoff);
-    }
-  };
   // Winograd input transform of a fragment: 4 x v_pk_fma_f16
   auto combine = [&](u32x4 (&pf)[2], const u32x4 (&ra)[2], const u32x4 (&rb)[2]) {
 #pragma unroll
@@ -297,23 +346,6 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino_kernel(ConvArgs p) {
         pf[mi][j] = __builtin_bit_cast(unsigned, r);
       }
   };
-  auto mma8 = [&](const u32x4 (&wf)[4], const u32x4 (&pf)[2]) {
-#pragma unroll
-    for (int nj = 0; nj < 4; ++nj)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-        acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[nj]), __builtin_bit_cast(f16x8, pf[mi]), acc[mi][nj], 0, 0, 0);
-#ifndef FD_NO_SGB
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS read
-      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // 5 VALU
-      __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);   // 2 SALU
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
-    }
-#endif
-  };
   // the shortcut steps use other operand selectors: positions 0 / 3 take k-half 0 with x(y0) / x(y1) (weights W / -W),
   // positions 1 / 2 take k-half 1 with x(y0) +- x(y1) (weights W / 2)
   auto switch_to_shortcut = [&]() {
@@ -323,11 +355,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino_kernel(ConvArgs p) {
     const int ksc = (xi == 1 || xi == 2) ? 1 : 0;
     set_pixel_bases(32 * ksc);
     sig2 = f16x2{(f16)sg, (f16)sg};
-#pragma unroll
-    for (int nj = 0; nj < 4; ++nj) {
-      const int row = nj * 32 + l31, sw = (row >> 2) & 3;
-      wb0[nj] = xi * NRING * SLAB + row * WROWB + (((2 * ksc + lh) ^ sw) * 16);
-    }
+    wb0 = xi * NRING * SLAB + l31 * WROWB + (((2 * ksc + lh) ^ wsw) * 16);
   };
   using TACT = std::integral_constant<bool, ACT>;
   using TRAW = std::integral_constant<bool, false>;
@@ -352,7 +380,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino_kernel(ConvArgs p) {
 #ifdef FD_TIMING2
   const unsigned long long t2_first = __builtin_amdgcn_s_memtime();
 #endif
-  read_ops(wfA, raA, rbA, wb0, 0, 0);
+  read_cluster<0, 0>(wfA, raA, rbA, wb0, pa0, pb0);
 
   int step = 0, hcur = 0;
   constexpr int CENTER = WP * ROWB;   // row offset of the output row itself (dy = 1)
@@ -364,46 +392,47 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino_kernel(ConvArgs p) {
   // follow in phase B2.  sched_barrier(0) pins the phase boundaries (hipcc otherwise hoists the conversion -- and its wait --
   // right behind the loads).
   auto chunk_body = [&](auto next_tag, bool to_shortcut) {
-    const int hb = hcur * HALO_BYTES, hbn = (hcur ^ 1) * HALO_BYTES;
     const int nb = hcur ^ 1;
+    const int pac = pa0 + hcur * HALO_BYTES, pbc = pb0 + hcur * HALO_BYTES;
     // ---------------- dy = 0
+    wait_ops(wfA, raA, rbA);
     combine(pfA, raA, rbA);
-    read_ops(wfB, raB, rbB, wb1, 0 * SLAB, hb + 0 * CENTER + 32);
-    mma8(wfA, pfA);
+    mma_cluster<0 * SLAB, 0 * CENTER + 32>(acc, wfA, pfA, wfB, raB, rbB, wb1, pac, pbc);
     step_barrier(K7{});
+    wait_ops(wfB, raB, rbB);
     combine(pfB, raB, rbB);
     conv_words(next_tag, 0, 3, nb);
-    read_ops(wfA, raA, rbA, wb0, 1 * SLAB, hb + 1 * CENTER);
-    mma8(wfB, pfB);
-    __builtin_amdgcn_sched_barrier(0);
+    mma_cluster<1 * SLAB, 1 * CENTER>(acc, wfB, pfB, wfA, raA, rbA, wb0, pac, pbc);
     // (the weight pieces go out at the END of the phase: hipcc does not count them, so its own wait for the first halo word
     // above -- vmcnt(2) by its count -- would otherwise also cover pieces issued in front of it)
     dma_step(step + 3 <= last_step ? step + 3 : last_step, 0);
     // ---------------- dy = 1
+    wait_ops(wfA, raA, rbA);
     combine(pfA, raA, rbA);
     conv_words(next_tag, 3, 6, nb);
-    read_ops(wfB, raB, rbB, wb1, 1 * SLAB, hb + 1 * CENTER + 32);
-    mma8(wfA, pfA);
+    mma_cluster<1 * SLAB, 1 * CENTER + 32>(acc, wfA, pfA, wfB, raB, rbB, wb1, pac, pbc);
     step_barrier(K4{});
+    wait_ops(wfB, raB, rbB);
     combine(pfB, raB, rbB);
     conv_words(next_tag, 6, 9, nb);
-    read_ops(wfA, raA, rbA, wb0, 2 * SLAB, hb + 2 * CENTER);
-    mma8(wfB, pfB);
-    __builtin_amdgcn_sched_barrier(0);
+    mma_cluster<2 * SLAB, 2 * CENTER>(acc, wfB, pfB, wfA, raA, rbA, wb0, pac, pbc);
     dma_step(step + 4 <= last_step ? step + 4 : last_step, 1);
     // ---------------- dy = 2
+    wait_ops(wfA, raA, rbA);
     combine(pfA, raA, rbA);
     conv_words(next_tag, 9, 12, nb);
-    read_ops(wfB, raB, rbB, wb1, 2 * SLAB, hb + 2 * CENTER + 32);
-    mma8(wfA, pfA);
+    mma_cluster<2 * SLAB, 2 * CENTER + 32>(acc, wfA, pfA, wfB, raB, rbB, wb1, pac, pbc);
     step_barrier(K4{});   // halo of the next chunk published
+    wait_ops(wfB, raB, rbB);
     combine(pfB, raB, rbB);
     next_chunk();
     load_halo();
-    if (to_shortcut) switch_to_shortcut();
-    read_ops(wfA, raA, rbA, wb0, 0 * SLAB, hbn + (to_shortcut ? CENTER : 0));
-    mma8(wfB, pfB);
-    __builtin_amdgcn_sched_barrier(0);
+    if (to_shortcut) {
+      switch_to_shortcut();
+      mma_cluster<0 * SLAB, CENTER>(acc, wfB, pfB, wfA, raA, rbA, wb0, pa0 + nb * HALO_BYTES, pb0 + nb * HALO_BYTES);
+    } else {
+      mma_cluster<0 * SLAB, 0>(acc, wfB, pfB, wfA, raA, rbA, wb0, pa0 + nb * HALO_BYTES, pb0 + nb * HALO_BYTES);
+    }
     dma_step(step + 5 <= last_step ? step + 5 : last_step, 2);
     step += 3;
     hcur ^= 1;
@@ -419,17 +448,20 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino_kernel(ConvArgs p) {
   // ---- folded 1x1 shortcut: one step per chunk, half a K step (8 MFMAs) per wave.  Same pipeline with short steps: the halo
   // of the next chunk is in registers, converted and stored before the barrier; the loads of the chunk after it follow.
   for (int i = 0; i < n1; ++i) {
-    const int hbn = (hcur ^ 1) * HALO_BYTES;
+    const int nb = hcur ^ 1;
     const int slot = step % NRING, slotn = (step + 1) % NRING;
+    wait_ops(wfA, raA, rbA);
     combine(pfA, raA, rbA);
-    mma8(wfA, pfA);
-    conv_words(TRAW{}, 0, 12, hcur ^ 1);
+    conv_words(TRAW{}, 0, 12, nb);
     __builtin_amdgcn_sched_barrier(0);
     next_chunk();
     load_halo();
+    // 8 MFMAs of this step; the operand reads of the next step follow the barrier (they need its halo and weights)
+    mma_cluster<0, 0>(acc, wfA, pfA, wfB, raB, rbB, wb0, pa0, pb0);   // (the reads of this call are dummies)
     step_barrier(K7{});
     dma_step(step + 3 <= last_step ? step + 3 : last_step, slot);
-    read_ops(wfA, raA, rbA, wb0, slotn * SLAB, hbn + CENTER);
+    wait_ops(wfB, raB, rbB);
+    read_cluster<0, CENTER>(wfA, raA, rbA, wb0 + slotn * SLAB, pa0 + nb * HALO_BYTES, pb0 + nb * HALO_BYTES);
     ++step; hcur ^= 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
