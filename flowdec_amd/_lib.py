@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("FLOWDEC_HIP_LIB") or os.path.join(_HERE, "libflowdec_
 
 FD_F32, FD_BF16 = 0, 1
 FD_WINOGRAD = 0x100  # algorithm flag OR-ed into a dtype argument (include/flowdec_hip.h)
+FD_WINOGRAD_LOWRES = 0x200
 SOLVERS = {"euler": 0, "midpoint": 1, "heun2": 2, "heun2_eulerlast": 3}
 
 c_void_p, c_int, c_float, c_ll, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -60,12 +61,14 @@ SIGNATURES = {
     "fd_conv_stats_tiles": (c_int, [c_int, c_int]),
     "fd_conv2d": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P, c_int, _P, c_float, _P, c_int, _P,
                           c_int, c_int, c_int, c_int, c_int, _P]),
-    "fd_tuning_set": (c_int, [C.c_char_p, c_int]),
     "fd_time_embedding": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, _P]),
     "fd_temb_bias": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
     "fd_stft_workspace_bytes": (c_size_t, [c_int] * 4),
-    "fd_stft_compress": (c_int, [_P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, _P, _P, c_int, _P, c_size_t, _P]),
-    "fd_decompress_istft": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, c_int, _P, c_size_t, _P]),
+    "fd_stft_plan_create": (c_int, [c_int, c_int, C.POINTER(c_void_p)]),
+    "fd_stft_plan_destroy": (None, [_P]),
+    "fd_stft_compress": (c_int, [_P, _P, c_int, c_int, c_float, c_float, c_int, _P, _P, c_int, _P, c_size_t, _P]),
+    "fd_decompress_istft": (c_int, [_P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, c_int, _P, c_size_t, _P]),
+    "fd_compress_spec": (c_int, [_P, _P, c_ll, c_float, c_float, c_int, _P]),
     "fd_num_frames": (c_int, [c_int, c_int]),
     "fd_padded_frames": (c_int, [c_int]),
     "fd_model_create": (c_int, [C.POINTER(FdModelConfig), C.POINTER(_P)]),
@@ -81,6 +84,8 @@ SIGNATURES = {
     "fd_ode_adaptive_workspace_bytes": (c_size_t, [_P, c_int, c_int]),
     "fd_ode_solve_adaptive": (c_int, [_P, _P, _P, c_float, c_int, c_float, c_float, _P, _P, C.POINTER(c_int), c_int, c_int, _P, c_size_t, _P]),
     "fd_enhance_workspace_bytes": (c_size_t, [_P, c_int, c_int]),
+    "fd_enhance_normfac_offset": (c_size_t, [_P, c_int, c_int]),
+    "fd_model_set_normalize": (c_int, [_P, c_int]),
     "fd_enhance": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "fd_score_num_draws": (c_int, [C.POINTER(FdScoreConfig)]),
     "fd_score_enhance": (c_int, [_P, _P, _P, C.POINTER(FdScoreConfig), _P, c_int, c_int, _P, c_size_t, c_int, _P]),
@@ -88,6 +93,7 @@ SIGNATURES = {
     "fd_regression_enhance": (c_int, [_P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "fd_profile_enable": (c_int, [_P, c_int]),
     "fd_profile_read": (c_int, [_P, C.POINTER(C.c_double), C.POINTER(c_ll), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "fd_profile_read_fir": (c_int, [_P, C.POINTER(C.c_double), C.POINTER(c_ll), C.POINTER(C.c_double)]),
 }
 
 _lib = None

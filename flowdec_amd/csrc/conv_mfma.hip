@@ -25,6 +25,7 @@
 //     squares of the f32 result are reduced per tile for the consumer GroupNorm (deterministic, no atomics).
 #include <string.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -657,8 +658,9 @@ inline int pad_to(int x, int a) { return (x + a - 1) / a * a; }
 inline int cout_pad(int Cout) { return Cout <= 32 ? 32 : (Cout <= 128 ? 128 : pad_to(Cout, 256)); }
 inline int n_steps(int C0, int C1, int taps, int CK) { return (fd_cdiv(C0, CK) + fd_cdiv(C1, CK)) * taps; }
 
-int g_variant = 0;  // tuning hook: 0 = auto, 1 = force the BN=128 config
-unsigned long long* g_dbg = nullptr;  // FD_TIMING2 builds: device buffer of 8 counters (fd_debug_buffer)
+#ifdef FD_TIMING2
+unsigned long long* g_dbg = nullptr;  // instrumented builds only: device buffer of 8 counters per workgroup (fd_debug_buffer)
+#endif
 
 template <typename T, int WM, int WN, int MT, int NT>
 int set_attr() {
@@ -687,29 +689,31 @@ int launch_conv(ConvArgs a, hipStream_t st) {
 template <typename T>
 int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   if (a.Cout <= 32) return launch_conv<T, 4, 1, 2, 1>(a, st);                             // 4 waves, BN = 32 (pyramid heads)
-  if (a.Cout <= 128 || g_variant == 1) return launch_conv<T, 4, 2, 2, 2>(a, st);         // 8 waves, BN = 128
+  if (a.Cout <= 128) return launch_conv<T, 4, 2, 2, 2>(a, st);                             // 8 waves, BN = 128
   return launch_conv<T, 2, 4, 4, 2>(a, st);                                               // 8 waves, BN = 256
 }
 
 }  // namespace
 
+// hipFuncSetAttribute (dynamic LDS above 64 KiB) is a per-device property: done once per device, thread-safe
 int fd_conv_init_attributes() {
-  static bool done = false;
-  if (done) return FD_OK;
+  static std::mutex mu;
+  static bool done_dev[64] = {};
+  int dev = 0;
+  FD_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  const bool known = dev >= 0 && dev < 64;
+  if (known && done_dev[dev]) return FD_OK;
   FD_TRY((set_attr<bf16, 4, 1, 2, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2>()));
   FD_TRY((set_attr<float, 4, 1, 2, 1>())); FD_TRY((set_attr<float, 4, 2, 2, 2>())); FD_TRY((set_attr<float, 2, 4, 4, 2>()));
   FD_TRY(fd_wino_init_attributes());
-  done = true;
+  if (known) done_dev[dev] = true;
   return FD_OK;
 }
 
-extern "C" int fd_tuning_set(const char* key, int value) {
-  FD_REQUIRE(key, "fd_tuning_set: null key");
-  if (!strcmp(key, "conv_variant")) { g_variant = value; return FD_OK; }
-  return fd_set_error(FD_EINVAL, "fd_tuning_set: unknown key '%s'", key);
-}
-
+#ifdef FD_TIMING2
 extern "C" int fd_debug_buffer(void* p) { g_dbg = reinterpret_cast<unsigned long long*>(p); return FD_OK; }
+#endif
 
 extern "C" int fd_conv_cout_pad(int Cout) { return cout_pad(Cout); }
 extern "C" int fd_conv_stats_tiles(int H, int W) { return fd_cdiv(H, 16) * fd_cdiv(W, 16); }
@@ -781,7 +785,10 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   a.affine = affine; a.affC = C0 + C1;
   a.w = packed_w; a.w_bytes = fd_conv_packed_bytes(Cout, C0, C1, ksize, S0, S1, dtype | (wino ? FD_WINOGRAD : 0));
   a.bias = bias; a.bias_rows = bias_rows; a.skip = skip; a.scale = scale; a.out = out; a.Cout = Cout; a.CoutPad = cout_pad(Cout);
-  a.stats = stats; a.B = B; a.H = H; a.W = W; a.dbg = g_dbg;
+  a.stats = stats; a.B = B; a.H = H; a.W = W;
+#ifdef FD_TIMING2
+  a.dbg = g_dbg;
+#endif
   FD_REQUIRE(a.w_bytes < (1ll << 31), "fd_conv2d: packed weights exceed 2 GiB");
   FD_REQUIRE(affine == nullptr || (C0 + C1) * 8 <= AFF_BYTES, "fd_conv2d: at most %d activated input channels", AFF_BYTES / 8);
   if (wino) return fd_wino_launch(a, fd_stream(stream));

@@ -44,9 +44,7 @@ int fd_caxpy(const float* a, const float* q, float cq, float* dst, long long n, 
 // conv_mfma.hip
 int fd_conv_init_attributes();
 // stft.hip
-struct fd_stft_plan;  // device-resident DFT matrices, window envelope
-int fd_stft_plan_create(int n_fft, int hop, fd_stft_plan** out);
-void fd_stft_plan_destroy(fd_stft_plan* p);
+// (fd_stft_plan / fd_stft_plan_create / fd_stft_plan_destroy: public, include/flowdec_hip.h)
 int fd_stft_forward(fd_stft_plan* p, const float* y, int B, int L, float alpha, float beta, int normalize, float* normfac,
                     float* Y, int T_pad, void* ws, size_t ws_bytes, hipStream_t st);
 int fd_stft_inverse(fd_stft_plan* p, const float* X, int B, int T, int T_pad, float alpha, float beta, const float* normfac,

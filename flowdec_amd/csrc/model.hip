@@ -6,7 +6,9 @@
 #include <string.h>
 
 #include <map>
+#include <set>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "common.h"
@@ -22,6 +24,8 @@ struct Mod {
   int cin = 0, cout = 0;
   int c0 = 0, c1 = 0;   // virtual-concat split of cin (RB)
   bool up = false, down = false, has_c2 = false;
+  int level = 0;                 // resolution level the block's convolutions run at (0 = full resolution)
+  bool wino0 = false, wino1 = false;   // Conv_0 / Conv_1 (+ folded Conv_2) packed for the Winograd kernel
   // device pointers (filled by finalize)
   void* w0 = nullptr; void* w1 = nullptr; void* w2 = nullptr;   // packed conv weights
   float *gn0_g = nullptr, *gn0_b = nullptr, *gn1_g = nullptr, *gn1_b = nullptr;
@@ -82,18 +86,25 @@ struct Tens {
   int tiles = 0, stride = 0;
 };
 
+// Everything a captured solve bakes into its kernel arguments.  Compared field by field (a memcmp over the struct would read
+// its padding bytes).
 struct GraphKey {
-  const void *Y, *noise, *X, *traj, *ws, *y, *xhat;
-  int B, T, N, solver, L, kind;
-  float sigma_fac;
-  fd_score_config score;   // kind 3 only (zero otherwise)
-  bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
+  const void *Y = nullptr, *noise = nullptr, *X = nullptr, *traj = nullptr, *ws = nullptr, *y = nullptr, *xhat = nullptr;
+  int B = 0, T = 0, N = 0, solver = 0, L = 0, kind = 0, normalize = 1;
+  float sigma_fac = 0.f;
+  fd_score_config score{};   // kind 3 only (zero otherwise)
+  auto tie() const {
+    return std::tie(Y, noise, X, traj, ws, y, xhat, B, T, N, solver, L, kind, normalize, sigma_fac, score.theta, score.sigma_min, score.sigma_max,
+                    score.t_eps, score.snr, score.N, score.predictor, score.corrector, score.corrector_steps, score.denoise);
+  }
+  bool operator<(const GraphKey& o) const { return tie() < o.tie(); }
 };
 
 }  // namespace
 
 struct fd_model {
   fd_model_config cfg;
+  int dt = FD_BF16;                 // storage type (cfg.act_dtype without the algorithm flags)
   int n_freq = 0, temb_dim = 0;
   std::vector<Mod> mods;
   std::vector<ParamInfo> params;
@@ -110,12 +121,18 @@ struct fd_model {
   float* wo = nullptr;              // output_layer weight [2][4]
   fd_stft_plan* stft = nullptr;
   std::map<GraphKey, hipGraphExec_t> graphs;
+  std::set<GraphKey> seen;          // keys that ran once eagerly: a solve is captured at its SECOND sighting
+  int normalize = 1;                // front end: 1 = per-clip max-abs normalisation ('noisy'), 0 = 'none'
   // profiling of the dominant kernel (conv MFMA)
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   size_t ev_used = 0;
   double prof_flops = 0.0;
   double prof_bytes = 0.0;   // algorithmic HBM bytes of the timed launches: every operand read once + output written once
+  // second class: the FIR resampling launches (HBM-bound): events + algorithmic bytes
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_fir;
+  size_t ev_fir_used = 0;
+  double prof_fir_bytes = 0.0;
   static constexpr int MAX_NT = 256;
 };
 
@@ -136,8 +153,8 @@ void build_structure(fd_model* m) {
   add_param("backbone.output_layer.weight", {2, nch, 1, 1});
   int idx = 0;
   auto push = [&](Mod md) { md.idx = idx++; mods.push_back(md); return (int)mods.size() - 1; };
-  auto add_rb = [&](int c0, int c1, int cout, bool up, bool down) {
-    Mod md{}; md.kind = M_RB; md.c0 = c0; md.c1 = c1; md.cin = c0 + c1; md.cout = cout; md.up = up; md.down = down;
+  auto add_rb = [&](int c0, int c1, int cout, bool up, bool down, int level) {
+    Mod md{}; md.kind = M_RB; md.c0 = c0; md.c1 = c1; md.cin = c0 + c1; md.cout = cout; md.up = up; md.down = down; md.level = level;
     md.has_c2 = (md.cin != cout) || up || down;
     const int i = mods[push(md)].idx;
     add_param(pref(i) + "GroupNorm_0.weight", {md.cin}); add_param(pref(i) + "GroupNorm_0.bias", {md.cin});
@@ -156,12 +173,12 @@ void build_structure(fd_model* m) {
   for (int lvl = 0; lvl < R; ++lvl) {
     for (int b = 0; b < nrb; ++b) {
       const int out_ch = nf * c.ch_mult[lvl];
-      add_rb(in_ch, 0, out_ch, false, false);
+      add_rb(in_ch, 0, out_ch, false, false, lvl);
       in_ch = out_ch;
       hs_c.push_back(in_ch);
     }
     if (lvl != R - 1) {
-      add_rb(in_ch, 0, in_ch, false, true);
+      add_rb(in_ch, 0, in_ch, false, true, lvl + 1);
       Mod md{}; md.kind = M_COMBINE; md.cin = nch; md.cout = in_ch;
       const int i = mods[push(md)].idx;
       add_param(pref(i) + "Conv_0.weight", {in_ch, nch, 1, 1}); add_param(pref(i) + "Conv_0.bias", {in_ch});
@@ -169,20 +186,20 @@ void build_structure(fd_model* m) {
     }
   }
   in_ch = hs_c.back();
-  add_rb(in_ch, 0, in_ch, false, false);
-  add_rb(in_ch, 0, in_ch, false, false);
+  add_rb(in_ch, 0, in_ch, false, false, R - 1);
+  add_rb(in_ch, 0, in_ch, false, false, R - 1);
   for (int lvl = R - 1; lvl >= 0; --lvl) {
     for (int b = 0; b < nrb + 1; ++b) {
       const int out_ch = nf * c.ch_mult[lvl];
       const int sk = hs_c.back(); hs_c.pop_back();
-      add_rb(in_ch, sk, out_ch, false, false);
+      add_rb(in_ch, sk, out_ch, false, false, lvl);
       in_ch = out_ch;
     }
     { Mod md{}; md.kind = M_GN; md.cin = in_ch; const int i = mods[push(md)].idx;
       add_param(pref(i) + "weight", {in_ch}); add_param(pref(i) + "bias", {in_ch}); }
     { Mod md{}; md.kind = M_CONV_HEAD; md.cin = in_ch; md.cout = nch; const int i = mods[push(md)].idx;
       add_param(pref(i) + "weight", {nch, in_ch, 3, 3}); add_param(pref(i) + "bias", {nch}); }
-    if (lvl != 0) add_rb(in_ch, 0, in_ch, true, false);
+    if (lvl != 0) add_rb(in_ch, 0, in_ch, true, false, lvl - 1);
   }
 }
 
@@ -199,15 +216,16 @@ int upload_f32(fd_model* m, const std::string& name, float** out) {
 }
 
 int pack_conv(fd_model* m, const std::string& name, int Cout, int C0, int C1, int ks, const std::string& sc_name, int S0, int S1,
-              void** out, hipStream_t st) {
+              void** out, hipStream_t st, int algo = 0) {
   float *src = nullptr, *sc = nullptr;
   FD_TRY(upload_f32(m, name, &src));
   if (!sc_name.empty()) FD_TRY(upload_f32(m, sc_name, &sc));
   void* dst = nullptr;
-  const long long bytes = fd_conv_packed_bytes(Cout, C0, C1, ks, S0, S1, m->cfg.act_dtype);
+  const long long bytes = fd_conv_packed_bytes(Cout, C0, C1, ks, S0, S1, m->dt | algo);
+  FD_REQUIRE(bytes > 0, "internal: no packing for conv '%s'", name.c_str());
   FD_HIP(hipMalloc(&dst, (size_t)bytes));
   m->dev_allocs.push_back(dst);
-  FD_TRY(fd_conv_pack_weights(src, sc, dst, Cout, C0, C1, ks, S0, S1, m->cfg.act_dtype, st));
+  FD_TRY(fd_conv_pack_weights(src, sc, dst, Cout, C0, C1, ks, S0, S1, m->dt | algo, st));
   *out = dst;
   return FD_OK;
 }
@@ -263,7 +281,7 @@ struct Fwd {
   }
   // out = scale * (conv_k(act([a|b])) + conv_1x1([s0|s1]) + bias + skip); optionally emits the GroupNorm partials of out
   int conv(const Tens& a, const Tens* b, size_t aff, const Tens* s0, const Tens* s1, const void* w, const float* bias, int bias_rows,
-           const Tens* skip, float scale, Tens& out, int ks, bool want_stats) {
+           const Tens* skip, float scale, Tens& out, int ks, bool want_stats, bool wino = false) {
     if (want_stats) {
       out.tiles = fd_conv_stats_tiles(out.H, out.W);
       out.stride = fd_conv_cout_pad(out.C);
@@ -281,7 +299,7 @@ struct Fwd {
     const int rc = fd_conv2d(ptr(a.off), a.C, b ? ptr(b->off) : nullptr, b ? b->C : 0, aff == (size_t)-1 ? nullptr : (const float*)ptr(aff),
                              s0 ? ptr(s0->off) : nullptr, s0 ? s0->C : 0, s1 ? ptr(s1->off) : nullptr, s1 ? s1->C : 0, w, bias, bias_rows,
                              skip ? ptr(skip->off) : nullptr, scale, ptr(out.off), out.C, want_stats ? (float*)ptr(out.sums) : nullptr, B,
-                             out.H, out.W, ks, dt, st);
+                             out.H, out.W, ks, dt | (wino ? FD_WINOGRAD : 0), st);
     if (m && m->profiling) {
       FD_HIP(hipEventRecord(m->ev[m->ev_used].second, st));
       ++m->ev_used;
@@ -289,6 +307,27 @@ struct Fwd {
                        ((a.C + (b ? b->C : 0)) * ks * ks + (s0 ? s0->C : 0) + (s1 ? s1->C : 0));
       const double cin = a.C + (b ? b->C : 0), csc = (s0 ? s0->C : 0) + (s1 ? s1->C : 0);
       m->prof_bytes += (double)B * out.H * out.W * esz * (cin + csc + (skip ? out.C : 0) + out.C) + (double)esz * out.C * (cin * ks * ks + csc);
+    }
+    return rc;
+  }
+
+  // fd_fir_resample with per-launch timing when profiling (bytes: input read once, every output written once)
+  int fir(const void* x, const float* aff, void* o_raw, void* o_act, int H, int W, int C, int dir) {
+    const bool prof = m && m->profiling;
+    if (prof) {
+      if (m->ev_fir_used == m->ev_fir.size()) {
+        hipEvent_t e0, e1;
+        FD_HIP(hipEventCreate(&e0)); FD_HIP(hipEventCreate(&e1));
+        m->ev_fir.emplace_back(e0, e1);
+      }
+      FD_HIP(hipEventRecord(m->ev_fir[m->ev_fir_used].first, st));
+    }
+    const int rc = fd_fir_resample(x, aff, o_raw, o_act, B, H, W, C, dir, dt, st);
+    if (prof) {
+      FD_HIP(hipEventRecord(m->ev_fir[m->ev_fir_used].second, st));
+      ++m->ev_fir_used;
+      const double in = (double)B * H * W * C * esz, out1 = dir > 0 ? 4.0 * in : 0.25 * in;
+      m->prof_fir_bytes += in + out1 * ((o_raw ? 1 : 0) + (o_act ? 1 : 0));
     }
     return rc;
   }
@@ -303,11 +342,11 @@ struct Fwd {
     Tens xr, hr;
     if (md.up || md.down) {
       xr = talloc(md.cin, OH, OW); hr = talloc(md.cin, OH, OW);
-      if (!dry) FD_TRY(fd_fir_resample(ptr(x0.off), (const float*)ptr(aff0), ptr(xr.off), ptr(hr.off), B, H, W, md.cin, md.up ? 1 : -1, dt, st));
-      FD_TRY(conv(hr, nullptr, (size_t)-1, nullptr, nullptr, md.w0, md.bias0_eff, nt, nullptr, 1.f, h1, 3, true));
+      if (!dry) FD_TRY(fir(ptr(x0.off), (const float*)ptr(aff0), ptr(xr.off), ptr(hr.off), H, W, md.cin, md.up ? 1 : -1));
+      FD_TRY(conv(hr, nullptr, (size_t)-1, nullptr, nullptr, md.w0, md.bias0_eff, nt, nullptr, 1.f, h1, 3, true, md.wino0));
       tfree(hr);
     } else {
-      FD_TRY(conv(x0, x1, aff0, nullptr, nullptr, md.w0, md.bias0_eff, nt, nullptr, 1.f, h1, 3, true));
+      FD_TRY(conv(x0, x1, aff0, nullptr, nullptr, md.w0, md.bias0_eff, nt, nullptr, 1.f, h1, 3, true, md.wino0));
     }
     arena.release(aff0);
     size_t aff1;
@@ -315,10 +354,10 @@ struct Fwd {
     if (!out_given) out = talloc(md.cout, OH, OW);
     else { out.C = md.cout; out.H = OH; out.W = OW; out.sums = (size_t)-1; }   // fd_resblock: the caller's output tensor
     if (md.has_c2) {  // Conv_1(act(GN1(h))) + Conv_2(x) in one launch (shortcut conv folded in as extra K steps)
-      if (md.up || md.down) FD_TRY(conv(h1, nullptr, aff1, &xr, nullptr, md.w1, md.b1, 1, nullptr, rs2, out, 3, true));
-      else FD_TRY(conv(h1, nullptr, aff1, &x0, x1, md.w1, md.b1, 1, nullptr, rs2, out, 3, true));
+      if (md.up || md.down) FD_TRY(conv(h1, nullptr, aff1, &xr, nullptr, md.w1, md.b1, 1, nullptr, rs2, out, 3, true, md.wino1));
+      else FD_TRY(conv(h1, nullptr, aff1, &x0, x1, md.w1, md.b1, 1, nullptr, rs2, out, 3, true, md.wino1));
     } else {
-      FD_TRY(conv(h1, nullptr, aff1, nullptr, nullptr, md.w1, md.b1, 1, &x0, rs2, out, 3, true));
+      FD_TRY(conv(h1, nullptr, aff1, nullptr, nullptr, md.w1, md.b1, 1, &x0, rs2, out, 3, true, md.wino1));
     }
     if (md.up || md.down) tfree(xr);
     arena.release(aff1);
@@ -360,7 +399,7 @@ struct Fwd {
         Tens hd;
         FD_TRY(resblock(mods[mi++], hs.back(), nullptr, nt, hd));
         Tens p2 = talloc(8, pyr_in.H / 2, pyr_in.W / 2);
-        if (!dry) FD_TRY(fd_fir_resample(ptr(pyr_in.off), nullptr, ptr(p2.off), nullptr, B, pyr_in.H, pyr_in.W, 8, -1, dt, st));
+        if (!dry) FD_TRY(fir(ptr(pyr_in.off), nullptr, ptr(p2.off), nullptr, pyr_in.H, pyr_in.W, 8, -1));
         tfree(pyr_in);
         pyr_in = p2;
         const Mod& md = mods[mi++];
@@ -397,7 +436,7 @@ struct Fwd {
       Tens pnew = talloc(4, h.H, h.W);
       if (have_pyr) {
         Tens pu = talloc(4, h.H, h.W);
-        if (!dry) FD_TRY(fd_fir_resample(ptr(pyramid.off), nullptr, ptr(pu.off), nullptr, B, pyramid.H, pyramid.W, 4, +1, dt, st));
+        if (!dry) FD_TRY(fir(ptr(pyramid.off), nullptr, ptr(pu.off), nullptr, pyramid.H, pyramid.W, 4, +1));
         FD_TRY(conv(h, nullptr, aff, nullptr, nullptr, head.w0, head.b_f32, 1, &pu, 1.f, pnew, 3, false));
         tfree(pu); tfree(pyramid);
       } else {
@@ -432,7 +471,7 @@ int check_ready(const fd_model* m) {
 }
 
 size_t forward_ws_bytes(const fd_model* m, int B, int T) {
-  Fwd f{const_cast<fd_model*>(m), true, nullptr, Arena(), nullptr, B, m->n_freq, T, m->cfg.act_dtype, (int)fd_dtype_size(m->cfg.act_dtype)};
+  Fwd f{const_cast<fd_model*>(m), true, nullptr, Arena(), nullptr, B, m->n_freq, T, m->dt, (int)fd_dtype_size(m->dt)};
   OutSpec os;
   if (f.run(nullptr, nullptr, nullptr, 0.f, 1, os) != FD_OK) return 0;
   return f.arena.peak() + 256;
@@ -447,7 +486,7 @@ int check_shape(const fd_model* m, int B, int T) {
 
 int forward_call(fd_model* m, const float* x, const float* y, const float* t, float t_imm, int nt, const OutSpec& os, int B, int T, void* ws,
                  size_t ws_bytes, hipStream_t st) {
-  Fwd f{m, false, (char*)ws, Arena(), st, B, m->n_freq, T, m->cfg.act_dtype, (int)fd_dtype_size(m->cfg.act_dtype)};
+  Fwd f{m, false, (char*)ws, Arena(), st, B, m->n_freq, T, m->dt, (int)fd_dtype_size(m->dt)};
   (void)ws_bytes;
   return f.run(x, y, t, t_imm, nt, os);
 }
@@ -582,6 +621,13 @@ int run_maybe_graph(fd_model* m, const GraphKey& key, bool use_graph, hipStream_
   if (!use_graph || m->profiling) return enqueue();
   auto it = m->graphs.find(key);
   if (it == m->graphs.end()) {
+    // A caller that walks a data set (one clip length per file) would capture and instantiate a ~1600-node graph per call and
+    // never replay it: the first sighting of a key runs eagerly, only a repeated key is captured.
+    if (!m->seen.count(key)) {
+      if (m->seen.size() >= 256) m->seen.clear();
+      m->seen.insert(key);
+      return enqueue();
+    }
     if (m->graphs.size() >= 32) {   // the key holds raw buffer pointers: bound the cache for callers that keep changing them
       FD_HIP(hipStreamSynchronize(st));   // (rare path) nothing captured earlier may still be in flight when it is destroyed
       for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
@@ -611,7 +657,8 @@ extern "C" int fd_model_create(const fd_model_config* cfg, fd_model** out) {
   FD_REQUIRE(cfg && out, "fd_model_create: null pointer");
   FD_REQUIRE(cfg->nf >= 8 && cfg->nf % 8 == 0 && cfg->nf <= 64, "fd_model_create: nf must be a multiple of 8 in [8, 64] (got %d)", cfg->nf);
   FD_REQUIRE(cfg->num_levels >= 1 && cfg->num_levels <= 8 && cfg->num_res_blocks >= 1, "fd_model_create: bad level / block counts");
-  FD_REQUIRE(cfg->act_dtype == FD_BF16 || cfg->act_dtype == FD_F32, "fd_model_create: act_dtype must be FD_BF16 or FD_F32");
+  FD_REQUIRE((cfg->act_dtype & 0xff) == FD_BF16 || cfg->act_dtype == FD_F32,
+             "fd_model_create: act_dtype must be FD_BF16 [| FD_WINOGRAD | FD_WINOGRAD_LOWRES] or FD_F32");
   FD_REQUIRE(cfg->n_fft > 0 && cfg->n_fft % 2 == 0 && cfg->hop > 0, "fd_model_create: bad STFT geometry");
   for (int i = 0; i < cfg->num_levels; ++i) {
     const int ch = cfg->nf * cfg->ch_mult[i];
@@ -619,6 +666,7 @@ extern "C" int fd_model_create(const fd_model_config* cfg, fd_model** out) {
   }
   fd_model* m = new fd_model();
   m->cfg = *cfg;
+  m->dt = cfg->act_dtype & 0xff;
   m->n_freq = cfg->n_fft / 2 + 1;
   m->temb_dim = 4 * cfg->nf;
   build_structure(m);
@@ -631,6 +679,7 @@ extern "C" void fd_model_destroy(fd_model* m) {
   for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
   for (void* p : m->dev_allocs) (void)hipFree(p);
   for (auto& e : m->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& e : m->ev_fir) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   fd_stft_plan_destroy(m->stft);
   delete m;
 }
@@ -663,7 +712,18 @@ extern "C" int fd_model_set_sigma_y(fd_model* m, const double* host_sigma, int n
   FD_REQUIRE(n == 1 || n == m->n_freq, "fd_model_set_sigma_y: expected 1 or %d values, got %d", m->n_freq, n);
   m->sigma_host.assign(host_sigma, host_sigma + n);
   m->sigma_n = n;
-  if (m->sigma_dev) FD_HIP(hipMemcpy(m->sigma_dev, m->sigma_host.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  if (m->sigma_dev) {
+    FD_HIP(hipDeviceSynchronize());   // (rare, init-time) captured solves bake sigma_n into their launches: drop them
+    for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
+    m->graphs.clear(); m->seen.clear();
+    FD_HIP(hipMemcpy(m->sigma_dev, m->sigma_host.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  }
+  return FD_OK;
+}
+
+extern "C" int fd_model_set_normalize(fd_model* m, int normalize) {
+  FD_REQUIRE(m, "fd_model_set_normalize: null model");
+  m->normalize = normalize != 0;
   return FD_OK;
 }
 
@@ -721,14 +781,18 @@ extern "C" int fd_model_finalize(fd_model* m, void* stream) {
         FD_TRY(upload_f32(m, p + "GroupNorm_0.weight", &md.gn0_g)); FD_TRY(upload_f32(m, p + "GroupNorm_0.bias", &md.gn0_b));
         FD_TRY(upload_f32(m, p + "GroupNorm_1.weight", &md.gn1_g)); FD_TRY(upload_f32(m, p + "GroupNorm_1.bias", &md.gn1_b));
         // up/down blocks resample the (single) input first, so Conv_0 / Conv_2 see one tensor of cin channels
-        FD_TRY(pack_conv(m, p + "Conv_0.weight", md.cout, md.c0, md.c1, 3, "", 0, 0, &md.w0, st));
+        // algorithm per convolution: Winograd F(2,3) where the configuration asks for it and the shape is supported
+        const bool want_wino = (m->cfg.act_dtype & FD_WINOGRAD) || ((m->cfg.act_dtype & FD_WINOGRAD_LOWRES) && md.level >= 2);
+        md.wino0 = want_wino && fd_conv_packed_bytes(md.cout, md.c0, md.c1, 3, 0, 0, m->dt | FD_WINOGRAD) > 0;
+        md.wino1 = want_wino && fd_conv_packed_bytes(md.cout, md.cout, 0, 3, md.has_c2 ? md.c0 : 0, md.has_c2 ? md.c1 : 0, m->dt | FD_WINOGRAD) > 0;
+        FD_TRY(pack_conv(m, p + "Conv_0.weight", md.cout, md.c0, md.c1, 3, "", 0, 0, &md.w0, st, md.wino0 ? FD_WINOGRAD : 0));
         if (md.has_c2) {  // fold the 1x1 shortcut into Conv_1's K loop; biases add
-          FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, p + "Conv_2.weight", md.c0, md.c1, &md.w1, st));
+          FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, p + "Conv_2.weight", md.c0, md.c1, &md.w1, st, md.wino1 ? FD_WINOGRAD : 0));
           std::vector<float>& b1 = m->host[p + "Conv_1.bias"];
           const std::vector<float>& b2 = m->host[p + "Conv_2.bias"];
           for (size_t i = 0; i < b1.size(); ++i) b1[i] += b2[i];
         } else {
-          FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, "", 0, 0, &md.w1, st));
+          FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, "", 0, 0, &md.w1, st, md.wino1 ? FD_WINOGRAD : 0));
         }
         FD_TRY(upload_f32(m, p + "Conv_1.bias", &md.b1));
         fd_temb_job j{};
@@ -788,7 +852,7 @@ extern "C" int fd_ode_solve(fd_model* m, const float* Y, const float* noise, flo
   const size_t need = ode_ws_bytes(m, B, T_pad);
   if (ws_bytes < need) return fd_set_error(FD_ENOMEM, "fd_ode_solve: workspace %zu < required %zu bytes", ws_bytes, need);
   hipStream_t st = fd_stream(stream);
-  GraphKey key{}; key.Y = Y; key.noise = noise; key.X = X_out; key.traj = traj; key.ws = ws; key.B = B; key.T = T_pad; key.N = N; key.solver = solver;
+  GraphKey key; key.Y = Y; key.noise = noise; key.X = X_out; key.traj = traj; key.ws = ws; key.B = B; key.T = T_pad; key.N = N; key.solver = solver;
   key.kind = 1; key.sigma_fac = sigma_fac;
   return run_maybe_graph(m, key, use_graph != 0, st, [&]() { return ode_enqueue(m, Y, noise, sigma_fac, N, solver, X_out, traj, B, T_pad, ws, ws_bytes, st); });
 }
@@ -924,6 +988,12 @@ extern "C" size_t fd_enhance_workspace_bytes(const fd_model* m, int B, int L) {
   return 2 * state + fd_align(sizeof(float) * B) + (a > b ? a : b) + 256;
 }
 
+extern "C" size_t fd_enhance_normfac_offset(const fd_model* m, int B, int L) {
+  if (!m || B <= 0 || L <= 0) return 0;
+  const int Tp = fd_padded_frames(1 + L / m->cfg.hop);
+  return 2 * fd_align(sizeof(float) * 2 * (size_t)B * m->n_freq * Tp);
+}
+
 extern "C" int fd_enhance(fd_model* m, const float* y, const float* noise, float sigma_fac, int N, int solver, float* x_hat, int B, int L, void* ws,
                           size_t ws_bytes, int use_graph, void* stream) {
   FD_TRY(check_ready(m));
@@ -941,10 +1011,10 @@ extern "C" int fd_enhance(fd_model* m, const float* y, const float* noise, float
   float* normfac = (float*)((char*)ws + 2 * state);
   char* rest = (char*)ws + 2 * state + fd_align(sizeof(float) * B);
   const size_t rest_bytes = ws_bytes - (2 * state + fd_align(sizeof(float) * B));
-  GraphKey key{}; key.y = y; key.noise = noise; key.xhat = x_hat; key.ws = ws; key.B = B; key.L = L; key.N = N; key.solver = solver; key.kind = 2;
-  key.sigma_fac = sigma_fac;
+  GraphKey key; key.y = y; key.noise = noise; key.xhat = x_hat; key.ws = ws; key.B = B; key.L = L; key.N = N; key.solver = solver; key.kind = 2;
+  key.sigma_fac = sigma_fac; key.normalize = m->normalize;
   return run_maybe_graph(m, key, use_graph != 0, st, [&]() {
-    FD_TRY(fd_stft_forward(m->stft, y, B, L, m->cfg.alpha, m->cfg.beta, 1, normfac, Y, Tp, rest, rest_bytes, st));
+    FD_TRY(fd_stft_forward(m->stft, y, B, L, m->cfg.alpha, m->cfg.beta, m->normalize, normfac, Y, Tp, rest, rest_bytes, st));
     FD_TRY(ode_enqueue(m, Y, noise, sigma_fac, N, solver, X, nullptr, B, Tp, rest, rest_bytes, st));
     FD_TRY(fd_stft_inverse(m->stft, X, B, T, Tp, m->cfg.alpha, m->cfg.beta, normfac, x_hat, L, rest, rest_bytes, st));
     return FD_OK;
@@ -969,9 +1039,9 @@ static int enhance_common(fd_model* m, const char* who, const float* y, float* x
   float* normfac = (float*)((char*)ws + 2 * state);
   char* rest = (char*)ws + 2 * state + fd_align(sizeof(float) * B);
   const size_t rest_bytes = ws_bytes - (2 * state + fd_align(sizeof(float) * B));
-  key.y = y; key.xhat = x_hat; key.ws = ws; key.B = B; key.L = L;
+  key.y = y; key.xhat = x_hat; key.ws = ws; key.B = B; key.L = L; key.normalize = m->normalize;
   return run_maybe_graph(m, key, use_graph != 0, st, [&]() {
-    FD_TRY(fd_stft_forward(m->stft, y, B, L, m->cfg.alpha, m->cfg.beta, 1, normfac, Y, Tp, rest, rest_bytes, st));
+    FD_TRY(fd_stft_forward(m->stft, y, B, L, m->cfg.alpha, m->cfg.beta, m->normalize, normfac, Y, Tp, rest, rest_bytes, st));
     FD_TRY(body(Y, X, Tp, (void*)rest, rest_bytes, st));
     FD_TRY(fd_stft_inverse(m->stft, X, B, T, Tp, m->cfg.alpha, m->cfg.beta, normfac, x_hat, L, rest, rest_bytes, st));
     return FD_OK;
@@ -992,7 +1062,7 @@ extern "C" int fd_score_enhance(fd_model* m, const float* y, const float* noise,
   FD_REQUIRE(c->corrector_steps >= 0 && c->corrector_steps <= 64, "fd_score_enhance: corrector_steps out of range");
   FD_REQUIRE(c->sigma_min > 0.f && c->sigma_max > c->sigma_min && c->theta > 0.f, "fd_score_enhance: bad OUVE parameters");
   FD_REQUIRE(c->t_eps > 0.f && c->t_eps < 1.f, "fd_score_enhance: t_eps must be in (0, 1)");
-  GraphKey key{}; key.noise = noise; key.kind = 3; key.score = *c;
+  GraphKey key; key.noise = noise; key.kind = 3; key.score = *c;
   const fd_score_config cfg = *c;
   return enhance_common(m, "fd_score_enhance", y, x_hat, B, L, ws, ws_bytes, key, use_graph, stream,
                         [&](float* Y, float* X, int Tp, void* rest, size_t rest_bytes, hipStream_t st) {
@@ -1026,7 +1096,7 @@ extern "C" int fd_score_eval(fd_model* m, const float* x, const float* Y, float 
 
 extern "C" int fd_regression_enhance(fd_model* m, const float* y, float* x_hat, int B, int L, void* ws, size_t ws_bytes, int use_graph,
                                      void* stream) {
-  GraphKey key{}; key.kind = 4;
+  GraphKey key; key.kind = 4;
   return enhance_common(m, "fd_regression_enhance", y, x_hat, B, L, ws, ws_bytes, key, use_graph, stream,
                         [&](float* Y, float* X, int Tp, void* rest, size_t rest_bytes, hipStream_t st) {
                           OutSpec os; os.dst = X; os.coef = 1.f;                                 // X_hat = backbone(Y, Y, t = 0), model.py:566-578
@@ -1088,6 +1158,25 @@ extern "C" int fd_profile_enable(fd_model* m, int enable) {
   m->ev_used = 0;
   m->prof_flops = 0.0;
   m->prof_bytes = 0.0;
+  m->ev_fir_used = 0;
+  m->prof_fir_bytes = 0.0;
+  return FD_OK;
+}
+
+extern "C" int fd_profile_read_fir(fd_model* m, double* ms_total, long long* launches, double* bytes_total) {
+  FD_REQUIRE(m, "fd_profile_read_fir: null model");
+  double ms = 0.0;
+  for (size_t i = 0; i < m->ev_fir_used; ++i) {
+    FD_HIP(hipEventSynchronize(m->ev_fir[i].second));
+    float e = 0.f;
+    FD_HIP(hipEventElapsedTime(&e, m->ev_fir[i].first, m->ev_fir[i].second));
+    ms += e;
+  }
+  if (ms_total) *ms_total = ms;
+  if (launches) *launches = (long long)m->ev_fir_used;
+  if (bytes_total) *bytes_total = m->prof_fir_bytes;
+  m->ev_fir_used = 0;
+  m->prof_fir_bytes = 0.0;
   return FD_OK;
 }
 

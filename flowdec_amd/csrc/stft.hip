@@ -206,7 +206,7 @@ inline int grid_cap(long long n) { long long g = (n + 255) / 256; return (int)(g
 
 }  // namespace
 
-int fd_stft_plan_create(int n_fft, int hop, fd_stft_plan** out) {
+extern "C" int fd_stft_plan_create(int n_fft, int hop, fd_stft_plan** out) {
   FD_REQUIRE(n_fft > 0 && n_fft % 2 == 0 && hop > 0, "stft plan: n_fft must be even and positive");
   fd_stft_plan* p = new fd_stft_plan();
   p->n_fft = n_fft; p->hop = hop; p->n_freq = n_fft / 2 + 1;
@@ -241,7 +241,7 @@ int fd_stft_plan_create(int n_fft, int hop, fd_stft_plan** out) {
   return FD_OK;
 }
 
-void fd_stft_plan_destroy(fd_stft_plan* p) {
+extern "C" void fd_stft_plan_destroy(fd_stft_plan* p) {
   if (!p) return;
   (void)hipFree(p->Dt); (void)hipFree(p->E); (void)hipFree(p->w2);
   delete p;
@@ -288,31 +288,45 @@ int fd_stft_inverse(fd_stft_plan* p, const float* X, int B, int T, int T_pad, fl
   return FD_OK;
 }
 
-// ---- stand-alone C ABI (plan cached per (n_fft, hop)) -------------------------------------------------------
-static fd_stft_plan* g_plan = nullptr;
-static int get_plan(int n_fft, int hop, fd_stft_plan** out) {
-  if (g_plan && (g_plan->n_fft != n_fft || g_plan->hop != hop)) { fd_stft_plan_destroy(g_plan); g_plan = nullptr; }
-  if (!g_plan) FD_TRY(fd_stft_plan_create(n_fft, hop, &g_plan));
-  *out = g_plan;
+// stand-alone amplitude compression / its inverse on a complex tensor (CompressAmplitudesAndScale.forward / .invert,
+// feature_extractors.py:118-139; on the hot path the same arithmetic is fused into compress_kernel / decompress_kernel)
+__global__ void compress_spec_kernel(const float2* __restrict__ X, float2* __restrict__ Y, long long n, float alpha, float beta, int inverse) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float re = X[i].x, im = X[i].y;
+    if (inverse) { re /= beta; im /= beta; }
+    const float e = inverse ? 1.0f / alpha : alpha;
+    if (e != 1.0f) {
+      const float mag = powf(hypotf(re, im), e);
+      const float th = atan2f(im, re);
+      float sn, cs;
+      sincosf(th, &sn, &cs);
+      re = mag * cs; im = mag * sn;
+    }
+    if (!inverse) { re *= beta; im *= beta; }
+    Y[i] = float2{re, im};
+  }
+}
+
+extern "C" int fd_compress_spec(const float* X, float* Y, long long n, float alpha, float beta, int inverse, void* stream) {
+  FD_REQUIRE(X && Y && n > 0 && alpha > 0.f && beta > 0.f, "fd_compress_spec: bad arguments");
+  hipLaunchKernelGGL(compress_spec_kernel, dim3(grid_cap(n)), dim3(256), 0, fd_stream(stream), (const float2*)X, (float2*)Y, n, alpha, beta, inverse);
+  FD_LAUNCH_CHECK();
   return FD_OK;
 }
 
+// ---- stand-alone C ABI: the caller owns the plan (no hidden state, nothing allocates on the hot path) -------------------
 extern "C" size_t fd_stft_workspace_bytes(int B, int L, int n_fft, int hop) { return fd_stft_ws_bytes(B, L, n_fft, hop); }
 extern "C" int fd_num_frames(int L, int hop) { return 1 + L / hop; }
 extern "C" int fd_padded_frames(int T) { return (T % 64 == 0) ? T : T + (64 - T % 64); }
 
-extern "C" int fd_stft_compress(const float* y, int B, int L, int n_fft, int hop, float alpha, float beta, int normalize,
+extern "C" int fd_stft_compress(const fd_stft_plan* plan, const float* y, int B, int L, float alpha, float beta, int normalize,
                                 float* normfac, float* Y, int T_pad, void* ws, size_t ws_bytes, void* stream) {
-  FD_REQUIRE(y && normfac && Y && ws && B > 0 && L > 0, "fd_stft_compress: bad arguments");
-  fd_stft_plan* p;
-  FD_TRY(get_plan(n_fft, hop, &p));
-  return fd_stft_forward(p, y, B, L, alpha, beta, normalize, normfac, Y, T_pad, ws, ws_bytes, fd_stream(stream));
+  FD_REQUIRE(plan && y && normfac && Y && ws && B > 0 && L > 0, "fd_stft_compress: bad arguments");
+  return fd_stft_forward(const_cast<fd_stft_plan*>(plan), y, B, L, alpha, beta, normalize, normfac, Y, T_pad, ws, ws_bytes, fd_stream(stream));
 }
 
-extern "C" int fd_decompress_istft(const float* X, int B, int T, int T_pad, int n_fft, int hop, float alpha, float beta,
+extern "C" int fd_decompress_istft(const fd_stft_plan* plan, const float* X, int B, int T, int T_pad, float alpha, float beta,
                                    const float* normfac, float* y, int L, void* ws, size_t ws_bytes, void* stream) {
-  FD_REQUIRE(X && y && ws && B > 0 && L > 0, "fd_decompress_istft: bad arguments");
-  fd_stft_plan* p;
-  FD_TRY(get_plan(n_fft, hop, &p));
-  return fd_stft_inverse(p, X, B, T, T_pad, alpha, beta, normfac, y, L, ws, ws_bytes, fd_stream(stream));
+  FD_REQUIRE(plan && X && y && ws && B > 0 && L > 0, "fd_decompress_istft: bad arguments");
+  return fd_stft_inverse(const_cast<fd_stft_plan*>(plan), X, B, T, T_pad, alpha, beta, normfac, y, L, ws, ws_bytes, fd_stream(stream));
 }

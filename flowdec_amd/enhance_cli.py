@@ -87,6 +87,24 @@ def resample(y: torch.Tensor, sr: int, target: int) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 # checkpoint reader
 # ------------------------------------------------------------------------------------------------
+def _to_plain(obj):
+    """hyper_parameters of a real Lightning checkpoint are an OmegaConf DictConfig (the reference calls
+    save_hyperparameters(self.full_config), model.py:60-63), not a dict: convert any Mapping / sequence tree to plain
+    Python containers (OmegaConf.to_container when omegaconf is importable, so that interpolations are resolved)."""
+    from collections.abc import Mapping, Sequence
+    try:
+        from omegaconf import OmegaConf
+        if OmegaConf.is_config(obj):
+            return OmegaConf.to_container(obj, resolve=True)
+    except ImportError:
+        pass
+    if isinstance(obj, Mapping):
+        return {k: _to_plain(v) for k, v in obj.items()}
+    if isinstance(obj, Sequence) and not isinstance(obj, (str, bytes)):
+        return [_to_plain(v) for v in obj]
+    return obj
+
+
 def _cfg_get(cfg, *path, default=None):
     for k in path:
         if isinstance(cfg, dict) and k in cfg:
@@ -107,7 +125,11 @@ def model_from_checkpoint(ckpt, ema: bool = True, precision: str = "bf16", prese
         sd = ckpt[key]
     else:
         sd = ckpt  # bare state_dict
-    hp = ckpt.get("hyper_parameters") if isinstance(ckpt.get("hyper_parameters", None), dict) else None
+    hp = None
+    if ckpt.get("hyper_parameters", None) is not None:
+        hp = _to_plain(ckpt["hyper_parameters"])
+        if not isinstance(hp, dict):   # silently falling back to the defaults would produce wrong audio for e.g. the ablation configs
+            raise RuntimeError(f"checkpoint 'hyper_parameters' of type {type(ckpt['hyper_parameters']).__name__} cannot be read as a mapping")
     mcfg = _cfg_get(hp, "model") or {}
     bb_cfg = dict(BACKBONE_FINAL_NO_ATTN)
     for k, v in (mcfg.get("backbone") or {}).items():
@@ -206,14 +228,17 @@ def main(argv=None, model: Optional[FlowModel] = None) -> int:
             out_path = os.path.join(args.outdir, os.path.basename(path))
             if not os.path.exists(out_path) or not args.skip_existing:
                 y, sr = load_wav(path)
-                if y.shape[-1] / sr <= MAX_SECONDS:
+                # one image must stay below 2 GiB (32-bit buffer offsets of the conv kernel): ~43 s in bf16, ~21 s in fp32
+                max_seconds = min(MAX_SECONDS, 20.0) if args.precision == "fp32" else MAX_SECONDS
+                if y.shape[-1] / sr <= max_seconds:
                     if sr != model.sampling_rate:
                         print("RESAMPLING from", sr, "to", model.sampling_rate)
                         y, sr = resample(y, sr, model.sampling_rate), model.sampling_rate
                     if args.rtf:
                         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         start.record()
-                    x_hat = model.enhance(y, N=args.N, solver=args.solver, generator=gen)
+                    # use_graph=False: every file has its own length, a captured graph would never be replayed
+                    x_hat = model.enhance(y, N=args.N, solver=args.solver, generator=gen, use_graph=False)
                     if args.rtf:
                         end.record()
                         torch.cuda.synchronize()

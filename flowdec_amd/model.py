@@ -60,6 +60,9 @@ class Combine(nn.Module):
 
 
 DEFAULT_OUTPUTLAYER_KWARGS = dict(kernel_size=3, bias=False, padding="same", padding_mode="zeros")
+# 3x3 convolution algorithm of the bf16 mode: direct MFMA implicit GEMM, Winograd F(2,3) wherever the shape allows it, or
+# Winograd only at the low-resolution levels (see include/flowdec_hip.h: FD_WINOGRAD / FD_WINOGRAD_LOWRES)
+CONV_ALGOS = {"direct": 0, "winograd": L.FD_WINOGRAD, "winograd_lowres": L.FD_WINOGRAD_LOWRES}
 
 
 class NCSNpp(nn.Module):
@@ -77,7 +80,7 @@ class NCSNpp(nn.Module):
                  progressive_input="input_skip", progressive_combine="sum", init_scale=0.0, fourier_scale=16,
                  image_size=256, embedding_type="fourier", dropout=0.0, num_channels=4,
                  output_layer_kwargs: dict = DEFAULT_OUTPUTLAYER_KWARGS, bottleneck_attn: bool = True,
-                 precision: str = "bf16"):
+                 precision: str = "bf16", conv_algo: str = "direct"):
         super().__init__()
         ch_mult = tuple(ch_mult)
         all_res = [image_size // (2 ** i) for i in range(len(ch_mult))]
@@ -98,7 +101,9 @@ class NCSNpp(nn.Module):
             raise NotImplementedError("flowdec_amd.NCSNpp: unsupported configuration: " + "; ".join(unsupported))
         if precision not in ("bf16", "fp32"):
             raise ValueError("precision must be 'bf16' or 'fp32'")
-        self.nf, self.ch_mult, self.num_res_blocks, self.precision = nf, ch_mult, num_res_blocks, precision
+        if conv_algo not in CONV_ALGOS or (conv_algo != "direct" and precision != "bf16"):
+            raise ValueError(f"conv_algo must be one of {sorted(CONV_ALGOS)} ('direct' only with precision='fp32')")
+        self.nf, self.ch_mult, self.num_res_blocks, self.precision, self.conv_algo = nf, ch_mult, num_res_blocks, precision, conv_algo
         self.num_resolutions = len(ch_mult)
         self.output_layer = nn.Conv2d(num_channels, 2, kernel_size=1, bias=False)
         temb_dim = nf * 4
@@ -133,6 +138,7 @@ class NCSNpp(nn.Module):
         self._ws = {}
         self._sigma_y = None
         self._stft_cfg = dict(n_fft=1534, hop=384, alpha=0.3, beta=0.33)
+        self._normalize = True
 
     # -- native handle management ----------------------------------------------------------------
     def _config_struct(self):
@@ -144,7 +150,7 @@ class NCSNpp(nn.Module):
         cfg.num_res_blocks = self.num_res_blocks
         cfg.n_fft, cfg.hop = self._stft_cfg["n_fft"], self._stft_cfg["hop"]
         cfg.alpha, cfg.beta = self._stft_cfg["alpha"], self._stft_cfg["beta"]
-        cfg.act_dtype = L.FD_BF16 if self.precision == "bf16" else L.FD_F32
+        cfg.act_dtype = (L.FD_BF16 | CONV_ALGOS[self.conv_algo]) if self.precision == "bf16" else L.FD_F32
         return cfg
 
     def invalidate(self):
@@ -166,7 +172,7 @@ class NCSNpp(nn.Module):
     def _sig(self):
         p = next(self.parameters())
         sig_sigma = None if self._sigma_y is None else (self._sigma_y.data_ptr(), self._sigma_y._version)
-        return (p.device, self.precision, tuple(sorted(self._stft_cfg.items())), sig_sigma,
+        return (p.device, self.precision, self.conv_algo, bool(self._normalize), tuple(sorted(self._stft_cfg.items())), sig_sigma,
                 tuple(q._version for q in self.parameters()))
 
     def handle(self):
@@ -199,6 +205,7 @@ class NCSNpp(nn.Module):
             if self._sigma_y is not None:
                 s = self._sigma_y.detach().to("cpu", torch.float64).contiguous().reshape(-1)
                 L.check(lib.fd_model_set_sigma_y(h, C.c_void_p(s.data_ptr()), s.numel()))
+            L.check(lib.fd_model_set_normalize(h, int(self._normalize)))
             L.check(lib.fd_model_finalize(h, L.stream()))
         self._handle, self._handle_sig = h, sig
         return h
@@ -230,8 +237,9 @@ class NCSNpp(nn.Module):
         if need == 0:
             raise RuntimeError("flowdec_hip: " + lib.fd_last_error().decode())
         ws = self.workspace(("fwd", B, T), need, x.device)
-        L.check(lib.fd_ncsnpp_forward(h, L.ptr(torch.view_as_real(x)), L.ptr(torch.view_as_real(y)), L.ptr(t), t.numel(),
-                                      L.ptr(torch.view_as_real(out)), B, T, L.ptr(ws), ws.numel(), L.stream()))
+        with torch.cuda.device(x.device):   # L.stream() must be the stream of the tensors' device
+            L.check(lib.fd_ncsnpp_forward(h, L.ptr(torch.view_as_real(x)), L.ptr(torch.view_as_real(y)), L.ptr(t), t.numel(),
+                                          L.ptr(torch.view_as_real(out)), B, T, L.ptr(ws), ws.numel(), L.stream()))
         return out
 
 
@@ -251,13 +259,48 @@ class ComplexSTFT(nn.Module):
         self.window = nn.Parameter(torch.signal.windows.hann(n_fft), requires_grad=False)
         self.n_fft, self.hop_length, self.sampling_rate, self.center = n_fft, hop_length, sampling_rate, True
 
+    def forward(self, x):
+        """x: [..., L] real (GPU) -> complex64 [..., n_fft/2+1, 1 + L // hop]  (feature_extractors.py:86-96)."""
+        from . import ops
+        shp = x.shape
+        Y, _, T = ops.stft_compress(x.reshape(-1, shp[-1]).float().contiguous(), n_fft=self.n_fft, hop=self.hop_length, alpha=1.0, beta=1.0,
+                                    normalize=False)
+        return Y[:, 0, :, :T].reshape(*shp[:-1], Y.shape[2], T)
+
+    def invert(self, X, orig_length: Optional[int] = None, **kwargs):
+        """torch.istft(..., length=orig_length)  (feature_extractors.py:98-109)."""
+        from . import ops
+        shp = X.shape
+        T = shp[-1]
+        if orig_length is None:
+            orig_length = self.hop_length * (T - 1)
+        Xp = X.reshape(-1, 1, shp[-2], T).to(torch.complex64).contiguous()
+        y = ops.decompress_istft(Xp, T, orig_length, None, n_fft=self.n_fft, hop=self.hop_length, alpha=1.0, beta=1.0)
+        return y.reshape(*shp[:-2], orig_length)
+
 
 class CompressAmplitudesAndScale(nn.Module):
-    """feature_extractors.py:112-139 (parameters only; arithmetic is fused into the STFT kernels)."""
+    """feature_extractors.py:112-139.  On the hot path the arithmetic is fused into the STFT kernels; forward / invert are
+    the stand-alone forms (fd_compress_spec)."""
 
     def __init__(self, compression_exponent: float, scale_factor: float):
         super().__init__()
         self.compression_exponent, self.scale_factor = compression_exponent, scale_factor
+
+    def _apply_spec(self, x, inverse):
+        L.require_cuda(x)
+        x = x.to(torch.complex64).contiguous()
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            L.check(L.load().fd_compress_spec(L.ptr(torch.view_as_real(x)), L.ptr(torch.view_as_real(out)), x.numel(),
+                                              float(self.compression_exponent), float(self.scale_factor), int(inverse), L.stream()))
+        return out
+
+    def forward(self, x):
+        return self._apply_spec(x, False)
+
+    def invert(self, x):
+        return self._apply_spec(x, True)
 
 
 class AmplitudeCompressedComplexSTFT(nn.Module):
@@ -308,6 +351,46 @@ def sigma_y_from_file(filename: str, factor: float = 1.0, kernel_bandwidth: Opti
     return factor * torch.from_numpy(curve).unsqueeze(-1)
 
 
+def _info_from_ws(lib, h, ws, B, Lw, T, squeeze_dims):
+    """preprocess_info of the reference (model.py:161-162); normfac is read where fd_enhance's front end left it."""
+    off = lib.fd_enhance_normfac_offset(h, B, Lw)
+    normfac = ws[off:off + 4 * B].view(torch.float32).clone().reshape(B, 1, 1)
+    return dict(orig_length=Lw, normfac=normfac, undo_pad_fn=(lambda Y_, T=T: Y_[..., :T]), squeeze_dims=squeeze_dims)
+
+
+def _preprocess(model, y):
+    """EnhancementModel._preprocess (model.py:129-163): [L] / [1, L] / [B, 1, L] waveform -> (Y [B, 1, F, T_pad] complex64 with the
+    frame axis zero-padded to a multiple of 64, preprocess_info)."""
+    from . import ops
+    dev = model.device
+    squeeze_dims = 0
+    while y.ndim < 3:
+        y = y.unsqueeze(0); squeeze_dims += 1
+    if y.ndim != 3 or y.shape[1] != 1:
+        raise RuntimeError(f"expected [L], [1, L] or [B, 1, L] waveforms (got {tuple(y.shape)})")
+    B, Lw = y.shape[0], y.shape[-1]
+    with torch.cuda.device(dev):
+        Y, normfac, T = ops.stft_compress(y.reshape(B, Lw).to(dev, torch.float32).contiguous(), normalize=model.normalize_mode == "noisy",
+                                          **model.feature_extractor._cfg())
+    info = dict(orig_length=Lw, normfac=normfac.reshape(B, 1, 1), undo_pad_fn=(lambda Y_, T=T: Y_[..., :T]), squeeze_dims=squeeze_dims)
+    return Y, info
+
+
+def _postprocess(model, X_hat, preprocess_info):
+    """EnhancementModel._postprocess (model.py:165-190): undo padding, invert the features, restore the level and the rank."""
+    from . import ops
+    T = preprocess_info["undo_pad_fn"](X_hat).shape[-1]   # frames before pad_spec
+    Lw = preprocess_info["orig_length"]
+    B = X_hat.shape[0]
+    Xp = X_hat.to(torch.complex64).contiguous()             # the kernel reads the first T frames of the (padded) frame axis
+    with torch.cuda.device(Xp.device):
+        x_hat = ops.decompress_istft(Xp, T, Lw, preprocess_info["normfac"].reshape(B).float().contiguous(), **model.feature_extractor._cfg())
+    x_hat = x_hat.reshape(B, 1, Lw)
+    for _ in range(preprocess_info["squeeze_dims"]):
+        x_hat = x_hat.squeeze(0)
+    return x_hat
+
+
 class FlowModel(nn.Module):
     """Drop-in for flowdec.model.FlowModel on the inference path (model.py:391-536).
 
@@ -321,8 +404,6 @@ class FlowModel(nn.Module):
                  sigma_x=0.0, sigma_y=0.66, flow_matcher=None, lr: float = 1e-4, normalize_mode: str = "noisy", **kwargs):
         super().__init__()
         assert normalize_mode in ("noisy", "none")
-        if normalize_mode != "noisy":
-            raise NotImplementedError("flowdec_amd.FlowModel: normalize_mode='none' is not wired to the HIP front-end")
         self.sampling_rate, self.normalize_mode, self.lr, self.flow_matcher = sampling_rate, normalize_mode, lr, flow_matcher
         self.backbone, self.feature_extractor = backbone, feature_extractor
         self.sigma_x = nn.Parameter(sigma_x if isinstance(sigma_x, torch.Tensor) else torch.tensor(float(sigma_x)), requires_grad=False)
@@ -342,7 +423,15 @@ class FlowModel(nn.Module):
     def _sync_native(self):
         self.backbone._sigma_y = self.sigma_y
         self.backbone._stft_cfg = self.feature_extractor._cfg()
+        self.backbone._normalize = self.normalize_mode == "noisy"
         return self.backbone.handle()
+
+    # EnhancementModel._preprocess / _postprocess (model.py:129-190) as stand-alone calls
+    def _preprocess(self, y):
+        return _preprocess(self, y)
+
+    def _postprocess(self, X_hat, preprocess_info):
+        return _postprocess(self, X_hat, preprocess_info)
 
     def _io_buffers(self, B, Lw, Tp, F, dev):
         key = (B, Lw, str(dev))
@@ -425,7 +514,7 @@ class FlowModel(nn.Module):
         """solver='dopri5': adaptive Dormand-Prince over t_span = linspace(0, 1, N+1) (torchdyn semantics restated, unpinned);
         host-driven (one read-back per attempted step), so no hipGraph.  The realised NFE is left in `self.last_nfe`."""
         from . import ops
-        Y, normfac, _ = ops.stft_compress(io["y"], normalize=True, **cfg)
+        Y, normfac, _ = ops.stft_compress(io["y"], normalize=self.normalize_mode == "noisy", **cfg)
         traj = torch.empty(N + 1, B, 1, F, Tp, dtype=torch.complex64, device=dev) if return_traj else None
         X = torch.empty_like(Y)
         need = lib.fd_ode_adaptive_workspace_bytes(h, B, Tp)
@@ -451,7 +540,7 @@ class FlowModel(nn.Module):
                         squeeze_dims, use_graph, dev):
         if return_traj:   # every solver state is needed: front end, solver and back end as separate native calls
             from . import ops
-            Y, normfac, _ = ops.stft_compress(io["y"], normalize=True, **cfg)
+            Y, normfac, _ = ops.stft_compress(io["y"], normalize=self.normalize_mode == "noisy", **cfg)
             traj = torch.empty(N + 1, B, 1, F, Tp, dtype=torch.complex64, device=dev)
             X = torch.empty_like(Y)
             need = lib.fd_model_workspace_bytes(h, B, Tp)
@@ -475,10 +564,7 @@ class FlowModel(nn.Module):
         x_hat = io["out"].reshape(B, 1, Lw).clone()
         info = None
         if return_preprocess_info:
-            # normfac was computed by the HIP front-end; it lives right after the two state buffers of the workspace
-            state = (8 * B * F * Tp + 255) // 256 * 256
-            normfac = ws[2 * state:2 * state + 4 * B].view(torch.float32).clone().reshape(B, 1, 1)
-            info = dict(orig_length=Lw, normfac=normfac, undo_pad_fn=(lambda Y_, T=T: Y_[..., :T]), squeeze_dims=squeeze_dims)
+            info = _info_from_ws(lib, h, ws, B, Lw, T, squeeze_dims)
         return x_hat, info
 
 
@@ -518,11 +604,16 @@ class _WaveModel(nn.Module):
     def __init__(self, backbone: NCSNpp, feature_extractor: AmplitudeCompressedComplexSTFT, sampling_rate: int = 48000,
                  lr: float = 1e-4, normalize_mode: str = "noisy", **kwargs):
         super().__init__()
-        if normalize_mode != "noisy":
-            raise NotImplementedError("flowdec_amd: normalize_mode='none' is not wired to the HIP front-end")
+        assert normalize_mode in ("noisy", "none")
         self.sampling_rate, self.normalize_mode, self.lr = sampling_rate, normalize_mode, lr
         self.backbone, self.feature_extractor = backbone, feature_extractor
         self._io, self._side_stream = {}, None
+
+    def _preprocess(self, y):
+        return _preprocess(self, y)
+
+    def _postprocess(self, X_hat, preprocess_info):
+        return _postprocess(self, X_hat, preprocess_info)
 
     @property
     def device(self):
@@ -534,9 +625,10 @@ class _WaveModel(nn.Module):
     def _sync_native(self):
         self.backbone._sigma_y = None
         self.backbone._stft_cfg = self.feature_extractor._cfg()
+        self.backbone._normalize = self.normalize_mode == "noisy"
         return self.backbone.handle()
 
-    def _wave_call(self, y, n_draws, noise, generator, launch):
+    def _wave_call(self, y, n_draws, noise, generator, launch, return_preprocess_info=False):
         """launch(lib, h, y_dev [B, L], noise_dev [n_draws, B, 1, F, Tp] | None, out [B, L], ws) on a capture-safe side stream."""
         dev = self.device
         if dev.type != "cuda":
@@ -577,11 +669,13 @@ class _WaveModel(nn.Module):
             with torch.cuda.stream(side):
                 launch(lib, h, io, B, Lw, ws)
                 x_hat = io["out"].reshape(B, 1, Lw).clone()
+                info = _info_from_ws(lib, h, ws, B, Lw, lib.fd_num_frames(Lw, cfg["hop"]), squeeze_dims) if return_preprocess_info else None
             cur.wait_stream(side)
         x_hat.record_stream(cur)
         for _ in range(squeeze_dims):
             x_hat = x_hat.squeeze(0)
-        return x_hat.to(orig_device)
+        x_hat = x_hat.to(orig_device)
+        return (x_hat, info) if return_preprocess_info else x_hat
 
 
 class ScoreModel(_WaveModel):
@@ -611,17 +705,13 @@ class ScoreModel(_WaveModel):
     def enhance(self, y, sampler_type="pc", predictor="reverse_diffusion", corrector="ald", N=30, corrector_steps=1, snr=0.5,
                 return_preprocess_info=False, denoise=True, noise=None, generator=None, use_graph: bool = True, **kwargs):
         if sampler_type == "ode":
-            if return_preprocess_info:
-                raise NotImplementedError("flowdec_amd.ScoreModel.enhance: return_preprocess_info is only wired for FlowModel")
-            return self._enhance_ode(y, N=N, denoise=denoise, noise=noise, generator=generator, **kwargs)
+            return self._enhance_ode(y, N=N, denoise=denoise, noise=noise, generator=generator, return_preprocess_info=return_preprocess_info, **kwargs)
         if sampler_type != "pc":
             raise ValueError(f"{sampler_type} is not a valid sampler type!")
         if predictor not in L.PREDICTORS:
             raise ValueError(f"unknown predictor {predictor!r}; supported: {sorted(L.PREDICTORS)}")
         if corrector not in L.CORRECTORS:
             raise ValueError(f"unknown corrector {corrector!r}; supported: {sorted(L.CORRECTORS)}")
-        if return_preprocess_info:
-            raise NotImplementedError("flowdec_amd.ScoreModel.enhance: return_preprocess_info is only wired for FlowModel")
         N = self.sde.N if N is None else int(N)
         cfg = L.FdScoreConfig(self.sde.theta, self.sde.sigma_min, self.sde.sigma_max, float(kwargs.get("eps", self.t_eps)), float(snr), N,
                               L.PREDICTORS[predictor], L.CORRECTORS[corrector], int(corrector_steps), int(bool(denoise)))
@@ -631,11 +721,11 @@ class ScoreModel(_WaveModel):
             assert lib.fd_score_num_draws(C.byref(cfg)) == n_draws
             L.check(lib.fd_score_enhance(h, L.ptr(io["y"]), L.ptr(torch.view_as_real(io["noise"])), C.byref(cfg), L.ptr(io["out"]), B, Lw,
                                          L.ptr(ws), ws.numel(), int(use_graph), L.stream()))
-        return self._wave_call(y, n_draws, noise, generator, launch)
+        return self._wave_call(y, n_draws, noise, generator, launch, return_preprocess_info)
 
 
     def _enhance_ode(self, y, N=None, denoise=True, noise=None, generator=None, rtol=1e-5, atol=1e-5, method="RK45", eps=None,
-                     return_nfe: bool = False, **ignored):
+                     return_nfe: bool = False, return_preprocess_info: bool = False, **ignored):
         """sampler_type='ode' (sampling/__init__.py:75-146): the probability-flow ODE integrated by scipy.integrate.solve_ivp
         on the host, exactly like the reference; every drift evaluation is one fd_score_eval (backbone + fused update) on
         the GPU, the STFT / iSTFT run in libflowdec_hip.so.  Host-driven and slow by construction (the state crosses PCIe
@@ -658,7 +748,7 @@ class ScoreModel(_WaveModel):
         B, Lw = y3.shape[0], y3.shape[-1]
         sc = L.FdScoreConfig(self.sde.theta, self.sde.sigma_min, self.sde.sigma_max, t_eps, 0.0, N, 0, 1, 0, int(bool(denoise)))
         with torch.cuda.device(dev):
-            Y, normfac, T = ops.stft_compress(y3.reshape(B, Lw).to(dev, torch.float32), normalize=True, **cfg)
+            Y, normfac, T = ops.stft_compress(y3.reshape(B, Lw).to(dev, torch.float32), normalize=self.normalize_mode == "noisy", **cfg)
             Tp = Y.shape[-1]
             if noise is None:
                 noise = torch.randn(Y.shape, dtype=torch.complex64, device=dev, generator=generator)
@@ -683,6 +773,9 @@ class ScoreModel(_WaveModel):
         for _ in range(squeeze_dims):
             x_hat = x_hat.squeeze(0)
         x_hat = x_hat.to(orig_device)
+        if return_preprocess_info:
+            info = dict(orig_length=Lw, normfac=normfac.reshape(B, 1, 1), undo_pad_fn=(lambda Y_, T=T: Y_[..., :T]), squeeze_dims=squeeze_dims)
+            return x_hat, info
         return (x_hat, int(sol.nfev)) if return_nfe else x_hat
 
 
@@ -701,12 +794,9 @@ class RegressionModel(_WaveModel):
 
     @torch.no_grad()
     def enhance(self, y, return_preprocess_info=False, use_graph: bool = True, **kwargs):
-        if return_preprocess_info:
-            raise NotImplementedError("flowdec_amd.RegressionModel.enhance: return_preprocess_info is only wired for FlowModel")
-
         def launch(lib, h, io, B, Lw, ws):
             L.check(lib.fd_regression_enhance(h, L.ptr(io["y"]), L.ptr(io["out"]), B, Lw, L.ptr(ws), ws.numel(), int(use_graph), L.stream()))
-        return self._wave_call(y, 0, None, None, launch)
+        return self._wave_call(y, 0, None, None, launch, return_preprocess_info)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -117,6 +117,33 @@ def temb_bias(temb, dense_w, dense_b, conv_bias):
     return out
 
 
+class _StftPlan:
+    """Caller-owned fd_stft_plan (device-resident DFT matrices of one (n_fft, hop)); freed with the object."""
+
+    def __init__(self, n_fft, hop):
+        import ctypes as C
+        self.handle = C.c_void_p()
+        L.check(L.load().fd_stft_plan_create(int(n_fft), int(hop), C.byref(self.handle)))
+
+    def __del__(self):
+        try:
+            L.load().fd_stft_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
+_PLANS = {}
+
+
+def stft_plan(n_fft, hop, device):
+    """One plan per (device, n_fft, hop), created on first use (allocates and uploads: call it outside graph capture)."""
+    key = (torch.device(device).index, int(n_fft), int(hop))
+    if key not in _PLANS:
+        with torch.cuda.device(device):
+            _PLANS[key] = _StftPlan(n_fft, hop)
+    return _PLANS[key].handle
+
+
 def stft_compress(y, n_fft=1534, hop=384, alpha=0.3, beta=0.33, normalize=True):
     """y [B, L] float32 -> (Y complex64 [B, 1, F, T_pad], normfac [B], T)."""
     L.require_cuda(y)
@@ -128,7 +155,8 @@ def stft_compress(y, n_fft=1534, hop=384, alpha=0.3, beta=0.33, normalize=True):
     nf = torch.empty(B, dtype=torch.float32, device=y.device)
     nws = lib.fd_stft_workspace_bytes(B, Ls, n_fft, hop)
     ws = torch.empty(nws, dtype=torch.uint8, device=y.device)
-    L.check(lib.fd_stft_compress(L.ptr(y), B, Ls, n_fft, hop, alpha, beta, int(normalize), L.ptr(nf), L.ptr(Y), Tp, L.ptr(ws), nws, L.stream()))
+    L.check(lib.fd_stft_compress(stft_plan(n_fft, hop, y.device), L.ptr(y), B, Ls, alpha, beta, int(normalize), L.ptr(nf), L.ptr(Y), Tp, L.ptr(ws),
+                                 nws, L.stream()))
     return Y, nf, T
 
 
@@ -140,7 +168,8 @@ def decompress_istft(X, T, length, normfac=None, n_fft=1534, hop=384, alpha=0.3,
     y = torch.empty(B, length, dtype=torch.float32, device=X.device)
     nws = lib.fd_stft_workspace_bytes(B, max(length, hop * T), n_fft, hop)
     ws = torch.empty(nws, dtype=torch.uint8, device=X.device)
-    L.check(lib.fd_decompress_istft(L.ptr(X), B, T, Tp, n_fft, hop, alpha, beta, L.ptr(normfac), L.ptr(y), length, L.ptr(ws), nws, L.stream()))
+    L.check(lib.fd_decompress_istft(stft_plan(n_fft, hop, X.device), L.ptr(X), B, T, Tp, alpha, beta, L.ptr(normfac), L.ptr(y), length, L.ptr(ws),
+                                    nws, L.stream()))
     return y
 
 

@@ -38,6 +38,9 @@ extern "C" {
  * (1.5x fewer MFMAs; bf16 storage, fp16 MFMA operands, f32 accumulation; conv_wino.hip).  The packed weights of the two
  * algorithms differ: pack and launch with the same flag. */
 #define FD_WINOGRAD 0x100
+/* fd_model_config.act_dtype only: Winograd for the blocks of resolution level >= 2 (small grids, where its 128-cout workgroups
+ * fill the chip better), direct MFMA convolution elsewhere. */
+#define FD_WINOGRAD_LOWRES 0x200
 
 /* solver ids (flowdec/model.py:487 'euler'/'midpoint' via torchdyn; sampling/solvers.py:15-57) */
 #define FD_SOLVER_EULER 0
@@ -119,8 +122,6 @@ int fd_conv_stats_tiles(int H, int W);   /* 16x16 tiles per image */
 int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const float* affine, const void* sc0, int S0, const void* sc1,
               int S1, const void* packed_w, const float* bias, int bias_rows, const void* skip, float scale, void* out,
               int Cout, float* stats, int B, int H, int W, int ksize, int dtype, void* stream);
-/* Tuning hook used by the benchmarks ("conv_variant": 0 auto, 1 force the 4-wave BN=128 configuration). */
-int fd_tuning_set(const char* key, int value);
 
 /* Time embedding: GaussianFourierProjection -> Linear -> SiLU -> Linear (ncsnpp.py:263-274,
  * layerspp.py:42-51); t [nt] float32 -> temb [nt][4*nf]. */
@@ -160,13 +161,23 @@ int fd_resblock(const fd_resblock_desc* d, const void* x0, const void* x1, void*
  * (util/other.py:55-82, feature_extractors.py:86-96,118-128, util/other.py:25-52).
  * y [B][L] f32 -> Y [B][1][n_fft/2+1][T_pad] complex64, normfac [B] f32.
  * ws: fd_stft_workspace_bytes(B, L, n_fft, hop) bytes of scratch. */
+/* The DFT matrices / window envelope of one (n_fft, hop) live in a plan the CALLER owns (2 x 9.4 MB on the current device for
+ * n_fft = 1534): fd_stft_plan_create allocates and uploads (synchronous, init time), the transforms themselves allocate
+ * nothing and keep no state. */
+typedef struct fd_stft_plan fd_stft_plan;
+int fd_stft_plan_create(int n_fft, int hop, fd_stft_plan** out);
+void fd_stft_plan_destroy(fd_stft_plan* plan);
 size_t fd_stft_workspace_bytes(int B, int L, int n_fft, int hop);
-int fd_stft_compress(const float* y, int B, int L, int n_fft, int hop, float alpha, float beta, int normalize,
+/* normalize != 0: per-clip max-abs normalisation (normalize_mode 'noisy'); 0: normfac = 1 (normalize_mode 'none', util/other.py:70) */
+int fd_stft_compress(const fd_stft_plan* plan, const float* y, int B, int L, float alpha, float beta, int normalize,
                      float* normfac, float* Y, int T_pad, void* ws, size_t ws_bytes, void* stream);
 /* Inverse: slice [:T] -> X/beta -> |.|^(1/alpha) -> torch.istft(length=L) -> * normfac
  * (model.py:165-190, feature_extractors.py:98-109,130-139).  normfac may be NULL. */
-int fd_decompress_istft(const float* X, int B, int T, int T_pad, int n_fft, int hop, float alpha, float beta,
+int fd_decompress_istft(const fd_stft_plan* plan, const float* X, int B, int T, int T_pad, float alpha, float beta,
                         const float* normfac, float* y, int L, void* ws, size_t ws_bytes, void* stream);
+/* CompressAmplitudesAndScale.forward (inverse = 0: beta |x|^alpha e^{j angle x}) / .invert (inverse = 1) on n complex64
+ * values (feature_extractors.py:118-139) as a stand-alone pass; X == Y allowed. */
+int fd_compress_spec(const float* X, float* Y, long long n, float alpha, float beta, int inverse, void* stream);
 int fd_num_frames(int L, int hop);     /* 1 + L / hop */
 int fd_padded_frames(int T);           /* next multiple of 64 */
 
@@ -183,7 +194,7 @@ typedef struct fd_model_config {
   int n_fft;             /* 1534 */
   int hop;               /* 384 */
   float alpha, beta;     /* 0.3, 0.33 */
-  int act_dtype;         /* FD_BF16 (bf16 storage + bf16 MFMA) or FD_F32 (f32 storage + exact f32 MFMA) */
+  int act_dtype;         /* FD_BF16 (bf16 storage + bf16 MFMA) [| FD_WINOGRAD | FD_WINOGRAD_LOWRES] or FD_F32 (f32 storage + exact f32 MFMA) */
 } fd_model_config;
 
 int fd_model_create(const fd_model_config* cfg, fd_model** out);
@@ -220,9 +231,14 @@ size_t fd_ode_adaptive_workspace_bytes(const fd_model* m, int B, int T_pad);
 int fd_ode_solve_adaptive(fd_model* m, const float* Y, const float* noise, float sigma_fac, int N, float atol, float rtol,
                           float* X_out, float* traj, int* nfe_out, int B, int T_pad, void* ws, size_t ws_bytes, void* stream);
 size_t fd_enhance_workspace_bytes(const fd_model* m, int B, int L);
+/* Byte offset, inside the workspace of fd_enhance / fd_score_enhance / fd_regression_enhance, of the B float32 normalisation
+ * factors the front end computed (EnhancementModel._preprocess' `normfac`, model.py:156-162); valid after the call. */
+size_t fd_enhance_normfac_offset(const fd_model* m, int B, int L);
 /* FlowModel.enhance (model.py:476-528) end to end on device buffers: y [B][L] f32 -> x_hat [B][L] f32. */
 int fd_enhance(fd_model* m, const float* y, const float* noise, float sigma_fac, int N, int solver, float* x_hat, int B,
                int L, void* ws, size_t ws_bytes, int use_graph, void* stream);
+/* normalize_mode of the model's front end: 1 = 'noisy' (default), 0 = 'none' (model.py:52, util/other.py:70). */
+int fd_model_set_normalize(fd_model* m, int normalize);
 
 /* ---- ScoreDec / regression baselines on the same backbone -------------------------------
  * ScoreModel.enhance (model.py:630-657) with the predictor-corrector sampler of sampling/__init__.py:32-72 on the OUVE
@@ -266,6 +282,9 @@ int fd_regression_enhance(fd_model* m, const float* y, float* x_hat, int B, int 
 int fd_profile_enable(fd_model* m, int enable);
 int fd_profile_read(fd_model* m, double* conv_ms_total, long long* conv_launches, double* conv_flops_total,
                     double* conv_bytes_total /* algorithmic HBM bytes: operands read once + output written once */);
+/* Same for the HBM-bound FIR resampling launches (fd_fir_resample inside the model): total time, launches and algorithmic
+ * bytes (input read once + every output written once) since fd_profile_enable. */
+int fd_profile_read_fir(fd_model* m, double* ms_total, long long* launches, double* bytes_total);
 
 #ifdef __cplusplus
 }

@@ -33,12 +33,9 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--stats", type=int, default=1)
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    from flowdec_amd import _lib as L
-    L.check(L.load().fd_tuning_set(b"conv_variant", a.variant))
     g = torch.Generator(device="cuda").manual_seed(0)
     for i, (name, H, W, C0, C1, Cout, k, aff, skip) in enumerate(SHAPES):
         if a.only >= 0 and i != a.only:

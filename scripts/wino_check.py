@@ -99,7 +99,7 @@ SHAPES = [  # name, H, W, C0, C1, Cout, affine, skip, S
 ]
 
 
-def timing(B, iters, rounds, only):
+def timing(B, iters, rounds, only, algos=(False, True)):
     g = torch.Generator(device="cuda").manual_seed(1)
     for i, (name, H, W, C0, C1, Cout, aff, skip, S) in enumerate(SHAPES):
         if only >= 0 and i != only:
@@ -119,7 +119,7 @@ def timing(B, iters, rounds, only):
             wsc = torch.randn(Cout, S, 1, 1, device="cuda", generator=g) / S ** 0.5
         fl = 2.0 * B * H * W * Cout * (Cin * 9 + S)
         fs = {}
-        for wino in (False, True):
+        for wino in algos:
             pw = ops.pack_conv_weight(w, C0=C0, dtype=torch.bfloat16, w_sc=wsc, S0=min(S, 256) if S else None, winograd=wino)
             fs[wino] = (lambda pw=pw, wino=wino: ops.conv2d(x0, pw, Cout, 3, x1=x1, affine=affine, bias=bias, skip=sk, scale=0.7071, sc0=sc0,
                                                             sc1=sc1, want_stats=True, winograd=wino))
@@ -136,6 +136,10 @@ def timing(B, iters, rounds, only):
                 e1.record()
                 torch.cuda.synchronize()
                 best[wino] = min(best[wino], e0.elapsed_time(e1) / iters)
+        if len(algos) < 2:
+            a = algos[0]
+            print(f"time {i:2d} {name:26s} B={B} {'wino' if a else 'direct'} {best[a]:7.3f} ms {fl / best[a] / 1e9:7.1f} TF", flush=True)
+            continue
         print(f"time {i:2d} {name:26s} B={B} direct {best[False]:7.3f} ms {fl / best[False] / 1e9:7.1f} TF | wino {best[True]:7.3f} ms "
               f"{fl / best[True] / 1e9:7.1f} TF(eff)  x{best[False] / best[True]:.3f}", flush=True)
 
@@ -148,8 +152,9 @@ if __name__ == "__main__":
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-timing", action="store_true")
+    ap.add_argument("--algo", default="both", choices=["both", "direct", "wino"])
     a = ap.parse_args()
     bad = 0 if a.no_parity else parity()
     if not a.no_timing:
-        timing(a.B, a.iters, a.rounds, a.only)
+        timing(a.B, a.iters, a.rounds, a.only, {"both": (False, True), "direct": (False,), "wino": (True,)}[a.algo])
     sys.exit(1 if bad else 0)

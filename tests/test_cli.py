@@ -1,5 +1,6 @@
 """enhance.py-equivalent driver and checkpoint reader."""
 import os
+from collections.abc import Mapping, Sequence
 
 import numpy as np
 import pytest
@@ -73,6 +74,41 @@ def test_checkpoint_reader_cpu():
         model_from_checkpoint({"state_dict": broken}, ema=False)
 
 
+class _FakeDictConfig(Mapping):
+    """Stands in for omegaconf.DictConfig (what Lightning stores for save_hyperparameters(full_config), model.py:60-63):
+    a Mapping that is NOT a dict, with nested nodes of the same kind and list-like nodes that are not lists."""
+
+    def __init__(self, d):
+        self._d = {k: (_FakeDictConfig(v) if isinstance(v, dict) else (_FakeList(v) if isinstance(v, list) else v)) for k, v in d.items()}
+
+    def __getitem__(self, k): return self._d[k]
+    def __iter__(self): return iter(self._d)
+    def __len__(self): return len(self._d)
+
+
+class _FakeList(Sequence):
+    def __init__(self, v): self._v = list(v)
+    def __getitem__(self, i): return self._v[i]
+    def __len__(self): return len(self._v)
+
+
+def test_checkpoint_reader_non_dict_hyper_parameters():
+    """ablation_higheralpha_75s-style checkpoint: alpha / beta differ from the defaults and hyper_parameters is a DictConfig-like
+    Mapping.  The reader must pick the values up (it used to fall back to alpha = 0.3 / beta = 0.33 silently)."""
+    from flowdec_amd.enhance_cli import model_from_checkpoint
+    ckpt = synthetic_ckpt()
+    hp = ckpt["hyper_parameters"]
+    hp["model"]["feature_extractor"].update(alpha=0.5, beta=0.16)
+    ckpt["hyper_parameters"] = _FakeDictConfig(hp)
+    m = model_from_checkpoint(ckpt)
+    cfg = m.feature_extractor._cfg()
+    assert cfg["alpha"] == pytest.approx(0.5) and cfg["beta"] == pytest.approx(0.16) and m.backbone.nf == 8
+    assert tuple(m.backbone.ch_mult) == (4, 4, 4, 2)
+    ckpt["hyper_parameters"] = 12345        # present but unreadable: refuse instead of guessing
+    with pytest.raises(RuntimeError):
+        model_from_checkpoint(ckpt)
+
+
 @pytest.mark.gpu
 def test_cli_end_to_end(tmp_path):
     from flowdec_amd import enhance_cli
@@ -99,3 +135,16 @@ def test_cli_end_to_end(tmp_path):
     y, _ = enhance_cli.load_wav(str(ind / "a.wav"))
     ref = m.enhance(y, N=2, solver="midpoint", generator=torch.Generator(device="cuda:0").manual_seed(3))
     assert torch.equal(ref, a)
+    # ... and the ORACLE's result on the same checkpoint: the CLI draws its noise with a seeded device generator, file a.wav
+    # (first in sorted order) gets the first draw, so the same tensor can be handed to the oracle (fp32 run, tolerance of the
+    # fp32 waveform parity tests)
+    out32 = tmp_path / "out32"
+    assert enhance_cli.main(["--ckpt", str(tmp_path / "m.ckpt"), "--files", str(ind / "a.wav"), "--single-file", "--outdir", str(out32), "--N", "2",
+                             "--solver", "midpoint", "--seed", "3", "--precision", "fp32"]) == 1
+    a32, _ = enhance_cli.load_wav(str(out32 / "a.wav"))
+    Tp = O.padded_frames(O.num_frames(24000))
+    noise = torch.randn((1, 1, 768, Tp), dtype=torch.complex64, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(3))
+    sd = {k: v.numpy() for k, v in synthetic_ckpt()["_pl_ema_state_dict"].items() if k.startswith("backbone.")}
+    ref_o = O.enhance(O.NCSNppOracle(sd, nf=8), y.numpy()[None], noise.cpu().numpy(), np.full((768, 1), 0.4), N=2, solver="midpoint")
+    err = float(np.linalg.norm(a32.numpy() - ref_o[0]) / np.linalg.norm(ref_o[0]))
+    assert err < 5e-4, f"CLI vs oracle: {err:.3e}"

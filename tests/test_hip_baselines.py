@@ -98,8 +98,6 @@ def test_score_errors():
         m.enhance(y, corrector="bogus")
     with pytest.raises(ValueError):
         m.enhance(y, sampler_type="bogus")
-    with pytest.raises(NotImplementedError):
-        m.enhance(y, sampler_type="ode", return_preprocess_info=True)
     lib = L.load()
     bad = L.FdScoreConfig(1.5, 0.5, 0.05, 0.03, 0.5, 3, 0, 0, 1, 1)    # sigma_max < sigma_min
     rc = lib.fd_score_enhance(m.backbone.handle(), C.c_void_p(8), C.c_void_p(8), C.byref(bad), C.c_void_p(8), 1, 4800, C.c_void_p(8), 1 << 40, 0, None)

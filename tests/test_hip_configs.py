@@ -1,0 +1,293 @@
+"""GPU tests of the BASELINE.json configurations at their real sizes (size-independent properties + parity where a golden
+vector exists), of the reference API surface that sits beside `enhance()` (feature extractor modules, _preprocess /
+_postprocess, normalize_mode, return_preprocess_info of the baselines) and of the Winograd convolution path."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import flowdec_oracle as O
+from test_hip_model import TOL_FWD, TOL_WAVE, cu, make_model
+from test_hip_ops import DT, check, dev, from_nhwc, nhwc, report
+
+pytestmark = pytest.mark.gpu
+
+
+def _preset_model(preset, nf, seed, precision, **kw):
+    import flowdec_amd
+    m = flowdec_amd.from_preset(preset, precision=precision, nf=nf, **kw)
+    sd = {k: torch.from_numpy(v) for k, v in O.random_state_dict(seed=seed, nf=nf).items()}
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys
+    return m.cuda(), {k: v.numpy() for k, v in sd.items()}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# full-width enhance against the REFERENCE (golden G17: FlowModel.enhance, nf = 64, one 0.5 s clip, headline solver settings)
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("solver,N", [("euler", 6), ("midpoint", 3)])
+def test_enhance_full_width_golden(solver, N, prec):
+    g = load_golden("g17_enhance_nf64.npz")
+    m = make_model(64, int(g["seed"]), prec)
+    x = m.enhance(torch.from_numpy(g["y"]), N=N, solver=solver, noise=torch.from_numpy(g["noise"]))
+    assert x.shape == (1, 1, 24000)
+    check(f"enhance_nf64[{solver},N={N},{prec}]", x.numpy(), g[f"{solver}_N{N}"], TOL_WAVE[prec])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# cfg 3: FlowDec-25s (per-frequency sigma_y curve of data/flowdec_autoparams_25s.npy), midpoint N = 3 (NFE 6)
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_flowdec_25s_midpoint_vs_oracle(prec):
+    m, sd = _preset_model("flowdec_25s", 8, 8, prec)
+    sig = m.sigma_y.detach().cpu().numpy()
+    assert sig.shape == (768, 1) and float(sig.std()) > 0          # a curve, not a scalar
+    g12 = load_golden("g12_sigma_y.npz")
+    assert np.allclose(sig, g12["25s"], rtol=1e-12)
+    rng = np.random.default_rng(25)
+    L = 19200
+    y = (0.1 * rng.standard_normal((2, 1, L))).astype(np.float32)
+    Tp = O.padded_frames(O.num_frames(L))
+    noise = ((rng.standard_normal((2, 1, 768, Tp)) + 1j * rng.standard_normal((2, 1, 768, Tp))) / np.sqrt(2)).astype(np.complex64)
+    out = m.enhance(torch.from_numpy(y), N=3, solver="midpoint", noise=torch.from_numpy(noise))
+    ref = O.enhance(O.NCSNppOracle(sd, nf=8), y, noise, sig, N=3, solver="midpoint")
+    check(f"enhance_flowdec_25s[midpoint,N=3,{prec}]", out.numpy(), ref, TOL_WAVE[prec])
+
+
+def _size_properties(m, B, seconds, N, solver, tag):
+    """finite output; hipGraph replay == eager launches; every clip alone == the same clip inside the batch."""
+    Lw = int(seconds * 48000)
+    gen = torch.Generator(device="cuda").manual_seed(17)
+    y = 0.1 * torch.randn(B, 1, Lw, device="cuda", generator=gen)
+    from flowdec_amd import _lib as L_
+    lib = L_.load()
+    Tp = lib.fd_padded_frames(lib.fd_num_frames(Lw, 384))
+    nz = torch.randn(B, 1, 768, Tp, dtype=torch.complex64, device="cuda", generator=gen)
+    eager = m.enhance(y, N=N, solver=solver, noise=nz, use_graph=False)
+    assert eager.shape == (B, 1, Lw) and torch.isfinite(eager).all() and float(eager.abs().max()) > 0
+    m.enhance(y, N=N, solver=solver, noise=nz, use_graph=True)             # first sighting of the shape: eager
+    cap = m.enhance(y, N=N, solver=solver, noise=nz, use_graph=True)       # captured
+    rep = m.enhance(y, N=N, solver=solver, noise=nz, use_graph=True)       # replayed
+    assert torch.equal(eager, cap) and torch.equal(cap, rep), f"{tag}: graph replay differs from eager launches"
+    for b in (0, B - 1):
+        one = m.enhance(y[b:b + 1], N=N, solver=solver, noise=nz[b:b + 1], use_graph=False)
+        e = rel_err(one.cpu().numpy(), eager[b:b + 1].cpu().numpy())
+        report(f"{tag}_clip{b}_independence", e, 1e-6)
+        assert e < 1e-6
+
+
+def test_cfg3_flowdec_25s_b32_full_width():
+    """BASELINE config 3: FlowDec-25s, batch = 32 x 2 s, midpoint (N = 3 -> NFE 6), bf16, full width."""
+    m, _ = _preset_model("flowdec_25s", 64, 64, "bf16")
+    _size_properties(m, 32, 2.0, 3, "midpoint", "cfg3_b32_midpoint")
+
+
+def test_cfg2_flowdec_75m_b8_euler6_full_width():
+    """BASELINE config 2 exactly: FlowDec-75m, batch = 8 x 2 s, 6-step Euler, bf16 (the bench.py workload)."""
+    m = make_model(64, 64, "bf16")
+    _size_properties(m, 8, 2.0, 6, "euler", "cfg2_b8_euler6")
+
+
+def test_cfg5_fp32_4s_32step_and_adaptive():
+    """BASELINE config 5, per-GPU shape: fp32, 8 x 4 s clips, 32 solver steps; the adaptive solver (dopri5 over the same 33-point
+    t_span) runs on 2 of the clips (>= 194 evaluations) and reports its realised NFE."""
+    m = make_model(64, 64, "fp32")
+    Lw = 4 * 48000
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    y = 0.1 * torch.randn(8, 1, Lw, device="cuda", generator=gen)
+    nz = torch.randn(8, 1, 768, 512, dtype=torch.complex64, device="cuda", generator=gen)
+    out = m.enhance(y, N=32, solver="euler", noise=nz)
+    assert out.shape == (8, 1, Lw) and torch.isfinite(out).all() and float(out.abs().max()) > 0
+    one = m.enhance(y[3:4], N=32, solver="euler", noise=nz[3:4])
+    assert rel_err(one.cpu().numpy(), out[3:4].cpu().numpy()) < 1e-6
+    ad = m.enhance(y[:2], N=32, solver="dopri5", noise=nz[:2], atol=1e-2, rtol=1e-2)
+    nfe = m.last_nfe
+    report("cfg5_dopri5_nfe", float(nfe), 1e9)
+    assert ad.shape == (2, 1, Lw) and torch.isfinite(ad).all() and nfe >= 2 + 6 * 32 and (nfe - 2) % 6 == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# reference API surface next to enhance()
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_feature_extractor_modules_golden():
+    """ComplexSTFT.forward / invert and CompressAmplitudesAndScale.forward / invert as stand-alone modules
+    (feature_extractors.py:86-139) against golden G1 (torch.stft / istft of the reference)."""
+    g = load_golden("g1_stft.npz")
+    m = make_model(8, 8, "fp32")
+    fe = m.feature_extractor
+    y = cu(g["y"])
+    S = fe.complex_stft(y)
+    assert S.shape == (2, 1, 768, 13) and S.dtype == torch.complex64
+    check("ComplexSTFT.forward", S.cpu().numpy(), g["stft"], 2e-5)
+    Cc = fe.compress(S)
+    check("Compress.forward", Cc.cpu().numpy(), g["compressed"], 2e-5)
+    check("Compress.invert", fe.compress.invert(cu(g["compressed"])).cpu().numpy(), g["decompressed"], 2e-5)
+    check("ComplexSTFT.invert", fe.complex_stft.invert(cu(g["stft"]), orig_length=4800).cpu().numpy(), g["roundtrip"], 2e-5)
+    check("FE.forward", fe(y).cpu().numpy(), g["compressed"], 2e-5)
+    check("FE.invert_len3000", fe.invert(cu(g["Z"]), orig_length=3000).cpu().numpy(), g["istft_len3000"], 2e-5)
+
+
+def test_preprocess_postprocess_golden():
+    """EnhancementModel._preprocess / _postprocess (model.py:129-190) against golden G3 (normalize_noisy + pad_spec) incl. the
+    silent clip, and as a round trip."""
+    g = load_golden("g3_pad_norm.npz")
+    m = make_model(8, 8, "fp32")
+    Y, info = m._preprocess(torch.from_numpy(g["y"]))
+    assert set(info) == {"orig_length", "normfac", "undo_pad_fn", "squeeze_dims"} and Y.shape == (2, 1, 768, int(g["padded_T"]))
+    assert np.array_equal(info["normfac"].cpu().numpy(), g["normfac"])                       # bit exact, silence guard included
+    assert float(torch.view_as_real(Y[..., int(g["orig_T"]):]).abs().max()) == 0.0           # zero padding of the frame axis
+    assert info["undo_pad_fn"](Y).shape[-1] == int(g["orig_T"])
+    Yo, info_o = O.preprocess(g["y"])                                                         # (G3's `spec` is the un-normalised clip's)
+    assert Yo.shape == tuple(Y.shape) and info_o["T"] == int(g["orig_T"])
+    check("_preprocess", Y.cpu().numpy(), Yo, 2e-5)
+    x = m._postprocess(Y, info)
+    assert x.shape == (2, 1, 4800)
+    check("_postprocess_roundtrip", x.cpu().numpy(), g["y"], 1e-4)
+    x1 = m._postprocess(*m._preprocess(torch.from_numpy(g["y"][0, 0])))                       # 1-D in -> 1-D out
+    assert x1.shape == (4800,)
+
+
+def test_normalize_mode_none_vs_oracle():
+    """normalize_mode = 'none' (model.py:52, util/other.py:70): no level normalisation in front of the STFT."""
+    import flowdec_amd
+    from flowdec_amd.model import BACKBONE_FINAL_NO_ATTN, NCSNpp, AmplitudeCompressedComplexSTFT, FlowModel
+    sd = O.random_state_dict(seed=8, nf=8)
+    bb = dict(BACKBONE_FINAL_NO_ATTN); bb["nf"] = 8
+    fe = AmplitudeCompressedComplexSTFT(window_fn="hann", n_fft=1534, n_hops=4, sampling_rate=48000, alpha=0.3, beta=0.33)
+    m = FlowModel(backbone=NCSNpp(precision="fp32", **bb), feature_extractor=fe, sampling_rate=48000, sigma_y=0.66, normalize_mode="none")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    m = m.cuda().eval()
+    rng = np.random.default_rng(9)
+    L = 12000
+    y = (0.3 * rng.standard_normal((1, 1, L))).astype(np.float32)
+    Tp = O.padded_frames(O.num_frames(L))
+    noise = ((rng.standard_normal((1, 1, 768, Tp)) + 1j * rng.standard_normal((1, 1, 768, Tp))) / np.sqrt(2)).astype(np.complex64)
+    out, info = m.enhance(torch.from_numpy(y), N=2, solver="euler", noise=torch.from_numpy(noise), return_preprocess_info=True)
+    assert float(info["normfac"].cpu().reshape(-1)[0]) == 1.0
+    # the oracle always normalises: feed it the clip pre-scaled so that its max-abs is exactly 1 (normfac = 1) -- identical input
+    ys = (y / np.abs(y).max()).astype(np.float32)
+    out_s = m.enhance(torch.from_numpy(ys), N=2, solver="euler", noise=torch.from_numpy(noise))
+    ref = O.enhance(O.NCSNppOracle(sd, nf=8), ys, noise, 0.66, N=2, solver="euler")
+    check("enhance_normalize_none[fp32]", out_s.numpy(), ref, TOL_WAVE["fp32"])
+    # and the un-normalised call really differs from the normalised one (the network is not scale-equivariant)
+    m2 = flowdec_amd.from_preset("flowdec_75m_globsigy", precision="fp32", nf=8)
+    m2.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    out_n = m2.cuda().enhance(torch.from_numpy(y), N=2, solver="euler", noise=torch.from_numpy(noise))
+    assert rel_err(out.numpy(), out_n.numpy()) > 1e-3
+
+
+def test_baselines_return_preprocess_info():
+    """RegressionModel / ScoreModel.enhance(return_preprocess_info=True) (model.py:575, 654)."""
+    import flowdec_amd
+    sd = {k: torch.from_numpy(v) for k, v in O.random_state_dict(seed=8, nf=8).items()}
+    y = 0.1 * torch.randn(2, 1, 9600, generator=torch.Generator().manual_seed(1))
+    for preset in ("baseline_regression_75s", "baseline_scoredec_75s"):
+        m = flowdec_amd.from_preset(preset, precision="fp32", nf=8)
+        m.load_state_dict(sd, strict=False)
+        m = m.cuda()
+        kw = dict(N=2, generator=torch.Generator(device="cuda").manual_seed(2)) if "score" in preset else {}
+        x, info = m.enhance(y, return_preprocess_info=True, **kw)
+        assert x.shape == (2, 1, 9600) and torch.isfinite(x).all()
+        assert set(info) == {"orig_length", "normfac", "undo_pad_fn", "squeeze_dims"} and info["orig_length"] == 9600
+        assert np.allclose(info["normfac"].cpu().numpy().ravel(), y.abs().amax(dim=(1, 2)).numpy(), rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Winograd F(2,3) convolution path (conv_wino.hip; FD_WINOGRAD)
+# ---------------------------------------------------------------------------------------------------------------------------
+WINO_CASES = [
+    # name, B, H, W, C0, C1, Cout, affine, bias_rows, skip, S0, S1
+    ("basic", 1, 16, 16, 32, 0, 128, False, 0, False, 0, 0),
+    ("two_ntiles_aff_skip", 2, 32, 16, 64, 0, 256, True, 2, True, 0, 0),
+    ("concat", 1, 16, 16, 64, 32, 128, True, 1, True, 0, 0),
+    ("ragged_odd_w", 1, 20, 13, 32, 0, 128, True, 1, True, 0, 0),       # H, W not multiples of the tile; odd W (half tile)
+    ("deepk", 1, 16, 16, 256, 256, 256, True, 1, True, 0, 0),
+    ("shortcut", 2, 16, 16, 256, 0, 256, True, 1, False, 64, 0),         # ResBlock 64 -> 256: Conv_1(h) + Conv_2(x) folded in
+    ("shortcut_cat", 1, 32, 16, 128, 0, 128, True, 1, False, 128, 256),
+    ("multi_tile", 2, 48, 80, 64, 0, 256, True, 2, True, 32, 0),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
+def test_conv2d_winograd(case):
+    """Same contract and same reference as test_hip_ops.test_conv2d (f64 conv of the bf16-rounded operands); the activated
+    operand is rounded to fp16 (not bf16) by this kernel, so the reference keeps it unrounded."""
+    from flowdec_amd import ops
+    import zlib
+    name, B, H, W, C0, C1, Cout, use_aff, bias_rows, use_skip, S0, S1 = case
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    bf = lambda a: O.round_bf16(np.asarray(a, np.float32))
+    Cin = C0 + C1
+    x = bf(rng.standard_normal((B, Cin, H, W)))
+    w = bf(rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9))
+    aff, xin = None, x
+    if use_aff:
+        a = (1 + 0.2 * rng.standard_normal((B, Cin))).astype(np.float32)
+        d = (0.3 * rng.standard_normal((B, Cin))).astype(np.float32)
+        aff = dev(np.stack([a, d], axis=-1))
+        xin = O.silu(x * a[:, :, None, None] + d[:, :, None, None]).astype(np.float32)
+    ref = O.conv2d(xin.astype(np.float64), w.astype(np.float64), None)
+    sc0 = sc1 = w_sc = None
+    if S0:
+        xs = bf(rng.standard_normal((B, S0 + S1, H, W)))
+        ws = bf(rng.standard_normal((Cout, S0 + S1, 1, 1)) / np.sqrt(S0 + S1))
+        ref = ref + O.conv2d(xs.astype(np.float64), ws.astype(np.float64), None)
+        sc0 = nhwc(xs[:, :S0], torch.bfloat16)
+        sc1 = nhwc(xs[:, S0:], torch.bfloat16) if S1 else None
+        w_sc = dev(ws)
+    bias = None
+    if bias_rows:
+        bv = rng.standard_normal((bias_rows, Cout)).astype(np.float32)
+        bias = dev(bv if bias_rows > 1 else bv[0])
+        ref = ref + (bv[:, :, None, None] if bias_rows > 1 else bv[0][None, :, None, None])
+    skip, scale = None, 1.0
+    if use_skip:
+        sk = bf(rng.standard_normal((B, Cout, H, W)))
+        skip = nhwc(sk, torch.bfloat16)
+        ref = ref + sk
+        scale = float(1 / np.sqrt(2))
+    ref = ref * scale
+    x0 = nhwc(x[:, :C0], torch.bfloat16)
+    x1 = nhwc(x[:, C0:], torch.bfloat16) if C1 else None
+    pw = ops.pack_conv_weight(dev(w), C0=C0, dtype=torch.bfloat16, w_sc=w_sc, S0=S0 if S0 else None, winograd=True)
+    out, stats = ops.conv2d(x0, pw, Cout, 3, x1=x1, affine=aff, bias=bias, skip=skip, scale=scale, sc0=sc0, sc1=sc1, want_stats=True, winograd=True)
+    torch.cuda.synchronize()
+    # error budget: bf16 rounding of the stored output (2^-9) dominates; operands fp16 (2^-11), Winograd transform in fp16
+    check(f"conv2d_winograd[{name}]", from_nhwc(out), ref, 6e-3)
+    st = stats.double().sum(dim=1).cpu().numpy()[:, :Cout]
+    ref_s = np.stack([ref.sum(axis=(2, 3)), (ref ** 2).sum(axis=(2, 3))], axis=-1)
+    e = float(np.abs(st - ref_s).max() / np.abs(ref_s).max())
+    report(f"conv2d_winograd_stats[{name}]", e, 3e-3)
+    assert e < 3e-3
+    # and against the direct MFMA kernel on the same inputs (both round their output to bf16: they agree to ~1 bf16 ulp)
+    pd = ops.pack_conv_weight(dev(w), C0=C0, dtype=torch.bfloat16, w_sc=w_sc, S0=S0 if S0 else None)
+    outd = ops.conv2d(x0, pd, Cout, 3, x1=x1, affine=aff, bias=bias, skip=skip, scale=scale, sc0=sc0, sc1=sc1)
+    assert rel_err(from_nhwc(out), from_nhwc(outd)) < 6e-3
+
+
+def test_conv2d_winograd_rejects_unsupported():
+    from flowdec_amd import ops
+    w = torch.randn(64, 32, 3, 3, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.pack_conv_weight(w, dtype=torch.bfloat16, winograd=True)          # Cout % 128 != 0
+    with pytest.raises(RuntimeError):
+        ops.pack_conv_weight(torch.randn(128, 32, 1, 1, device="cuda"), dtype=torch.bfloat16, winograd=True)   # 1x1
+    with pytest.raises(RuntimeError):
+        ops.pack_conv_weight(torch.randn(128, 32, 3, 3, device="cuda"), dtype=torch.float32, winograd=True)    # f32 storage
+
+
+@pytest.mark.parametrize("algo", ["winograd", "winograd_lowres"])
+def test_model_winograd_parity(algo):
+    """The whole network with the Winograd kernel on every supported 3x3 convolution (or on the low-resolution levels only):
+    full-width forward against the reference golden G10, full enhance against G17 -- at the bf16 mode's tolerances."""
+    import flowdec_amd
+    g = load_golden("g10_ncsnpp_nf64.npz")
+    m = flowdec_amd.from_preset("flowdec_75m", precision="bf16", conv_algo=algo)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in O.random_state_dict(seed=int(g["seed"]), nf=64).items()}, strict=False)
+    m = m.cuda()
+    out = m(cu(g["x"]), cu(g["y"]), torch.tensor([0.5], device="cuda"))
+    check(f"ncsnpp_nf64[bf16,{algo}]", out.cpu().numpy(), g["out"], TOL_FWD["bf16"])
+    g17 = load_golden("g17_enhance_nf64.npz")
+    x = m.enhance(torch.from_numpy(g17["y"]), N=6, solver="euler", noise=torch.from_numpy(g17["noise"]))
+    check(f"enhance_nf64[euler,N=6,bf16,{algo}]", x.numpy(), g17["euler_N6"], TOL_WAVE["bf16"])

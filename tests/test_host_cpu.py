@@ -143,6 +143,39 @@ def test_batch_sharding_gloo_world2(tmp_path):
     assert all("ok" in o for o in outs)
 
 
+def test_bench_self_launch_gloo_world2():
+    """`python bench.py --gpus 2` WITHOUT a launcher re-executes itself under torch.distributed.run with two ranks, shards the
+    global batch by clip, all-gathers the results inside the timed region and prints ONE line with n_gpus = the real world size
+    (here: gloo + a stub step, the model needs a GPU; the code path -- relaunch, sharded_apply, timing reduction -- is the
+    one the multi-GPU bench takes)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub-step", "--steps", "2",
+                        "--warmup", "1", "--seconds", "0.01", "--batch", "3"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 6 and res["scaling"] == "weak" and len(res["per_rank_ms_per_step"]) == 2
+    assert res["config"]["parallelism"] == "batch-shard x2" and res["allgather_ms_per_step"] > 0
+    # strong scaling form: the global batch is fixed and split
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub-step", "--steps", "1",
+                        "--warmup", "0", "--seconds", "0.01", "--global-batch", "5"], env=env, capture_output=True, text=True, timeout=300)
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 5 and res["scaling"] == "strong"
+
+
+def test_bench_refuses_missing_gpus():
+    """Never a silent N = 1 line: asking for more GPUs than the box has must fail loudly (this container has none)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has the GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stdout + r.stderr) and "{" not in r.stdout
+
+
 def test_parity_metrics_match_reference():
     """SI-SDR / SI-SIR / SI-SAR equal the reference's eval/metrics.py SISXR on the golden signals; logspec_mse properties."""
     from conftest import load_golden
