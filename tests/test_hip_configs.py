@@ -7,7 +7,7 @@ import torch
 
 from conftest import load_golden, rel_err
 from oracle import flowdec_oracle as O
-from test_hip_model import TOL_FWD, TOL_WAVE, cu, make_model
+from test_hip_model import TOL_FWD, TOL_WAVE, TOL_WAVE_FULL, cu, make_model
 from test_hip_ops import DT, check, dev, from_nhwc, nhwc, report
 
 pytestmark = pytest.mark.gpu
@@ -32,7 +32,7 @@ def test_enhance_full_width_golden(solver, N, prec):
     m = make_model(64, int(g["seed"]), prec)
     x = m.enhance(torch.from_numpy(g["y"]), N=N, solver=solver, noise=torch.from_numpy(g["noise"]))
     assert x.shape == (1, 1, 24000)
-    check(f"enhance_nf64[{solver},N={N},{prec}]", x.numpy(), g[f"{solver}_N{N}"], TOL_WAVE[prec])
+    check(f"enhance_nf64[{solver},N={N},{prec}]", x.numpy(), g[f"{solver}_N{N}"], TOL_WAVE_FULL[prec])
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -290,4 +290,4 @@ def test_model_winograd_parity(algo):
     check(f"ncsnpp_nf64[bf16,{algo}]", out.cpu().numpy(), g["out"], TOL_FWD["bf16"])
     g17 = load_golden("g17_enhance_nf64.npz")
     x = m.enhance(torch.from_numpy(g17["y"]), N=6, solver="euler", noise=torch.from_numpy(g17["noise"]))
-    check(f"enhance_nf64[euler,N=6,bf16,{algo}]", x.numpy(), g17["euler_N6"], TOL_WAVE["bf16"])
+    check(f"enhance_nf64[euler,N=6,bf16,{algo}]", x.numpy(), g17["euler_N6"], TOL_WAVE_FULL["bf16"])
