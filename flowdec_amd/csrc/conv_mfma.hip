@@ -119,96 +119,8 @@ struct Geo {
   static_assert(HITER <= 6, "the halo is converted in three groups of at most two slots");
 };
 
-
-#ifndef FD_ASM_CLUSTER
-#define FD_ASM_CLUSTER 0
-#endif
-// MFMA cluster of one phase of the 8-wave bf16 configuration (wave tile 4 pixel patches x 2 cout tiles), hand-placed: the 8
-// MFMAs of one k-half with the 6 operand reads of the NEXT phase between them and a single s_waitcnt in front (the operands
-// were read a whole cluster earlier).  hipcc's own schedule of the same work pairs most MFMAs with a wait for the read it has
-// just issued (lgkmcnt(0) between every MFMA).  The reads are invisible to hipcc's counters; every cluster waits for the reads
-// of the previous one itself, and nothing else touches the operand registers in between.
-// waddr / paddr: LDS byte addresses of the lane's first weight row (cout tile 1 = + 2048 B: the XOR swizzle does not depend on
-// the tile) and of its pixel in patch 0 (patches 1..3 = + 8 columns, + 4 rows, + both).
-template <int P1, int P2>
-__device__ __forceinline__ void mma_cluster_bf16(f32x16 (&acc)[4][2], const u32x4 (&wf)[2], const u32x4 (&pf)[4], u32x4 (&nwf)[2], u32x4 (&npf)[4],
-                                                 int waddr, int paddr) {
-  asm volatile(
-      "s_waitcnt lgkmcnt(0)\n\t"
-#ifdef FD_SETPRIO
-      "s_setprio 1\n\t"
-#endif
-      "v_mfma_f32_32x32x16_bf16 %[a00], %[w0], %[p0], %[a00]\n\t"
-      "ds_read_b128 %[nw0], %[wa]\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a10], %[w0], %[p1], %[a10]\n\t"
-      "ds_read_b128 %[nw1], %[wa] offset:2048\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a20], %[w0], %[p2], %[a20]\n\t"
-      "ds_read_b128 %[np0], %[pa]\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a30], %[w0], %[p3], %[a30]\n\t"
-      "ds_read_b128 %[np1], %[pa] offset:%[o1]\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a01], %[w1], %[p0], %[a01]\n\t"
-      "ds_read_b128 %[np2], %[pa] offset:%[o2]\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a11], %[w1], %[p1], %[a11]\n\t"
-      "ds_read_b128 %[np3], %[pa] offset:%[o3]\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a21], %[w1], %[p2], %[a21]\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a31], %[w1], %[p3], %[a31]"
-#ifdef FD_SETPRIO
-      "\n\ts_setprio 0"
-#endif
-      : [a00] "+v"(acc[0][0]), [a10] "+v"(acc[1][0]), [a20] "+v"(acc[2][0]), [a30] "+v"(acc[3][0]), [a01] "+v"(acc[0][1]), [a11] "+v"(acc[1][1]),
-        [a21] "+v"(acc[2][1]), [a31] "+v"(acc[3][1]), [nw0] "=&v"(nwf[0]), [nw1] "=&v"(nwf[1]), [np0] "=&v"(npf[0]), [np1] "=&v"(npf[1]),
-        [np2] "=&v"(npf[2]), [np3] "=&v"(npf[3])
-      : [w0] "v"(wf[0]), [w1] "v"(wf[1]), [p0] "v"(pf[0]), [p1] "v"(pf[1]), [p2] "v"(pf[2]), [p3] "v"(pf[3]), [wa] "v"(waddr), [pa] "v"(paddr),
-        [o1] "i"(P1), [o2] "i"(P2), [o3] "i"(P1 + P2)
-      : "memory");
-}
-
-
-// The same for the 4-wave configuration (wave tile 4 pixel patches x 4 cout tiles = 256 accumulator registers, ONE wave per
-// SIMD, 0.5 instead of 0.75 operand reads per MFMA): 16 MFMAs + 8 reads as two statements (inline asm takes 30 operands).
-template <int P1, int P2>
-__device__ __forceinline__ void mma_cluster_bf16_4x4(f32x16 (&acc)[4][4], const u32x4 (&wf)[4], const u32x4 (&pf)[4], u32x4 (&nwf)[4], u32x4 (&npf)[4],
-                                                     int waddr, int paddr) {
-  asm volatile(
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a00], %[w0], %[p0], %[a00]\n\t"
-      "ds_read_b128 %[nw0], %[wa]\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a10], %[w0], %[p1], %[a10]\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a20], %[w0], %[p2], %[a20]\n\t"
-      "ds_read_b128 %[nw1], %[wa] offset:2048\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a30], %[w0], %[p3], %[a30]\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a01], %[w1], %[p0], %[a01]\n\t"
-      "ds_read_b128 %[nw2], %[wa] offset:4096\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a11], %[w1], %[p1], %[a11]\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a21], %[w1], %[p2], %[a21]\n\t"
-      "ds_read_b128 %[nw3], %[wa] offset:6144\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a31], %[w1], %[p3], %[a31]"
-      : [a00] "+a"(acc[0][0]), [a10] "+a"(acc[1][0]), [a20] "+a"(acc[2][0]), [a30] "+a"(acc[3][0]), [a01] "+a"(acc[0][1]), [a11] "+a"(acc[1][1]),
-        [a21] "+a"(acc[2][1]), [a31] "+a"(acc[3][1]), [nw0] "=&v"(nwf[0]), [nw1] "=&v"(nwf[1]), [nw2] "=&v"(nwf[2]), [nw3] "=&v"(nwf[3])
-      : [w0] "v"(wf[0]), [w1] "v"(wf[1]), [p0] "v"(pf[0]), [p1] "v"(pf[1]), [p2] "v"(pf[2]), [p3] "v"(pf[3]), [wa] "v"(waddr)
-      : "memory");
-  asm volatile(
-      "v_mfma_f32_32x32x16_bf16 %[a02], %[w2], %[p0], %[a02]\n\t"
-      "ds_read_b128 %[np0], %[pa]\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a12], %[w2], %[p1], %[a12]\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a22], %[w2], %[p2], %[a22]\n\t"
-      "ds_read_b128 %[np1], %[pa] offset:%[o1]\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a32], %[w2], %[p3], %[a32]\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a03], %[w3], %[p0], %[a03]\n\t"
-      "ds_read_b128 %[np2], %[pa] offset:%[o2]\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a13], %[w3], %[p1], %[a13]\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a23], %[w3], %[p2], %[a23]\n\t"
-      "ds_read_b128 %[np3], %[pa] offset:%[o3]\n\t"
-      "v_mfma_f32_32x32x16_bf16 %[a33], %[w3], %[p3], %[a33]"
-      : [a02] "+a"(acc[0][2]), [a12] "+a"(acc[1][2]), [a22] "+a"(acc[2][2]), [a32] "+a"(acc[3][2]), [a03] "+a"(acc[0][3]), [a13] "+a"(acc[1][3]),
-        [a23] "+a"(acc[2][3]), [a33] "+a"(acc[3][3]), [np0] "=&v"(npf[0]), [np1] "=&v"(npf[1]), [np2] "=&v"(npf[2]), [np3] "=&v"(npf[3])
-      : [w2] "v"(wf[2]), [w3] "v"(wf[3]), [p0] "v"(pf[0]), [p1] "v"(pf[1]), [p2] "v"(pf[2]), [p3] "v"(pf[3]), [pa] "v"(paddr), [o1] "i"(P1), [o2] "i"(P2),
-        [o3] "i"(P1 + P2)
-      : "memory");
-}
-
 template <typename T, int WM, int WN, int MT, int NT, bool SKIP>
-__global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void conv_mfma_kernel(ConvArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) {
   using G = Geo<WM, WN, MT, NT>;
   constexpr int EPS = Math<T>::EPS;
   constexpr int CK = 4 * EPS;
@@ -410,19 +322,6 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void conv_mf
 #endif
   };
 
-  // one phase: the operand reads of the NEXT k-half (-> wfN / pfN) together with the MFMAs of the current one (wfC / pfC)
-  constexpr bool ASMC = FD_ASM_CLUSTER != 0 && sizeof(T) == 2 && MT == 4 && (NT == 2 || NT == 4);
-  auto read_mma = [&](u32x4 (&wfN)[NT], u32x4 (&pfN)[MT], const char* hb, const char* wb, int off, int ks, u32x4 (&wfC)[NT], u32x4 (&pfC)[MT]) {
-    if constexpr (ASMC) {
-      constexpr int P1 = 8 * ROWB, P2 = 4 * PITCH * ROWB;   // patch (pi & 1) = + 8 columns, (pi >> 1) = + 4 rows
-      if constexpr (NT == 2) mma_cluster_bf16<P1, P2>(acc, wfC, pfC, wfN, pfN, (int)(wb - smem) + wbase[ks][0], (int)(hb - smem) + pbase[0] + off + 32 * ks);
-      else mma_cluster_bf16_4x4<P1, P2>(acc, wfC, pfC, wfN, pfN, (int)(wb - smem) + wbase[ks][0], (int)(hb - smem) + pbase[0] + off + 32 * ks);
-    } else {
-      read_frags(wfN, pfN, hb, wb, off, ks);
-      mma_all(wfC, pfC);
-    }
-  };
-
   int step = 0, hcur = 0;   // step = running (chunk, tap) index = index of the weight slab in K order
   int fetch = 0;            // next slab to DMA; slab i lives in ring slot i % NWBUF
   const int last_step = nsteps - 1;
@@ -492,7 +391,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void conv_mf
         for (int k = 0; k < G::HPG; ++k)
           if ((tap - 3) / 2 * G::HPG + k < G::HITER) store_halo_slot((tap - 3) / 2 * G::HPG + k, hcur ^ 1);
       }
-      read_mma(wfB, pfB, hb, wb, imm, 1, wfA, pfA);
+      read_frags(wfB, pfB, hb, wb, imm, 1);
+      mma_all(wfA, pfA);
       if (barrier_here) {
         // everything issued after the previous barrier has landed and is published; all reads of the finished group's
         // slabs are complete, so their ring slots are refilled with the next slabs in K order
@@ -508,8 +408,9 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void conv_mf
 #pragma unroll
         for (int k = 0; k < G::HITER; ++k) load_halo_slot(k);
       }
-      if (tap < 8) read_mma(wfA, pfA, hb, wbn, imm_next, 0, wfB, pfB);
-      else read_mma(wfA, pfA, hbn, wbn, first_off_next, 0, wfB, pfB);
+      if (tap < 8) read_frags(wfA, pfA, hb, wbn, imm_next, 0);
+      else read_frags(wfA, pfA, hbn, wbn, first_off_next, 0);
+      mma_all(wfB, pfB);
       ++step;
     }
     hcur ^= 1;
@@ -525,15 +426,17 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void conv_mf
     // the next 1-tap chunk's halo: loaded and published within this step
 #pragma unroll
     for (int k = 0; k < G::HITER; ++k) load_halo_slot(k);
-    read_mma(wfB, pfB, hb, wb, CENTER, 1, wfA, pfA);
+    read_frags(wfB, pfB, hb, wb, CENTER, 1);
+    mma_all(wfA, pfA);
 #pragma unroll
     for (int k = 0; k < G::HITER; ++k) store_halo_slot(k, hcur ^ 1);
     block_sync();
     fetch_slabs(1);
-    read_mma(wfA, pfA, hbn, wbn, CENTER, 0, wfB, pfB);
+    read_frags(wfA, pfA, hbn, wbn, CENTER, 0);
+    mma_all(wfB, pfB);
     ++step; hcur ^= 1;
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // all fragment reads / DMA done before the epilogue reuses the LDS
 
 #ifdef FD_TIMING2
@@ -787,9 +690,6 @@ template <typename T>
 int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   if (a.Cout <= 32) return launch_conv<T, 4, 1, 2, 1>(a, st);                             // 4 waves, BN = 32 (pyramid heads)
   if (a.Cout <= 128) return launch_conv<T, 4, 2, 2, 2>(a, st);                             // 8 waves, BN = 128
-#ifdef FD_BIGTILE   // experiment: 4 waves x (128 px x 128 cout), one wave per SIMD
-  if constexpr (sizeof(T) == 2) return launch_conv<T, 2, 2, 4, 4>(a, st);
-#endif
   return launch_conv<T, 2, 4, 4, 2>(a, st);                                               // 8 waves, BN = 256
 }
 
@@ -806,9 +706,6 @@ int fd_conv_init_attributes() {
   if (known && done_dev[dev]) return FD_OK;
   FD_TRY((set_attr<bf16, 4, 1, 2, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2>()));
   FD_TRY((set_attr<float, 4, 1, 2, 1>())); FD_TRY((set_attr<float, 4, 2, 2, 2>())); FD_TRY((set_attr<float, 2, 4, 4, 2>()));
-#ifdef FD_BIGTILE
-  FD_TRY((set_attr<bf16, 2, 2, 4, 4>()));
-#endif
   FD_TRY(fd_wino_init_attributes());
   if (known) done_dev[dev] = true;
   return FD_OK;
