@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--N", type=int, default=6)
     ap.add_argument("--solver", default="euler")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--conv-algo", default="direct", choices=["direct", "winograd", "winograd_lowres"])
+    ap.add_argument("--conv-algo", default="auto", choices=["direct", "winograd", "winograd_lowres", "auto"])
     ap.add_argument("--preset", default="flowdec_75m")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -258,7 +258,7 @@ def main():
         # HBM bytes per launch from the committed PMC passes of this same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # corrected as profiles/summarize_pmc.py documents); PMC counters cannot be collected from inside the timed run.
         default_cfg = (args.preset, args.precision, args.solver, args.N, gbatch, args.seconds, args.conv_algo) == \
-            ("flowdec_75m", "bf16", "euler", 6, 8, 2.0, "direct")
+            ("flowdec_75m", "bf16", "euler", 6, 8, 2.0, "auto")
         tf = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
         if default_cfg and os.path.exists(tf):
             with open(tf) as f:

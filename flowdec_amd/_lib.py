@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("FLOWDEC_HIP_LIB") or os.path.join(_HERE, "libflowdec_
 FD_F32, FD_BF16 = 0, 1
 FD_WINOGRAD = 0x100  # algorithm flag OR-ed into a dtype argument (include/flowdec_hip.h)
 FD_WINOGRAD_LOWRES = 0x200
+FD_WINOGRAD_AUTO = 0x400
 SOLVERS = {"euler": 0, "midpoint": 1, "heun2": 2, "heun2_eulerlast": 3}
 
 c_void_p, c_int, c_float, c_ll, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t

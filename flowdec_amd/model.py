@@ -61,8 +61,8 @@ class Combine(nn.Module):
 
 DEFAULT_OUTPUTLAYER_KWARGS = dict(kernel_size=3, bias=False, padding="same", padding_mode="zeros")
 # 3x3 convolution algorithm of the bf16 mode: direct MFMA implicit GEMM, Winograd F(2,3) wherever the shape allows it, or
-# Winograd only at the low-resolution levels (see include/flowdec_hip.h: FD_WINOGRAD / FD_WINOGRAD_LOWRES)
-CONV_ALGOS = {"direct": 0, "winograd": L.FD_WINOGRAD, "winograd_lowres": L.FD_WINOGRAD_LOWRES}
+# Winograd only at the low-resolution levels, or chosen per launch by grid fill ('auto'; include/flowdec_hip.h: FD_WINOGRAD*)
+CONV_ALGOS = {"direct": 0, "winograd": L.FD_WINOGRAD, "winograd_lowres": L.FD_WINOGRAD_LOWRES, "auto": L.FD_WINOGRAD_AUTO}
 
 
 class NCSNpp(nn.Module):
@@ -80,7 +80,7 @@ class NCSNpp(nn.Module):
                  progressive_input="input_skip", progressive_combine="sum", init_scale=0.0, fourier_scale=16,
                  image_size=256, embedding_type="fourier", dropout=0.0, num_channels=4,
                  output_layer_kwargs: dict = DEFAULT_OUTPUTLAYER_KWARGS, bottleneck_attn: bool = True,
-                 precision: str = "bf16", conv_algo: str = "direct"):
+                 precision: str = "bf16", conv_algo: str = "auto"):
         super().__init__()
         ch_mult = tuple(ch_mult)
         all_res = [image_size // (2 ** i) for i in range(len(ch_mult))]
@@ -101,8 +101,10 @@ class NCSNpp(nn.Module):
             raise NotImplementedError("flowdec_amd.NCSNpp: unsupported configuration: " + "; ".join(unsupported))
         if precision not in ("bf16", "fp32"):
             raise ValueError("precision must be 'bf16' or 'fp32'")
-        if conv_algo not in CONV_ALGOS or (conv_algo != "direct" and precision != "bf16"):
-            raise ValueError(f"conv_algo must be one of {sorted(CONV_ALGOS)} ('direct' only with precision='fp32')")
+        if conv_algo not in CONV_ALGOS or (conv_algo not in ("direct", "auto") and precision != "bf16"):
+            raise ValueError(f"conv_algo must be one of {sorted(CONV_ALGOS)} (the Winograd kernel exists for precision='bf16' only)")
+        if precision != "bf16":
+            conv_algo = "direct"   # 'auto' = best available: the exact-f32 mode has the direct kernel only
         self.nf, self.ch_mult, self.num_res_blocks, self.precision, self.conv_algo = nf, ch_mult, num_res_blocks, precision, conv_algo
         self.num_resolutions = len(ch_mult)
         self.output_layer = nn.Conv2d(num_channels, 2, kernel_size=1, bias=False)

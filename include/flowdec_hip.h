@@ -41,6 +41,9 @@ extern "C" {
 /* fd_model_config.act_dtype only: Winograd for the blocks of resolution level >= 2 (small grids, where its 128-cout workgroups
  * fill the chip better), direct MFMA convolution elsewhere. */
 #define FD_WINOGRAD_LOWRES 0x200
+/* fd_model_config.act_dtype only: both packings are kept and every launch picks its kernel by its grid: Winograd when the direct
+ * kernel would run fewer than 3 workgroups per CU (small batches / low-resolution levels), direct otherwise. */
+#define FD_WINOGRAD_AUTO 0x400
 
 /* solver ids (flowdec/model.py:487 'euler'/'midpoint' via torchdyn; sampling/solvers.py:15-57) */
 #define FD_SOLVER_EULER 0
@@ -194,7 +197,7 @@ typedef struct fd_model_config {
   int n_fft;             /* 1534 */
   int hop;               /* 384 */
   float alpha, beta;     /* 0.3, 0.33 */
-  int act_dtype;         /* FD_BF16 (bf16 storage + bf16 MFMA) [| FD_WINOGRAD | FD_WINOGRAD_LOWRES] or FD_F32 (f32 storage + exact f32 MFMA) */
+  int act_dtype;         /* FD_BF16 (bf16 storage + bf16 MFMA) [| FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO] or FD_F32 (f32 storage + exact f32 MFMA) */
 } fd_model_config;
 
 int fd_model_create(const fd_model_config* cfg, fd_model** out);

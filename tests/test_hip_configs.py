@@ -277,7 +277,7 @@ def test_conv2d_winograd_rejects_unsupported():
         ops.pack_conv_weight(torch.randn(128, 32, 3, 3, device="cuda"), dtype=torch.float32, winograd=True)    # f32 storage
 
 
-@pytest.mark.parametrize("algo", ["winograd", "winograd_lowres"])
+@pytest.mark.parametrize("algo", ["winograd", "winograd_lowres", "auto", "direct"])
 def test_model_winograd_parity(algo):
     """The whole network with the Winograd kernel on every supported 3x3 convolution (or on the low-resolution levels only):
     full-width forward against the reference golden G10, full enhance against G17 -- at the bf16 mode's tolerances."""
