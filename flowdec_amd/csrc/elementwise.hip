@@ -628,7 +628,10 @@ static int launch_fir(const void* x, const float* affine, void* out_raw, void* o
     auto dgrid = [&](int by, int bx) { return dim3(fd_cdiv((long long)B * fd_cdiv(H / 2, by) * fd_cdiv(W / 2, bx) * (C / VEC), 256)); };
 #define FD_FIR_DOWN(ACT_, BY_, BX_) hipLaunchKernelGGL((fir_down_kernel<T, VEC, ACT_, BY_, BX_>), dgrid(BY_, BX_), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C)
     // measured on MI355X at 8 x 768 x 256 x 256 (bf16, dual output): 1x1 756 us, 2x2 675, 2x1 614, 8x1 565, 4x2 543, 4x1 467
+    // round 2 (profiles/r02_fir_down_variants.txt): with 4-channel vectors the 4x2 block (6.25 instead of 10 SiLU evaluations per
+    // output) fits the register budget: 430 us vs 512 us for 8-channel vectors x 4x1 at the same shape
     if (!affine) FD_FIR_DOWN(false, 1, 1);
+    else if (VEC == 4 && sizeof(T) == 2) FD_FIR_DOWN(true, 4, 2);
     else FD_FIR_DOWN(true, 4, 1);
 #undef FD_FIR_DOWN
   }
@@ -645,6 +648,7 @@ extern "C" int fd_fir_resample(const void* x, const float* affine, void* out_raw
   FD_REQUIRE(out_act == nullptr || affine != nullptr, "fd_fir_resample: out_act needs affine");
   hipStream_t st = fd_stream(stream);
   if (dtype == FD_BF16) {
+    if (direction < 0 && affine) return launch_fir<bf16, 4>(x, affine, out_raw, out_act, B, H, W, C, direction, st);   // fused down: 4x2 blocks
     if (C % 8 == 0) return launch_fir<bf16, 8>(x, affine, out_raw, out_act, B, H, W, C, direction, st);
     return launch_fir<bf16, 4>(x, affine, out_raw, out_act, B, H, W, C, direction, st);
   } else if (dtype == FD_F32) {
