@@ -281,12 +281,10 @@ struct Fwd {
                           b ? b->stride : 0, b ? b->C : 0, gamma, beta, (float*)ptr(*aff_off), B, gn_groups(C), (long long)a.H * a.W, 1e-6f, st);
   }
   // out = scale * (conv_k(act([a|b])) + conv_1x1([s0|s1]) + bias + skip); optionally emits the GroupNorm partials of out
-  // FD_WINOGRAD_AUTO: the Winograd kernel's 128-cout workgroups are half the size of the direct kernel's, so a launch whose direct
-  // grid is only a few workgroups per CU fills the chip better with them (measured: 1.12-1.14x at 384 tiles, 0.93-0.97x at 1536+)
-  bool auto_wino(const Tens& out) const {
-    const long long tiles = (long long)B * fd_cdiv(out.H, 16) * fd_cdiv(out.W, 16) * fd_cdiv(out.C, 256);
-    return tiles < 3 * 256;
-  }
+  // FD_WINOGRAD_AUTO: the Winograd kernel's 128-cout workgroups are half the size of the direct kernel's, so a small grid fills the
+  // chip better with them (measured: 1.12-1.14x at 48 tiles per image x 8 clips, 0.93-0.97x at 192+ per image).  The choice looks at
+  // the IMAGE only, never at the batch: a clip must give the same bits alone, in a batch, or in a shard of a batch (section 8(e)).
+  bool auto_wino(const Tens& out) const { return fd_cdiv(out.H, 16) * fd_cdiv(out.W, 16) <= 96; }
   int conv(const Tens& a, const Tens* b, size_t aff, const Tens* s0, const Tens* s1, const void* w, const float* bias, int bias_rows,
            const Tens* skip, float scale, Tens& out, int ks, bool want_stats, bool wino = false, const void* w_wino = nullptr) {
     if (w_wino && auto_wino(out)) { w = w_wino; wino = true; }

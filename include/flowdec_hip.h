@@ -41,8 +41,9 @@ extern "C" {
 /* fd_model_config.act_dtype only: Winograd for the blocks of resolution level >= 2 (small grids, where its 128-cout workgroups
  * fill the chip better), direct MFMA convolution elsewhere. */
 #define FD_WINOGRAD_LOWRES 0x200
-/* fd_model_config.act_dtype only: both packings are kept and every launch picks its kernel by its grid: Winograd when the direct
- * kernel would run fewer than 3 workgroups per CU (small batches / low-resolution levels), direct otherwise. */
+/* fd_model_config.act_dtype only: both packings are kept and every launch picks its kernel by the image size: Winograd for images
+ * of at most 96 tiles of 16 x 16 pixels (the low-resolution levels), direct otherwise.  Independent of the batch size, so that a
+ * clip gives the same bits alone and inside any batch. */
 #define FD_WINOGRAD_AUTO 0x400
 
 /* solver ids (flowdec/model.py:487 'euler'/'midpoint' via torchdyn; sampling/solvers.py:15-57) */

@@ -30,18 +30,25 @@ def main(fetch_dir, write_dir, steps, pixels=0):
     fe, wr = load(fetch_dir), load(write_dir)
     out = {"units": "bytes", "steps_in_run": steps, "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 half-count of wide coalesced reads)", "kernels": {}}
     conv = dict(launches=0, fetch_raw=0.0, write=0.0)
+    fir = dict(launches=0, fetch_raw=0.0, write=0.0)
     for k in sorted(set(fe) | set(wr), key=lambda k: -(fe.get(k, [0, 0])[1] + wr.get(k, [0, 0])[1])):
         n = max(fe.get(k, [0, 0])[0], wr.get(k, [0, 0])[0])
         if not k or n == 0:
             continue
         f, w = fe.get(k, [0, 0.0])[1], wr.get(k, [0, 0.0])[1]
         out["kernels"][k] = dict(launches=n, fetch_raw_per_launch=f / n, fetch_corrected_per_launch=2 * f / n, write_per_launch=w / n)
-        if k.startswith("conv_mfma_kernel"):
+        if k.startswith("conv_mfma_kernel") or k.startswith("conv_wino_kernel"):
             conv["launches"] += n; conv["fetch_raw"] += f; conv["write"] += w
+        if (k.startswith("fir_up_kernel") or k.startswith("fir_down_kernel")):
+            fir["launches"] += n; fir["fetch_raw"] += f; fir["write"] += w
     n = conv["launches"]
     out["conv_mfma_kernel"] = dict(launches=n, launches_per_step=n // steps, fetch_corrected_per_launch=2 * conv["fetch_raw"] / n,
                                    write_per_launch=conv["write"] / n, traffic_per_launch=(2 * conv["fetch_raw"] + conv["write"]) / n,
                                    traffic_per_step=(2 * conv["fetch_raw"] + conv["write"]) / steps)
+    n = max(fir["launches"], 1)
+    out["fir_kernels"] = dict(launches=fir["launches"], launches_per_step=fir["launches"] // steps, fetch_corrected_per_launch=2 * fir["fetch_raw"] / n,
+                              write_per_launch=fir["write"] / n, traffic_per_launch=(2 * fir["fetch_raw"] + fir["write"]) / n,
+                              traffic_per_step=(2 * fir["fetch_raw"] + fir["write"]) / steps)
     if pixels:  # kernels with exactly known traffic: pack_input reads two complex64 planes and writes 8 bf16 channels per pixel
         for k, v in out["kernels"].items():
             if k.startswith("pack_input_kernel"):
