@@ -70,7 +70,7 @@ def free_port():
 
 def relaunch(args):
     """`python bench.py --gpus N` without a launcher: become `torch.distributed.run` with N local ranks (one per GPU)."""
-    if args.backend == "nccl":
+    if args.backend == "nccl" and not args.share_gpu:
         import torch
         have = torch.cuda.device_count()
         if have < args.gpus:
@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --stub-step: launcher / collective test on CPU")
     ap.add_argument("--stub-step", action="store_true", help="replace enhance() by a trivial CPU function (tests of the launcher only)")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (with --backend gloo: exercises the N > 1 path on a 1-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "0"))
@@ -117,7 +118,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(0 if args.share_gpu else local_rank)
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
         assert dist.get_world_size() == world
 
@@ -135,7 +136,7 @@ def main():
     else:
         import flowdec_amd
         from flowdec_amd import _lib as L
-        dev = torch.device("cuda", local_rank)
+        dev = torch.device("cuda", 0 if args.share_gpu else local_rank)
         torch.cuda.set_device(dev)
         # synthetic data + seeded random-init weights of the FlowDec-75m architecture (no checkpoints offline)
         model = flowdec_amd.from_preset(args.preset, precision=args.precision, conv_algo=args.conv_algo)

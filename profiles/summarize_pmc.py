@@ -20,7 +20,10 @@ def load(d):
             name = r["Kernel_Name"]
             for pre in ("_ZN12_GLOBAL__N_1", "(anonymous namespace)::"):
                 name = name.replace(pre, "")
-            key = name.split("(")[0].lstrip("0123456789")[:60]
+            key = name.split("(")[0].lstrip("0123456789")
+            if key.startswith("void "):
+                key = key[5:]
+            key = key[:60]
             agg[key][0] += 1
             agg[key][1] += float(r["Counter_Value"]) * 1024.0
     return agg
