@@ -49,3 +49,8 @@ int fd_wino_pack_weights(const float* w, const float* w_sc, void* packed, int Co
 int fd_wino_launch(fdconv::ConvArgs a, hipStream_t st);
 int fd_wino_init_attributes();
 bool fd_wino_supported(int Cout, int C0, int C1, int S0, int S1, int ksize);
+
+// conv_head.hip (Cout = 4 pyramid heads, bf16)
+bool fd_head_supported(const fdconv::ConvArgs& a, int ksize, int dtype);
+int fd_head_launch(fdconv::ConvArgs a, hipStream_t st);
+int fd_head_init_attributes();

@@ -707,6 +707,7 @@ int fd_conv_init_attributes() {
   FD_TRY((set_attr<bf16, 4, 1, 2, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2>()));
   FD_TRY((set_attr<float, 4, 1, 2, 1>())); FD_TRY((set_attr<float, 4, 2, 2, 2>())); FD_TRY((set_attr<float, 2, 4, 4, 2>()));
   FD_TRY(fd_wino_init_attributes());
+  FD_TRY(fd_head_init_attributes());
   if (known) done_dev[dev] = true;
   return FD_OK;
 }
@@ -792,6 +793,9 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   FD_REQUIRE(a.w_bytes < (1ll << 31), "fd_conv2d: packed weights exceed 2 GiB");
   FD_REQUIRE(affine == nullptr || (C0 + C1) * 8 <= AFF_BYTES, "fd_conv2d: at most %d activated input channels", AFF_BYTES / 8);
   if (wino) return fd_wino_launch(a, fd_stream(stream));
+#ifndef FD_NO_HEAD_KERNEL
+  if (fd_head_supported(a, ksize, dtype)) return fd_head_launch(a, fd_stream(stream));
+#endif
   if (dtype == FD_BF16) return dispatch_conv<bf16>(a, fd_stream(stream));
   return dispatch_conv<float>(a, fd_stream(stream));
 }

@@ -64,6 +64,9 @@ CONV_CASES = [
     ("3x3_concat_pad", 2, 16, 16, 32, 16, 128, 3, True, 1, False, 0, 0),     # second segment padded to a chunk
     ("3x3_partial_tiles", 1, 24, 8, 32, 0, 128, 3, True, 1, True, 0, 0),     # W = 8 < tile, H not multiple of 16
     ("3x3_head_cout4", 2, 16, 16, 128, 0, 4, 3, True, 1, True, 0, 0),
+    ("3x3_head_odd_chunks", 1, 24, 20, 96, 0, 4, 3, True, 1, True, 0, 0),     # 3 chunks: generic BN = 32 configuration
+    ("3x3_head_concat_plain", 2, 20, 36, 64, 64, 4, 3, False, 1, False, 0, 0),  # dedicated head kernel, two segments, ragged tiles
+    ("3x3_head_256", 1, 32, 16, 256, 0, 4, 3, True, 2, True, 0, 0),
     ("3x3_small_c8", 1, 16, 16, 8, 0, 8, 3, True, 1, False, 0, 0),
     ("3x3_cout16", 1, 32, 16, 16, 8, 16, 3, True, 1, True, 0, 0),
     ("1x1_basic", 2, 16, 16, 64, 0, 128, 1, False, 1, False, 0, 0),
