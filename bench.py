@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--N", type=int, default=6)
     ap.add_argument("--solver", default="euler")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--conv-algo", default="auto", choices=["direct", "winograd", "winograd_lowres", "auto"])
+    ap.add_argument("--conv-algo", default="auto", choices=["direct", "winograd", "winograd_lowres", "auto", "latency"])
     ap.add_argument("--preset", default="flowdec_75m")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")

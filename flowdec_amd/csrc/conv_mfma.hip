@@ -86,7 +86,10 @@ __device__ __forceinline__ u32x4 transform_slot(u32x4 raw, const char* ad) {
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 
-template <int WM, int WN, int MT, int NT>
+// CW ("chunk-resident weights", the low-latency configuration): the ring holds the slabs of TWO whole chunks (18 slots), the K loop
+// has ONE barrier per chunk and every slab is requested a full chunk before its first use -- on a small grid the tap-pair ring below
+// makes every barrier group wait for one memory round trip (measured: 31 us for a 256 -> 256 convolution whatever the tile width).
+template <int WM, int WN, int MT, int NT, bool CW = false>
 struct Geo {
   static constexpr int NTH = 64 * WM * WN;
   static constexpr int NP = WM * MT;       // 4x8-pixel patches per tile, arranged (NP/2) x 2
@@ -100,7 +103,7 @@ struct Geo {
   // (0,1)(2,3)(4,5)(6,7)(8) with ONE barrier per group (5 instead of 9 per chunk): the per-barrier cost (drain + skew) is
   // amortised over twice as many MFMAs per wave.  After each barrier the slots freed by the finished group are refilled by
   // DMA with the next slabs in K order.
-  static constexpr int NWBUF = 4;
+  static constexpr int NWBUF = CW ? 18 : 4;
   static constexpr int MAIN_BYTES = 2 * HALO_BYTES + NWBUF * W_LDS + AFF_BYTES;
   // epilogue staging: one M-tile row of the block (WM * 32 pixels) x BN floats (+16 B pad per pixel)
   static constexpr int EP_PIX = WM * 32;
@@ -119,9 +122,17 @@ struct Geo {
   static_assert(HITER <= 6, "the halo is converted in three groups of at most two slots");
 };
 
-template <typename T, int WM, int WN, int MT, int NT, bool SKIP>
+// LDS-DMA of one 1-KiB piece from inline asm (CW configuration): invisible to hipcc's waitcnt pass, which otherwise puts a
+// vmcnt(0) in front of the first ds_read after every DMA; the barriers wait for it explicitly (block_sync).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <typename T, int WM, int WN, int MT, int NT, bool SKIP, bool CW = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) {
-  using G = Geo<WM, WN, MT, NT>;
+  using G = Geo<WM, WN, MT, NT, CW>;
   constexpr int EPS = Math<T>::EPS;
   constexpr int CK = 4 * EPS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -200,6 +211,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // Weight slab of one step: BN rows x 80 B, contiguous in global memory with exactly the LDS image -> copied by
   // direct-to-LDS DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB per wave instruction, destination =
   // wave-uniform base + lane * 16).  No VGPR staging, no ds_write.
+  // CW: n consecutive slabs starting at `first` (slab i -> ring slot i % NWBUF), the 1-KiB pieces dealt round-robin to the waves
+  auto dma_chunk = [&](int first, int n, int last) {
+    constexpr int NPIECE = G::W_LDS / 1024, NW = G::NTH / 64;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const char* src0 = reinterpret_cast<const char*>(p.w) + (size_t)n0 * WROWB + (t & 63) * 16;
+    for (int j = wv; j < n * NPIECE; j += NW) {
+      const int sl = first + j / NPIECE, pce = j % NPIECE;
+      if (sl > last) break;
+      glds16(src0 + (size_t)sl * p.CoutPad * WROWB + pce * 1024, (unsigned)(2 * G::HALO_BYTES + (sl % G::NWBUF) * G::W_LDS + pce * 1024));
+    }
+  };
   auto dma_w = [&](int step, int buf) {
     // straight-line code (no exec masking, no branches): the slab is copied in NPIECE 1-KiB pieces, every wave issues
     // PER_WAVE of them; surplus slots re-copy another piece (identical bytes), and a partial last piece over-reads into
@@ -330,6 +352,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #ifdef FD_EXP_NODMA
     if (fetch >= G::NWBUF) { fetch += n; return; }
 #endif
+    if constexpr (CW) { dma_chunk(fetch, n, last_step); fetch += n; return; }
     for (int k = 0; k < n; ++k) { dma_w(fetch <= last_step ? fetch : last_step, fetch % G::NWBUF); ++fetch; }
   };
   // Prologue: all global traffic of the first step is issued at once (first halo, weight ring, affine table) so that the
@@ -362,6 +385,72 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // site pair: with both tap counts inside one loop the compiler keeps two copies of the 128-register accumulator.
   // The phases are straight-line code: work past the end of the K loop (the DMA / halo prefetch / fragment reads of the
   // last steps) is not branched around but redirected to harmless targets (re-load of the last slab / the current chunk).
+  if constexpr (CW) {
+    // Low-latency K loop.  With few MFMAs per phase the two-set pipeline above is a pure latency chain (the MFMAs of phase p + 1
+    // wait for reads issued one MFMA pair earlier: ~350 cycles per phase whatever the tile width, measured); here the fragments
+    // run TWO phases ahead through three register sets (18 phases per chunk: the rotation is the same in every chunk), all slabs
+    // of a chunk are resident, and the one barrier per chunk sits at the end of tap 7: by then every fragment of the chunk is in
+    // registers (taps 8's were read during tap 7), so the barrier publishes the next halo / the next chunk's slabs AND frees this
+    // chunk's buffers for the prefetch of chunk i + 2.
+    u32x4 wfS[3][NT], pfS[3][MT];
+#pragma unroll
+    for (int nj = 0; nj < NT; ++nj) wfS[0][nj] = wfA[nj];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) pfS[0][mi] = pfA[mi];
+    if (n9 > 0) read_frags(wfS[1], pfS[1], hbuf, wbuf, 0, 1);
+    for (int i = 0; i < n9; ++i) {
+      const bool last_chunk = (i == n9 - 1) && n1 == 0;
+      if (!last_chunk) { advance(cs, cch); next_chunk(cs, cch); }
+      else npix_on = 0;
+      const char* hb = hbuf + hcur * G::HALO_BYTES;
+      const char* hbn = hbuf + (hcur ^ 1) * G::HALO_BYTES;
+      const char* wcur = wbuf + (i & 1) * 9 * G::W_LDS;
+      const char* wnext = wbuf + ((i + 1) & 1) * 9 * G::W_LDS;
+      const int first_off_next = (i == n9 - 1) ? CENTER : 0;
+#pragma unroll
+      for (int ph = 0; ph < 18; ++ph) {
+        const int tap = ph >> 1;
+#ifdef FD_EXP_CW_NOHALO   // experiments (timing only, wrong results): no halo traffic at all / no activation
+        if (false)
+#endif
+        if (ph == 2) {
+#pragma unroll
+          for (int k = 0; k < G::HITER; ++k) load_halo_slot(k);
+        }
+#ifdef FD_EXP_CW_NOACT
+        naff = -1;
+#endif
+#ifdef FD_EXP_CW_NOHALO
+        if (false)
+#endif
+        if ((ph & 1) == 0 && tap >= 4 && tap <= 6) {
+#pragma unroll
+          for (int k = 0; k < G::HPG; ++k)
+            if ((tap - 4) * G::HPG + k < G::HITER) store_halo_slot((tap - 4) * G::HPG + k, hcur ^ 1);
+        }
+        const int f = ph + 2;   // fragment read in this phase: (tap f / 2, k-half f % 2) of this chunk, or tap 0 of the next one
+        if (f < 18) read_frags(wfS[f % 3], pfS[f % 3], hb, wcur + (f >> 1) * G::W_LDS, (((f >> 1) / 3) * PITCH + ((f >> 1) % 3)) * ROWB, f & 1);
+        else read_frags(wfS[f % 3], pfS[f % 3], hbn, wnext, first_off_next, f & 1);
+        // (no scheduling hints here: the phase boundary below keeps hipcc from sinking the reads towards their first use,
+        // which would turn the two-phase distance back into a wait per MFMA)
+#pragma unroll
+        for (int nj = 0; nj < NT; ++nj)
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi) Math<T>::mma(acc[mi][nj], wfS[ph % 3][nj], pfS[ph % 3][mi]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ph == 15) {
+          block_sync();
+          fetch_slabs(9);
+        }
+      }
+      step += 9;
+      hcur ^= 1;
+    }
+#pragma unroll
+    for (int nj = 0; nj < NT; ++nj) wfA[nj] = wfS[0][nj];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) pfA[mi] = pfS[0][mi];
+  } else
   for (int i = 0; i < n9; ++i) {
     const bool last_chunk = (i == n9 - 1) && n1 == 0;
     if (!last_chunk) { advance(cs, cch); next_chunk(cs, cch); }   // else: the prefetch of this chunk is unused
@@ -431,7 +520,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #pragma unroll
     for (int k = 0; k < G::HITER; ++k) store_halo_slot(k, hcur ^ 1);
     block_sync();
-    fetch_slabs(1);
+    if constexpr (!CW) fetch_slabs(1);   // (CW: all shortcut slabs are already in the ring -- the launcher guarantees n1 <= NWBUF)
     read_frags(wfA, pfA, hbn, wbn, CENTER, 0);
     mma_all(wfB, pfB);
     ++step; hcur ^= 1;
@@ -662,34 +751,46 @@ inline int n_steps(int C0, int C1, int taps, int CK) { return (fd_cdiv(C0, CK) +
 unsigned long long* g_dbg = nullptr;  // instrumented builds only: device buffer of 8 counters per workgroup (fd_debug_buffer)
 #endif
 
-template <typename T, int WM, int WN, int MT, int NT>
+template <typename T, int WM, int WN, int MT, int NT, bool CW = false>
 int set_attr() {
-  using G = Geo<WM, WN, MT, NT>;
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, WM, WN, MT, NT, false>),
+  using G = Geo<WM, WN, MT, NT, CW>;
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, WM, WN, MT, NT, false, CW>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, WM, WN, MT, NT, true>),
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, WM, WN, MT, NT, true, CW>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
   return FD_OK;
 }
 
-template <typename T, int WM, int WN, int MT, int NT>
+template <typename T, int WM, int WN, int MT, int NT, bool CW = false>
 int launch_conv(ConvArgs a, hipStream_t st) {
-  using G = Geo<WM, WN, MT, NT>;
+  using G = Geo<WM, WN, MT, NT, CW>;
   a.tiles_h = fd_cdiv(a.H, G::TH);
   a.tiles_w = fd_cdiv(a.W, G::TW);
   a.tiles_n = fd_cdiv(a.Cout, G::BN);
   const long long nblk = (long long)a.B * a.tiles_h * a.tiles_w * a.tiles_n;
   FD_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
-  if (a.skip) hipLaunchKernelGGL((conv_mfma_kernel<T, WM, WN, MT, NT, true>), dim3((unsigned)nblk), dim3(G::NTH), G::LDS_BYTES, st, a);
-  else hipLaunchKernelGGL((conv_mfma_kernel<T, WM, WN, MT, NT, false>), dim3((unsigned)nblk), dim3(G::NTH), G::LDS_BYTES, st, a);
+  if (a.skip) hipLaunchKernelGGL((conv_mfma_kernel<T, WM, WN, MT, NT, true, CW>), dim3((unsigned)nblk), dim3(G::NTH), G::LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((conv_mfma_kernel<T, WM, WN, MT, NT, false, CW>), dim3((unsigned)nblk), dim3(G::NTH), G::LDS_BYTES, st, a);
   FD_LAUNCH_CHECK();
   return FD_OK;
 }
 
+// bn_hint: output channels per workgroup (32 / 64 / 128 / 256) or 0 = by Cout.  All configurations run the same K order per
+// output, so the convolution result does not depend on the choice (the per-tile statistics differ in summation order only).
 template <typename T>
-int dispatch_conv(const ConvArgs& a, hipStream_t st) {
-  if (a.Cout <= 32) return launch_conv<T, 4, 1, 2, 1>(a, st);                             // 4 waves, BN = 32 (pyramid heads)
-  if (a.Cout <= 128) return launch_conv<T, 4, 2, 2, 2>(a, st);                             // 8 waves, BN = 128
+int dispatch_conv(const ConvArgs& a, hipStream_t st, int bn_hint, bool chunk_ring) {
+  int bn = a.Cout <= 32 ? 32 : (a.Cout <= 128 ? 128 : 256);
+  if (bn_hint > 0 && bn_hint < bn) bn = bn_hint;
+  if constexpr (sizeof(T) == 2) {
+    if (chunk_ring && bn <= 64) {   // low-latency configurations: bf16, at most 18 folded-shortcut (or 1x1) steps
+      int n1 = 0;
+      for (int s = 0; s < a.nseg; ++s) if (a.seg[s].taps == 1) n1 += fd_cdiv(a.seg[s].C, 32);
+      if (n1 <= 18) return bn == 64 ? launch_conv<T, 4, 2, 2, 1, true>(a, st) : launch_conv<T, 4, 1, 2, 1, true>(a, st);
+    }
+  }
+  if (bn == 32) return launch_conv<T, 4, 1, 2, 1>(a, st);                                 // 4 waves, BN = 32 (pyramid heads, tiny grids)
+  if (bn == 64) return launch_conv<T, 4, 2, 2, 1>(a, st);                                 // 8 waves, BN = 64
+  if (bn == 128) return launch_conv<T, 4, 2, 2, 2>(a, st);                                // 8 waves, BN = 128
   return launch_conv<T, 2, 4, 4, 2>(a, st);                                               // 8 waves, BN = 256
 }
 
@@ -704,8 +805,8 @@ int fd_conv_init_attributes() {
   std::lock_guard<std::mutex> lock(mu);
   const bool known = dev >= 0 && dev < 64;
   if (known && done_dev[dev]) return FD_OK;
-  FD_TRY((set_attr<bf16, 4, 1, 2, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2>()));
-  FD_TRY((set_attr<float, 4, 1, 2, 1>())); FD_TRY((set_attr<float, 4, 2, 2, 2>())); FD_TRY((set_attr<float, 2, 4, 4, 2>()));
+  FD_TRY((set_attr<bf16, 4, 1, 2, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 1, true>())); FD_TRY((set_attr<bf16, 4, 1, 2, 1, true>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2>()));
+  FD_TRY((set_attr<float, 4, 1, 2, 1>())); FD_TRY((set_attr<float, 4, 2, 2, 1>())); FD_TRY((set_attr<float, 4, 2, 2, 2>())); FD_TRY((set_attr<float, 2, 4, 4, 2>()));
   FD_TRY(fd_wino_init_attributes());
   FD_TRY(fd_head_init_attributes());
   if (known) done_dev[dev] = true;
@@ -759,6 +860,9 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   FD_REQUIRE(in0 && packed_w && out, "fd_conv2d: null pointer");
   FD_REQUIRE(ksize == 1 || ksize == 3, "fd_conv2d: ksize must be 1 or 3 (got %d)", ksize);
   const bool wino = (dtype & FD_WINOGRAD) != 0;
+  const int tile = dtype & FD_TILE_MASK;
+  const int bn_hint = (tile == FD_TILE_BN32 || tile == FD_TILE_BN32_CHUNK) ? 32 : (tile == FD_TILE_BN64 || tile == FD_TILE_BN64_CHUNK) ? 64 : tile == FD_TILE_BN128 ? 128 : 0;
+  FD_REQUIRE(tile == 0 || bn_hint > 0, "fd_conv2d: bad FD_TILE_* flag");
   dtype &= 0xff;
   FD_REQUIRE(!wino || (dtype == FD_BF16 && fd_wino_supported(Cout, C0, C1, S0, S1, ksize)),
              "fd_conv2d: FD_WINOGRAD needs bf16 storage, ksize 3, Cout %% 128 == 0 and channel counts %% 32 == 0");
@@ -794,8 +898,8 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   FD_REQUIRE(affine == nullptr || (C0 + C1) * 8 <= AFF_BYTES, "fd_conv2d: at most %d activated input channels", AFF_BYTES / 8);
   if (wino) return fd_wino_launch(a, fd_stream(stream));
 #ifndef FD_NO_HEAD_KERNEL
-  if (fd_head_supported(a, ksize, dtype)) return fd_head_launch(a, fd_stream(stream));
+  if (bn_hint == 0 && fd_head_supported(a, ksize, dtype)) return fd_head_launch(a, fd_stream(stream));
 #endif
-  if (dtype == FD_BF16) return dispatch_conv<bf16>(a, fd_stream(stream));
-  return dispatch_conv<float>(a, fd_stream(stream));
+  if (dtype == FD_BF16) return dispatch_conv<bf16>(a, fd_stream(stream), bn_hint, tile == FD_TILE_BN64_CHUNK || tile == FD_TILE_BN32_CHUNK);
+  return dispatch_conv<float>(a, fd_stream(stream), bn_hint, false);
 }

@@ -285,9 +285,16 @@ struct Fwd {
   // chip better with them (measured: 1.12-1.14x at 48 tiles per image x 8 clips, 0.93-0.97x at 192+ per image).  The choice looks at
   // the IMAGE only, never at the batch: a clip must give the same bits alone, in a batch, or in a shard of a batch (section 8(e)).
   bool auto_wino(const Tens& out) const { return fd_cdiv(out.H, 16) * fd_cdiv(out.W, 16) <= 96; }
+  // FD_LOW_LATENCY (one short clip on the whole chip; profiles/r02_latency_tiles.txt): images of at most 24 tiles run the direct
+  // kernel with 32-channel workgroups and chunk-resident weights (8 x the workgroups, one barrier per chunk); the Winograd kernel
+  // (128-channel workgroups) takes everything else up to 512 tiles unless a 1x1 shortcut is folded in.  By image size only.
   int conv(const Tens& a, const Tens* b, size_t aff, const Tens* s0, const Tens* s1, const void* w, const float* bias, int bias_rows,
            const Tens* skip, float scale, Tens& out, int ks, bool want_stats, bool wino = false, const void* w_wino = nullptr) {
-    if (w_wino && auto_wino(out)) { w = w_wino; wino = true; }
+    int tile = 0;
+    const int px_tiles = fd_cdiv(out.H, 16) * fd_cdiv(out.W, 16);
+    const bool latency = m && (m->cfg.act_dtype & FD_LOW_LATENCY) && dt == FD_BF16;
+    if (latency && px_tiles <= 24 && out.C >= 64) tile = FD_TILE_BN32_CHUNK;
+    else if (w_wino && (auto_wino(out) || (latency && px_tiles <= 512 && !s0))) { w = w_wino; wino = true; }
     if (want_stats) {
       out.tiles = fd_conv_stats_tiles(out.H, out.W);
       out.stride = fd_conv_cout_pad(out.C);
@@ -305,7 +312,7 @@ struct Fwd {
     const int rc = fd_conv2d(ptr(a.off), a.C, b ? ptr(b->off) : nullptr, b ? b->C : 0, aff == (size_t)-1 ? nullptr : (const float*)ptr(aff),
                              s0 ? ptr(s0->off) : nullptr, s0 ? s0->C : 0, s1 ? ptr(s1->off) : nullptr, s1 ? s1->C : 0, w, bias, bias_rows,
                              skip ? ptr(skip->off) : nullptr, scale, ptr(out.off), out.C, want_stats ? (float*)ptr(out.sums) : nullptr, B,
-                             out.H, out.W, ks, dt | (wino ? FD_WINOGRAD : 0), st);
+                             out.H, out.W, ks, dt | (wino ? FD_WINOGRAD : 0) | tile, st);
     if (m && m->profiling) {
       FD_HIP(hipEventRecord(m->ev[m->ev_used].second, st));
       ++m->ev_used;
@@ -664,7 +671,7 @@ extern "C" int fd_model_create(const fd_model_config* cfg, fd_model** out) {
   FD_REQUIRE(cfg->nf >= 8 && cfg->nf % 8 == 0 && cfg->nf <= 64, "fd_model_create: nf must be a multiple of 8 in [8, 64] (got %d)", cfg->nf);
   FD_REQUIRE(cfg->num_levels >= 1 && cfg->num_levels <= 8 && cfg->num_res_blocks >= 1, "fd_model_create: bad level / block counts");
   FD_REQUIRE((cfg->act_dtype & 0xff) == FD_BF16 || cfg->act_dtype == FD_F32,
-             "fd_model_create: act_dtype must be FD_BF16 [| FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO] or FD_F32");
+             "fd_model_create: act_dtype must be FD_BF16 [| FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY] or FD_F32");
   FD_REQUIRE(cfg->n_fft > 0 && cfg->n_fft % 2 == 0 && cfg->hop > 0, "fd_model_create: bad STFT geometry");
   for (int i = 0; i < cfg->num_levels; ++i) {
     const int ch = cfg->nf * cfg->ch_mult[i];
@@ -791,7 +798,7 @@ extern "C" int fd_model_finalize(fd_model* m, void* stream) {
         const bool want_wino = (m->cfg.act_dtype & FD_WINOGRAD) || ((m->cfg.act_dtype & FD_WINOGRAD_LOWRES) && md.level >= 2);
         md.wino0 = want_wino && fd_conv_packed_bytes(md.cout, md.c0, md.c1, 3, 0, 0, m->dt | FD_WINOGRAD) > 0;
         md.wino1 = want_wino && fd_conv_packed_bytes(md.cout, md.cout, 0, 3, md.has_c2 ? md.c0 : 0, md.has_c2 ? md.c1 : 0, m->dt | FD_WINOGRAD) > 0;
-        const bool both = (m->cfg.act_dtype & FD_WINOGRAD_AUTO) != 0;   // both packings; the kernel is chosen per launch by its grid
+        const bool both = (m->cfg.act_dtype & (FD_WINOGRAD_AUTO | FD_LOW_LATENCY)) != 0;   // both packings; the kernel is chosen per launch by its grid
         if (both && fd_conv_packed_bytes(md.cout, md.c0, md.c1, 3, 0, 0, m->dt | FD_WINOGRAD) > 0)
           FD_TRY(pack_conv(m, p + "Conv_0.weight", md.cout, md.c0, md.c1, 3, "", 0, 0, &md.w0w, st, FD_WINOGRAD));
         if (both && fd_conv_packed_bytes(md.cout, md.cout, 0, 3, md.has_c2 ? md.c0 : 0, md.has_c2 ? md.c1 : 0, m->dt | FD_WINOGRAD) > 0)

@@ -62,7 +62,8 @@ class Combine(nn.Module):
 DEFAULT_OUTPUTLAYER_KWARGS = dict(kernel_size=3, bias=False, padding="same", padding_mode="zeros")
 # 3x3 convolution algorithm of the bf16 mode: direct MFMA implicit GEMM, Winograd F(2,3) wherever the shape allows it, or
 # Winograd only at the low-resolution levels, or chosen per launch by grid fill ('auto'; include/flowdec_hip.h: FD_WINOGRAD*)
-CONV_ALGOS = {"direct": 0, "winograd": L.FD_WINOGRAD, "winograd_lowres": L.FD_WINOGRAD_LOWRES, "auto": L.FD_WINOGRAD_AUTO}
+CONV_ALGOS = {"direct": 0, "winograd": L.FD_WINOGRAD, "winograd_lowres": L.FD_WINOGRAD_LOWRES, "auto": L.FD_WINOGRAD_AUTO,
+              "latency": L.FD_LOW_LATENCY}   # one short clip on the whole chip (FD_LOW_LATENCY)
 
 
 class NCSNpp(nn.Module):

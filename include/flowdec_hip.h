@@ -45,6 +45,21 @@ extern "C" {
  * of at most 96 tiles of 16 x 16 pixels (the low-resolution levels), direct otherwise.  Independent of the batch size, so that a
  * clip gives the same bits alone and inside any batch. */
 #define FD_WINOGRAD_AUTO 0x400
+/* fd_conv2d only (direct kernel): output channels per workgroup, 32 / 64 / 128 instead of the default min(256, padded Cout).  Narrow
+ * workgroups put a SMALL image on more compute units (latency) at the price of re-activating the input once per workgroup
+ * (throughput).  The convolution result is bit-identical for every width (same K order per output); the per-tile statistics
+ * differ in summation order only. */
+#define FD_TILE_BN32 0x1000
+#define FD_TILE_BN64 0x2000
+#define FD_TILE_BN128 0x3000
+#define FD_TILE_BN64_CHUNK 0x4000 /* 64 + the weight slabs of two whole 32-channel chunks resident in LDS: one barrier and one memory
+                                     round trip per chunk instead of per tap pair (bf16; falls back to FD_TILE_BN64 otherwise) */
+#define FD_TILE_BN32_CHUNK 0x5000 /* same with 32-channel workgroups (4 waves) */
+#define FD_TILE_MASK 0xf000
+/* fd_model_config.act_dtype only: low-latency schedule for ONE short clip -- both packings are kept (as with FD_WINOGRAD_AUTO) and
+ * every convolution picks kernel and workgroup width by its IMAGE size (never by the batch size): FD_TILE_BN32_CHUNK for images of
+ * at most 24 tiles, Winograd up to 512 tiles (unless a 1x1 shortcut is folded in), direct otherwise. */
+#define FD_LOW_LATENCY 0x800
 
 /* solver ids (flowdec/model.py:487 'euler'/'midpoint' via torchdyn; sampling/solvers.py:15-57) */
 #define FD_SOLVER_EULER 0
@@ -198,7 +213,7 @@ typedef struct fd_model_config {
   int n_fft;             /* 1534 */
   int hop;               /* 384 */
   float alpha, beta;     /* 0.3, 0.33 */
-  int act_dtype;         /* FD_BF16 (bf16 storage + bf16 MFMA) [| FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO] or FD_F32 (f32 storage + exact f32 MFMA) */
+  int act_dtype;         /* FD_BF16 (bf16 storage + bf16 MFMA) [| FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY] or FD_F32 (f32 storage + exact f32 MFMA) */
 } fd_model_config;
 
 int fd_model_create(const fd_model_config* cfg, fd_model** out);

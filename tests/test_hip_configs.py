@@ -277,7 +277,7 @@ def test_conv2d_winograd_rejects_unsupported():
         ops.pack_conv_weight(torch.randn(128, 32, 3, 3, device="cuda"), dtype=torch.float32, winograd=True)    # f32 storage
 
 
-@pytest.mark.parametrize("algo", ["winograd", "winograd_lowres", "auto", "direct"])
+@pytest.mark.parametrize("algo", ["winograd", "winograd_lowres", "auto", "latency", "direct"])
 def test_model_winograd_parity(algo):
     """The whole network with the Winograd kernel on every supported 3x3 convolution (or on the low-resolution levels only):
     full-width forward against the reference golden G10, full enhance against G17 -- at the bf16 mode's tolerances."""
@@ -291,3 +291,45 @@ def test_model_winograd_parity(algo):
     g17 = load_golden("g17_enhance_nf64.npz")
     x = m.enhance(torch.from_numpy(g17["y"]), N=6, solver="euler", noise=torch.from_numpy(g17["noise"]))
     check(f"enhance_nf64[euler,N=6,bf16,{algo}]", x.numpy(), g17["euler_N6"], TOL_WAVE_FULL["bf16"])
+
+
+TILE_CASES = [
+    # name, B, H, W, C0, C1, Cout, k, affine, skip, S0, S1
+    ("plain_256", 1, 32, 16, 64, 0, 256, 3, False, False, 0, 0),
+    ("aff_skip_ragged", 2, 24, 20, 96, 0, 128, 3, True, True, 0, 0),
+    ("concat_shortcut", 1, 16, 48, 128, 64, 256, 3, True, False, 128, 64),      # 6 shortcut steps
+    ("one_chunk", 1, 16, 16, 32, 0, 64, 3, True, False, 32, 0),                  # a single 9-tap chunk + 1 shortcut step
+    ("long_shortcut", 1, 16, 16, 64, 0, 128, 3, True, False, 256, 384),          # 20 shortcut steps: chunk-ring falls back
+    ("conv1x1", 2, 16, 32, 128, 64, 256, 1, False, False, 0, 0),                 # no 9-tap chunk at all
+]
+
+
+@pytest.mark.parametrize("case", TILE_CASES, ids=[c[0] for c in TILE_CASES])
+def test_conv2d_tile_widths(case):
+    """fd_conv2d with the FD_TILE_* workgroup widths (incl. the chunk-resident low-latency configurations): the convolution
+    result is BIT-IDENTICAL to the default configuration (same K order per output), the statistics agree to f32 rounding."""
+    from flowdec_amd import ops
+    import zlib
+    name, B, H, W, C0, C1, Cout, k, use_aff, use_skip, S0, S1 = case
+    g = torch.Generator(device="cuda").manual_seed(zlib.crc32(name.encode()))
+    Cin = C0 + C1
+    x0 = torch.randn(B, H, W, C0, device="cuda", generator=g).bfloat16()
+    x1 = torch.randn(B, H, W, C1, device="cuda", generator=g).bfloat16() if C1 else None
+    w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5
+    aff = torch.stack([1 + 0.2 * torch.randn(B, Cin, device="cuda", generator=g), 0.3 * torch.randn(B, Cin, device="cuda", generator=g)], -1).contiguous() \
+        if use_aff else None
+    bias = torch.randn(B, Cout, device="cuda", generator=g)
+    sk = torch.randn(B, H, W, Cout, device="cuda", generator=g).bfloat16() if use_skip else None
+    sc0 = sc1 = wsc = None
+    if S0:
+        sc0 = torch.randn(B, H, W, S0, device="cuda", generator=g).bfloat16()
+        sc1 = torch.randn(B, H, W, S1, device="cuda", generator=g).bfloat16() if S1 else None
+        wsc = torch.randn(Cout, S0 + S1, 1, 1, device="cuda", generator=g) / (S0 + S1) ** 0.5
+    pw = ops.pack_conv_weight(w, C0=C0, dtype=torch.bfloat16, w_sc=wsc, S0=S0 if S0 else None)
+    run = lambda bn: ops.conv2d(x0, pw, Cout, k, x1=x1, affine=aff, bias=bias, skip=sk, scale=0.7071, sc0=sc0, sc1=sc1, want_stats=True, tile_bn=bn)
+    ref, ref_st = run(0)
+    assert torch.isfinite(ref.float()).all()
+    for bn in (128, 64, 32, "64c", "32c"):
+        out, st = run(bn)
+        assert torch.equal(out, ref), (name, bn)
+        assert torch.allclose(st[:, :, :Cout], ref_st[:, :, :Cout], rtol=1e-4, atol=1e-3), (name, bn)
