@@ -344,6 +344,25 @@ __global__ void fused_bias_act_kernel(const float* __restrict__ x, const float* 
 // =====================================================================================================
 // Time embedding (ncsnpp.py:263-274, layerspp.py:42-51) -- one block per t row.
 // =====================================================================================================
+// acc = init + sum_k w[k] * x[k], k ascending (one fma per term: the order the parity tests pin), n % 4 == 0.  The weight row is read
+// as 16-byte vectors with 16 of them in flight: these matrix-vector products are one dependent chain per thread and sit on the
+// critical path of every network evaluation.
+__device__ __forceinline__ float fd_row_dot(const float* __restrict__ w, const float* x, int n, float init) {
+  float acc = init;
+  for (int k0 = 0; k0 < n; k0 += 64) {
+    f32x4 wv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) wv[j] = (k0 + 4 * j < n) ? *reinterpret_cast<const f32x4*>(w + k0 + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (k0 + 4 * j < n) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = fmaf(wv[j][e], x[k0 + 4 * j + e], acc);
+      }
+  }
+  return acc;
+}
+
 __global__ __launch_bounds__(256) void time_embedding_kernel(const float* __restrict__ t, float t_imm, const float* __restrict__ W,
                                                              int nf, const float* __restrict__ w1, const float* __restrict__ b1,
                                                              const float* __restrict__ w2, const float* __restrict__ b2,
@@ -361,15 +380,11 @@ __global__ __launch_bounds__(256) void time_embedding_kernel(const float* __rest
   __syncthreads();
   const int E = 2 * nf, D = 4 * nf;
   for (int o = threadIdx.x; o < D; o += blockDim.x) {
-    float acc = b1[o];
-    for (int k = 0; k < E; ++k) acc = fmaf(w1[(size_t)o * E + k], emb[k], acc);
-    hid[o] = fd_silu(acc);
+    hid[o] = fd_silu(fd_row_dot(w1 + (size_t)o * E, emb, E, b1[o]));
   }
   __syncthreads();
   for (int o = threadIdx.x; o < D; o += blockDim.x) {
-    float acc = b2[o];
-    for (int k = 0; k < D; ++k) acc = fmaf(w2[(size_t)o * D + k], hid[k], acc);
-    temb[(size_t)r * D + o] = acc;
+    temb[(size_t)r * D + o] = fd_row_dot(w2 + (size_t)o * D, hid, D, b2[o]);
   }
 }
 
@@ -382,9 +397,7 @@ __global__ __launch_bounds__(256) void temb_bias_kernel(const fd_temb_job* __res
   for (int k = threadIdx.x; k < temb_dim; k += blockDim.x) st[k] = fd_silu(temb[(size_t)r * temb_dim + k]);
   __syncthreads();
   for (int o = threadIdx.x; o < job.Cout; o += blockDim.x) {
-    float acc = job.dense_b[o];
-    for (int k = 0; k < temb_dim; ++k) acc = fmaf(job.dense_w[(size_t)o * temb_dim + k], st[k], acc);
-    job.out[(size_t)r * job.Cout + o] = acc + job.conv_b[o];
+    job.out[(size_t)r * job.Cout + o] = fd_row_dot(job.dense_w + (size_t)o * temb_dim, st, temb_dim, job.dense_b[o]) + job.conv_b[o];
   }
 }
 
@@ -394,9 +407,7 @@ __global__ __launch_bounds__(256) void temb_bias_single_kernel(fd_temb_job job, 
   for (int k = threadIdx.x; k < temb_dim; k += blockDim.x) st[k] = fd_silu(temb[(size_t)r * temb_dim + k]);
   __syncthreads();
   for (int o = threadIdx.x; o < job.Cout; o += blockDim.x) {
-    float acc = job.dense_b[o];
-    for (int k = 0; k < temb_dim; ++k) acc = fmaf(job.dense_w[(size_t)o * temb_dim + k], st[k], acc);
-    job.out[(size_t)r * job.Cout + o] = acc + (job.conv_b ? job.conv_b[o] : 0.f);
+    job.out[(size_t)r * job.Cout + o] = fd_row_dot(job.dense_w + (size_t)o * temb_dim, st, temb_dim, job.dense_b[o]) + (job.conv_b ? job.conv_b[o] : 0.f);
   }
 }
 
@@ -435,21 +446,35 @@ __global__ __launch_bounds__(256) void combine_kernel(const T* __restrict__ p4, 
   float s[8], ss[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) s[i] = ss[i] = 0.f;
-  for (int p = p0 + pl; p < p1; p += lanes) {
-    const size_t pix = (size_t)b * HW + p;
-    float v[4], hv[8], o[8];
-    fd_load_vec<T, 4>(p4 + pix * 8, v);   // the 4-channel pyramid is stored with 8-channel stride (see pack_input_kernel)
-    fd_load_vec<T, 8>(h + pix * Cout + cg * 8, hv);
+  // eight pixels per trip with all loads issued first (the statistics are accumulated in the same pixel order as a plain loop)
+  constexpr int UP = 8;
+  for (int pb = p0 + pl; pb < p1; pb += UP * lanes) {
+    float v[UP][4], hv[UP][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float acc = bs[i];
-#pragma unroll
-      for (int ci = 0; ci < 4; ++ci) acc = fmaf(wr[i][ci], v[ci], acc);
-      o[i] = acc + hv[i];
-      const float q = (float)(T)o[i];     // statistics of the stored (rounded) tensor, as channel_sums_kernel would see it
-      s[i] += q; ss[i] = fmaf(q, q, ss[i]);
+    for (int u = 0; u < UP; ++u) {
+      const int p = pb + u * lanes;
+      const size_t pix = (size_t)b * HW + (p < p1 ? p : p0);
+      fd_load_vec<T, 4>(p4 + pix * 8, v[u]);   // the 4-channel pyramid is stored with 8-channel stride (see pack_input_kernel)
+      fd_load_vec<T, 8>(h + pix * Cout + cg * 8, hv[u]);
     }
-    fd_store_vec<T, 8>(out + pix * Cout + cg * 8, o);
+#pragma unroll
+    for (int u = 0; u < UP; ++u) {
+      const int p = pb + u * lanes;
+      if (p < p1) {
+        const size_t pix = (size_t)b * HW + p;
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float acc = bs[i];
+#pragma unroll
+          for (int ci = 0; ci < 4; ++ci) acc = fmaf(wr[i][ci], v[u][ci], acc);
+          o[i] = acc + hv[u][i];
+          const float q = (float)(T)o[i];     // statistics of the stored (rounded) tensor, as channel_sums_kernel would see it
+          s[i] += q; ss[i] = fmaf(q, q, ss[i]);
+        }
+        fd_store_vec<T, 8>(out + pix * Cout + cg * 8, o);
+      }
+    }
   }
   __shared__ float red[256][17];
 #pragma unroll
@@ -619,11 +644,16 @@ extern "C" int fd_gn_finalize(const float* part0, int tiles0, int stride0, int C
 template <typename T, int VEC>
 static int launch_fir(const void* x, const float* affine, void* out_raw, void* out_act, int B, int H, int W, int C,
                       int direction, hipStream_t st) {
-  constexpr int NS = 8;  // rows per thread of the fused (activated) variants
+  // Rows / output block per thread of the fused (activated) variants: big blocks re-use activated inputs (fewer SiLU evaluations per
+  // output), small ones make more, shorter threads -- a small image is latency-bound (one clip at 384 x 64: 13-25 us with the big
+  // blocks).  Every output is the same fma sequence in every variant, so the choice may depend on the batch size.
   auto blocks = [&](int rows, int cols, int n) { return dim3(fd_cdiv((long long)B * fd_cdiv(rows, n) * cols * (C / VEC), 256)); };
+  constexpr unsigned ENOUGH = 512;   // workgroups that keep 256 CUs busy
   if (direction > 0) {
-    if (affine) hipLaunchKernelGGL((fir_up_kernel<T, VEC, true, NS>), blocks(H, W, NS), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C);
-    else hipLaunchKernelGGL((fir_up_kernel<T, VEC, false, 1>), blocks(H, W, 1), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C);
+    if (!affine) hipLaunchKernelGGL((fir_up_kernel<T, VEC, false, 1>), blocks(H, W, 1), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C);
+    else if (blocks(H, W, 8).x >= ENOUGH) hipLaunchKernelGGL((fir_up_kernel<T, VEC, true, 8>), blocks(H, W, 8), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C);
+    else if (blocks(H, W, 2).x >= ENOUGH) hipLaunchKernelGGL((fir_up_kernel<T, VEC, true, 2>), blocks(H, W, 2), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C);
+    else hipLaunchKernelGGL((fir_up_kernel<T, VEC, true, 1>), blocks(H, W, 1), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C);
   } else {
     auto dgrid = [&](int by, int bx) { return dim3(fd_cdiv((long long)B * fd_cdiv(H / 2, by) * fd_cdiv(W / 2, bx) * (C / VEC), 256)); };
 #define FD_FIR_DOWN(ACT_, BY_, BX_) hipLaunchKernelGGL((fir_down_kernel<T, VEC, ACT_, BY_, BX_>), dgrid(BY_, BX_), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C)
@@ -631,8 +661,12 @@ static int launch_fir(const void* x, const float* affine, void* out_raw, void* o
     // round 2 (profiles/r02_fir_down_variants.txt): with 4-channel vectors the 4x2 block (6.25 instead of 10 SiLU evaluations per
     // output) fits the register budget: 430 us vs 512 us for 8-channel vectors x 4x1 at the same shape
     if (!affine) FD_FIR_DOWN(false, 1, 1);
-    else if (VEC == 4 && sizeof(T) == 2) FD_FIR_DOWN(true, 4, 2);
-    else FD_FIR_DOWN(true, 4, 1);
+    else if (VEC == 4 && sizeof(T) == 2) {
+      if (dgrid(4, 2).x >= ENOUGH) FD_FIR_DOWN(true, 4, 2);
+      else if (dgrid(2, 1).x >= ENOUGH) FD_FIR_DOWN(true, 2, 1);
+      else FD_FIR_DOWN(true, 1, 1);
+    } else if (dgrid(4, 1).x >= ENOUGH) FD_FIR_DOWN(true, 4, 1);
+    else FD_FIR_DOWN(true, 1, 1);
 #undef FD_FIR_DOWN
   }
   FD_LAUNCH_CHECK();

@@ -64,65 +64,90 @@ __global__ void frame_kernel(const float* __restrict__ y, const float* __restric
   }
 }
 
-// C[M][N] = A[M][K] * B[K][N], row-major f32, N and K multiples of 128 / 16.  128x128x16 tiles,
-// 4 waves (2x2) x (2x2) v_mfma_f32_32x32x2_f32 tiles: exact f32 products, f32 accumulation.
+// C[M][N] = A[M][K] * B[K][N], row-major f32, N and K multiples of 128 / 16.  128 x BN x 16 tiles of v_mfma_f32_32x32x2_f32 (exact f32
+// products, f32 accumulation, k ascending: the result does not depend on BN).  BN = 128: 4 waves as 2 x 2, each 2 x 2 MFMA tiles;
+// BN = 32: 4 waves as 4 x 1, one tile each -- 4 x the workgroups for the small grids (one clip: 12 workgroups of 128 x 128 took
+// 154 us, MFMA-bound per workgroup at 32 f32 MFMAs per k-block).
+template <int BN>
 __global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C,
                                                          int M, int N, int K) {
-  constexpr int BM = 128, BN = 128, BK = 16, AP = BK + 1, BP = BN + 4;
+  constexpr int BM = 128, BK = 16, AP = BK + 1, BP = BN + 4;
+  constexpr int WN = BN == 128 ? 2 : 1, WM = 4 / WN, TI = BM / (32 * WM), TJ = BN / (32 * WN);   // wave grid, MFMA tiles per wave
   __shared__ float As[BM * AP];
   __shared__ float Bs[BK * BP];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  f32x16 acc[2][2];
+  f32x16 acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   const int ar = t >> 1, ac = (t & 1) * 8;     // A tile: 128 rows x 16 cols, 8 floats per thread
-  const int br = t >> 4, bc = (t & 15) * 8;    // B tile: 16 rows x 128 cols
+  constexpr int BV = BN * BK / 256;             // B tile: 16 rows x BN cols, 8 (BN = 128) or 2 (BN = 32) floats per thread
+  const int br = t / (BN / BV), bc = (t % (BN / BV)) * BV;
   const bool arow_ok = (m0 + ar) < M;
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+  // the global loads of k-block i + 1 are issued before the MFMAs of block i (register double buffer)
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+  float bv[BV];
+  auto load_block = [&](int k0) {
     if (arow_ok) {
       const float* ap = A + (size_t)(m0 + ar) * K + k0 + ac;
       a0 = *reinterpret_cast<const f32x4*>(ap);
       a1 = *reinterpret_cast<const f32x4*>(ap + 4);
     }
     const float* bp = Bm + (size_t)(k0 + br) * N + n0 + bc;
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+    if constexpr (BV == 8) {
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(bp), q1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bv[e] = q0[e]; bv[4 + e] = q1[e]; }
+    } else {
+      const float2 q = *reinterpret_cast<const float2*>(bp);
+      bv[0] = q.x; bv[1] = q.y;
+    }
+  };
+  load_block(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 4; ++e) { As[ar * AP + ac + e] = a0[e]; As[ar * AP + ac + 4 + e] = a1[e]; }
-    *reinterpret_cast<f32x4*>(&Bs[br * BP + bc]) = b0;
-    *reinterpret_cast<f32x4*>(&Bs[br * BP + bc + 4]) = b1;
+#pragma unroll
+    for (int e = 0; e < BV; ++e) Bs[br * BP + bc + e] = bv[e];
     __syncthreads();
+    load_block(k0 + BK < K ? k0 + BK : k0);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      float af[2], bf[2];
+      float af[TI], bf[TJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = As[(wm * 64 + i * 32 + l31) * AP + kk + lh];
+      for (int i = 0; i < TI; ++i) af[i] = As[(wm * 32 * TI + i * 32 + l31) * AP + kk + lh];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = Bs[(kk + lh) * BP + wn * 64 + j * 32 + l31];
+      for (int j = 0; j < TJ; ++j) bf[j] = Bs[(kk + lh) * BP + wn * 32 * TJ + j * 32 + l31];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int n = n0 + wn * 64 + j * 32 + l31;
+        const int m = m0 + wm * 32 * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int n = n0 + wn * 32 * TJ + j * 32 + l31;
         if (m < M) C[(size_t)m * N + n] = acc[i][j][r];
       }
+}
+
+// narrow tiles while the wide ones would leave compute units idle
+static void launch_sgemm(const float* A, const float* Bm, float* C, int M, int N, int K, hipStream_t st) {
+  const int rows = fd_cdiv(M, 128);
+  if ((long long)rows * (N / 128) >= 512) hipLaunchKernelGGL(sgemm_mfma_kernel<128>, dim3(N / 128, rows), dim3(256), 0, st, A, Bm, C, M, N, K);
+  else hipLaunchKernelGGL(sgemm_mfma_kernel<32>, dim3(N / 32, rows), dim3(256), 0, st, A, Bm, C, M, N, K);
 }
 
 // spec[b*T+t][2f,2f+1] -> Y[b][f][t] = beta * |X|^alpha * exp(j angle X); frames t >= T are zero padding
@@ -264,7 +289,7 @@ int fd_stft_forward(fd_stft_plan* p, const float* y, int B, int L, float alpha, 
   const int M = B * T;
   hipLaunchKernelGGL(absmax_kernel, dim3(B), dim3(1024), 0, st, y, L, normalize, normfac);
   hipLaunchKernelGGL(frame_kernel, dim3(grid_cap((long long)M * K)), dim3(256), 0, st, y, normfac, frames, B, L, T, p->n_fft, p->hop, K);
-  hipLaunchKernelGGL(sgemm_mfma_kernel, dim3(K / 128, fd_cdiv(M, 128)), dim3(256), 0, st, frames, p->Dt, spec, M, K, K);
+  launch_sgemm(frames, p->Dt, spec, M, K, K, st);
   hipLaunchKernelGGL(compress_kernel, dim3(grid_cap((long long)B * p->n_freq * T_pad)), dim3(256), 0, st, spec, (float2*)Y, B, p->n_freq, T,
                      T_pad, K, alpha, beta);
   FD_LAUNCH_CHECK();
@@ -282,7 +307,7 @@ int fd_stft_inverse(fd_stft_plan* p, const float* X, int B, int T, int T_pad, fl
   const int M = B * T;
   hipLaunchKernelGGL(decompress_kernel, dim3(grid_cap((long long)M * (K / 2))), dim3(256), 0, st, (const float2*)X, Z, B, p->n_freq, T, T_pad, K,
                      alpha, beta);
-  hipLaunchKernelGGL(sgemm_mfma_kernel, dim3(K / 128, fd_cdiv(M, 128)), dim3(256), 0, st, Z, p->E, FR, M, K, K);
+  launch_sgemm(Z, p->E, FR, M, K, K, st);
   hipLaunchKernelGGL(overlap_add_kernel, dim3(grid_cap((long long)B * L)), dim3(256), 0, st, FR, p->w2, normfac, y, B, T, L, p->n_fft, p->hop, K);
   FD_LAUNCH_CHECK();
   return FD_OK;

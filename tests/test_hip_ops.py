@@ -66,7 +66,7 @@ CONV_CASES = [
     ("3x3_head_cout4", 2, 16, 16, 128, 0, 4, 3, True, 1, True, 0, 0),
     ("3x3_head_odd_chunks", 1, 24, 20, 96, 0, 4, 3, True, 1, True, 0, 0),     # 3 chunks: generic BN = 32 configuration
     ("3x3_head_concat_plain", 2, 20, 36, 64, 64, 4, 3, False, 1, False, 0, 0),  # dedicated head kernel, two segments, ragged tiles
-    ("3x3_head_256", 1, 32, 16, 256, 0, 4, 3, True, 2, True, 0, 0),
+    ("3x3_head_256", 2, 32, 16, 256, 0, 4, 3, True, 2, True, 0, 0),
     ("3x3_small_c8", 1, 16, 16, 8, 0, 8, 3, True, 1, False, 0, 0),
     ("3x3_cout16", 1, 32, 16, 16, 8, 16, 3, True, 1, True, 0, 0),
     ("1x1_basic", 2, 16, 16, 64, 0, 128, 1, False, 1, False, 0, 0),
@@ -227,6 +227,25 @@ def test_fir_resample(ops, direction, C, prec):
     raw2, act2 = ops.fir_resample(nhwc(x, DT[prec]), direction)
     assert act2 is None
     check(f"fir_raw_only[{direction},{C},{prec}]", from_nhwc(raw2), ref_raw, tol)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+@pytest.mark.parametrize("direction", [1, -1])
+def test_fir_resample_block_variants(ops, direction, prec):
+    """The fused FIR kernels pick rows / output block per thread by the grid size (big blocks on big grids); every output is the
+    same fma sequence in every variant: a batch large enough for the big-block variant gives, clip by clip, the bits of the
+    one-clip launches (small-block variants), which test_fir_resample pins against the oracle."""
+    g = torch.Generator(device="cuda").manual_seed(7 + direction)
+    B, H, W, C = 6, 256, 128, 256
+    x = torch.randn(B, H, W, C, device="cuda", generator=g).to(DT[prec])
+    aff = torch.stack([1 + 0.2 * torch.randn(B, C, device="cuda", generator=g), 0.3 * torch.randn(B, C, device="cuda", generator=g)], -1).contiguous()
+    raw, act = ops.fir_resample(x, direction, affine=aff)
+    for b in (0, B - 1):
+        raw1, act1 = ops.fir_resample(x[b:b + 1].contiguous(), direction, affine=aff[b:b + 1].contiguous())
+        assert torch.equal(raw[b], raw1[0]) and torch.equal(act[b], act1[0])
+    small = x[:1, :24, :16].contiguous()
+    raw_s, act_s = ops.fir_resample(small, direction, affine=aff[:1].contiguous())
+    assert torch.isfinite(raw_s.float()).all() and torch.isfinite(act_s.float()).all()
 
 
 def test_upfirdn2d_golden():
