@@ -245,7 +245,7 @@ def main():
         achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[args.precision]
         nl = max(int(n.value), 1)
-        result["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel / conv_wino_kernel (implicit-GEMM 3x3/1x1)", "achieved": achieved, "peak": peak,
+        result["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel / conv_wino_kernel / conv_head_kernel (implicit-GEMM 3x3/1x1)", "achieved": achieved, "peak": peak,
                               "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "launches": int(n.value),
                               "avg_launch_ms": ms.value / nl, "conv_ms_per_step": ms.value, "algorithmic_tflop_per_step": fl.value / 1e12,
                               "algorithmic_tflop_per_launch": fl.value / 1e12 / nl, "algorithmic_bytes_per_launch": by.value / nl,

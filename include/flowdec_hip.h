@@ -41,9 +41,9 @@ extern "C" {
 /* fd_model_config.act_dtype only: Winograd for the blocks of resolution level >= 2 (small grids, where its 128-cout workgroups
  * fill the chip better), direct MFMA convolution elsewhere. */
 #define FD_WINOGRAD_LOWRES 0x200
-/* fd_model_config.act_dtype only: both packings are kept and every launch picks its kernel by the image size: Winograd for images
- * of at most 96 tiles of 16 x 16 pixels (the low-resolution levels), direct otherwise.  Independent of the batch size, so that a
- * clip gives the same bits alone and inside any batch. */
+/* fd_model_config.act_dtype only: both packings are kept and every launch picks its kernel by the image size: the direct kernel with
+ * FD_TILE_BN64_CHUNK for images of at most 16 tiles of 16 x 16 pixels, Winograd up to 96 tiles (the low-resolution levels), direct
+ * otherwise.  Independent of the batch size, so that a clip gives the same bits alone and inside any batch. */
 #define FD_WINOGRAD_AUTO 0x400
 /* fd_conv2d only (direct kernel): output channels per workgroup, 32 / 64 / 128 instead of the default min(256, padded Cout).  Narrow
  * workgroups put a SMALL image on more compute units (latency) at the price of re-activating the input once per workgroup

@@ -13,6 +13,7 @@ run cfg2_direct --conv-algo direct
 run b1_direct --batch 1 --seconds 1 --steps 20 --warmup 3 --conv-algo direct
 run b1_auto --batch 1 --seconds 1 --steps 20 --warmup 3
 run b1_winograd --batch 1 --seconds 1 --steps 20 --warmup 3 --conv-algo winograd
+run b1_latency --batch 1 --seconds 1 --steps 20 --warmup 3 --conv-algo latency
 run b2_direct --batch 2 --seconds 2 --steps 10 --warmup 3 --conv-algo direct
 run b2_winograd --batch 2 --seconds 2 --steps 10 --warmup 3 --conv-algo winograd
 run cfg5like --precision fp32 --batch 8 --seconds 4 --N 32 --steps 1 --warmup 2 --no-roofline
