@@ -17,6 +17,7 @@ FD_WINOGRAD = 0x100  # algorithm flag OR-ed into a dtype argument (include/flowd
 FD_WINOGRAD_LOWRES = 0x200
 FD_WINOGRAD_AUTO = 0x400
 FD_LOW_LATENCY = 0x800
+FD_BF16_OPERANDS = 0x10000  # with FD_F32: f32 storage, bf16 MFMA operands (precision='mixed')
 FD_TILE = {0: 0, 32: 0x1000, 64: 0x2000, 128: 0x3000, "64c": 0x4000, "32c": 0x5000}  # fd_conv2d: output channels per workgroup (0 = default)
 SOLVERS = {"euler": 0, "midpoint": 1, "heun2": 2, "heun2_eulerlast": 3}
 

@@ -85,6 +85,26 @@ __device__ __forceinline__ u32x4 transform_slot(u32x4 raw, const char* ad) {
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
+// MIXED configurations (f32 storage, bf16 MFMA operands): the 8 channels of one LDS slot are 32 bytes of f32 in memory; they are
+// activated in f32 and rounded to bf16 HERE, at the LDS store -- the only rounding of the residual stream on its way into a conv.
+template <bool ACT>
+__device__ __forceinline__ u32x4 wide_slot(u32x4 lo, u32x4 hi, const char* ad) {
+  u32x4 out;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned u0 = j < 2 ? lo[2 * j] : hi[2 * j - 4], u1 = j < 2 ? lo[2 * j + 1] : hi[2 * j - 3];
+    float y0 = __builtin_bit_cast(float, u0), y1 = __builtin_bit_cast(float, u1);
+    if constexpr (ACT) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ad + 16 * j);
+      y0 = fd_silu(fmaf(y0, a[0], a[1]));
+      y1 = fd_silu(fmaf(y1, a[2], a[3]));
+    }
+    bf16x2 r = {(bf16)y0, (bf16)y1};
+    out[j] = __builtin_bit_cast(unsigned, r);
+  }
+  return out;
+}
+
 
 // CW ("chunk-resident weights", the low-latency configuration): the ring holds the slabs of TWO whole chunks (18 slots), the K loop
 // has ONE barrier per chunk and every slab is requested a full chunk before its first use -- on a small grid the tap-pair ring below
@@ -130,9 +150,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <typename T, int WM, int WN, int MT, int NT, bool SKIP, bool CW = false>
+template <typename T, int WM, int WN, int MT, int NT, bool SKIP, bool CW = false, bool MIXED = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) {
   using G = Geo<WM, WN, MT, NT, CW>;
+  using TS = std::conditional_t<MIXED, float, T>;   // storage type of activations / residual / output (T: MFMA operand type)
+  static_assert(!MIXED || sizeof(T) == 2, "MIXED = f32 storage around bf16 MFMA operands");
   constexpr int EPS = Math<T>::EPS;
   constexpr int CK = 4 * EPS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -182,6 +204,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const size_t img_elems = (size_t)H * W;
 
   u32x4 hreg[G::HITER];
+  u32x4 hreg_hi[MIXED ? G::HITER : 1];   // MIXED: channels 4..7 of the slot (f32 in memory)
 
   // state of the chunk being prefetched (all wave-uniform)
   __amdgpu_buffer_rsrc_t nsrd = wsrd;
@@ -189,8 +212,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   bool nchan_ok = false;
   auto next_chunk = [&](int s, int ch) {
     const Seg sg = p.seg[s];
-    const T* src = reinterpret_cast<const T*>(sg.src) + (size_t)b * img_elems * sg.C;
-    nsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(src), 0, (int)(img_elems * sg.C * sizeof(T)), 0x00020000);
+    const TS* src = reinterpret_cast<const TS*>(sg.src) + (size_t)b * img_elems * sg.C;
+    nsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<TS*>(src), 0, (int)(img_elems * sg.C * sizeof(TS)), 0x00020000);
     nC = sg.C;
     const int c = ch * CK + q * EPS;
     nchan_ok = c < sg.C;
@@ -201,10 +224,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #define FD_HALO_AUX 0
 #endif
   int npix_on = 1;   // 0: the prefetch target is unused (last chunk of the K loop) -> every lane re-reads pixel 0 (one cache line, no HBM traffic)
-  auto load_halo_slot = [&](int i) { hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(nsrd, (pixl[i] * npix_on * nC + nc) * (int)sizeof(T), 0, FD_HALO_AUX); };
+  auto load_halo_slot = [&](int i) {
+    const int off = (pixl[i] * npix_on * nC + nc) * (int)sizeof(TS);
+    hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(nsrd, off, 0, FD_HALO_AUX);
+    if constexpr (MIXED) hreg_hi[i] = __builtin_amdgcn_raw_buffer_load_b128(nsrd, off + 16, 0, FD_HALO_AUX);
+  };
   auto store_halo_slot = [&](int i, int buf) {
     u32x4 v = hreg[i];
-    if (naff >= 0) v = transform_slot<T, EPS>(v, afftab + naff);
+    if constexpr (MIXED) v = naff >= 0 ? wide_slot<true>(hreg[i], hreg_hi[i], afftab + naff) : wide_slot<false>(hreg[i], hreg_hi[i], afftab);
+    else if (naff >= 0) v = transform_slot<T, EPS>(v, afftab + naff);
     if (!(nchan_ok && ((pvalid >> i) & 1u))) v = u32x4{0u, 0u, 0u, 0u};  // zero padding AFTER the activation
     if ((hexist >> i) & 1u) *reinterpret_cast<u32x4*>(hbuf + buf * G::HALO_BYTES + hlds[i]) = v;
   };
@@ -547,8 +575,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // ---- epilogue ------------------------------------------------------------------------------------------------------
   // MT rounds; in round mi every wave stages its acc[mi][*] (32 pixels x NT*32 couts, f32) to LDS as
   // [pixel (wm*32 + l31)][cout], then all threads sweep the WM*32 pixels with 8 couts (16/32 B) per lane.
-  T* out = reinterpret_cast<T*>(p.out);
-  const T* skip = SKIP ? reinterpret_cast<const T*>(p.skip) : nullptr;   // residual input (compile-time: see the sweep below)
+  TS* out = reinterpret_cast<TS*>(p.out);
+  const TS* skip = SKIP ? reinterpret_cast<const TS*>(p.skip) : nullptr;   // residual input (compile-time: see the sweep below)
   const int oct = t % G::OCT, prow_e = t / G::OCT;
   const int n_e = n0 + oct * 8;
   const bool n_ok = n_e < p.Cout;
@@ -577,7 +605,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     // (a) addresses + skip prefetch for this round's passes
     size_t oaddr[G::NPASS];
     bool ovalid[G::NPASS];
-    u32x4 skraw[G::NPASS][sizeof(T) == 2 ? 1 : 2];
+    u32x4 skraw[G::NPASS][sizeof(TS) == 2 ? 1 : 2];
 #pragma unroll
     for (int ps = 0; ps < G::NPASS; ++ps) {
       const int pp = prow_e + ps * G::PPASS;          // staged pixel: wm' = pp >> 5, l31' = pp & 31
@@ -589,9 +617,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         if (n_cnt == 8) {
           const u32x4* sp = reinterpret_cast<const u32x4*>(skip + oaddr[ps]);
           skraw[ps][0] = sp[0];
-          if constexpr (sizeof(T) == 4) skraw[ps][1] = sp[1];
+          if constexpr (sizeof(TS) == 4) skraw[ps][1] = sp[1];
         } else if (ovalid[ps]) {   // 4 channels (pyramid heads): 8 / 16 bytes
-          if constexpr (sizeof(T) == 2) { const uint2 q2 = *reinterpret_cast<const uint2*>(skip + oaddr[ps]); skraw[ps][0] = u32x4{q2.x, q2.y, 0u, 0u}; }
+          if constexpr (sizeof(TS) == 2) { const uint2 q2 = *reinterpret_cast<const uint2*>(skip + oaddr[ps]); skraw[ps][0] = u32x4{q2.x, q2.y, 0u, 0u}; }
           else skraw[ps][0] = *reinterpret_cast<const u32x4*>(skip + oaddr[ps]);
         }
       }
@@ -616,7 +644,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     // stores (hipcc puts a vmcnt(0) in front of the first use of a residual value) would drain the previous store at full
     // memory latency.  For the same reason the residual input is a compile-time property of the kernel (SKIP): launches
     // without it have no load, hence no wait, anywhere in the epilogue.
-    u32x4 packed[G::NPASS][sizeof(T) == 2 ? 1 : 2];
+    u32x4 packed[G::NPASS][sizeof(TS) == 2 ? 1 : 2];
 #pragma unroll
     for (int ps = 0; ps < G::NPASS; ++ps) {
       const int pp = prow_e + ps * G::PPASS;
@@ -624,7 +652,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       if constexpr (SKIP) {
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (sizeof(TS) == 2) {
           const bf16x8 sk = __builtin_bit_cast(bf16x8, skraw[ps][0]);   // (the upper 4 lanes are zero in the 4-channel case)
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += (float)sk[j];
@@ -646,7 +674,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         const float w = j < n_cnt ? v[j] * keep : 0.f;
         ssum[j] += w; ssq[j] = fmaf(w, w, ssq[j]);
       }
-      if constexpr (sizeof(T) == 2) {
+      if constexpr (sizeof(TS) == 2) {
         bf16x8 tv;
 #pragma unroll
         for (int j = 0; j < 8; ++j) tv[j] = (bf16)v[j];
@@ -659,15 +687,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #pragma unroll
     for (int ps = 0; ps < G::NPASS; ++ps) {
       if (!ovalid[ps]) continue;
-      T* op = out + oaddr[ps];
+      TS* op = out + oaddr[ps];
 #ifdef FD_EXP_NOSTORE
       if (packed[ps][0][0] == 0x12345678u)
 #endif
       if (n_cnt == 8) {
         *reinterpret_cast<u32x4*>(op) = packed[ps][0];
-        if constexpr (sizeof(T) == 4) *(reinterpret_cast<u32x4*>(op) + 1) = packed[ps][1];
+        if constexpr (sizeof(TS) == 4) *(reinterpret_cast<u32x4*>(op) + 1) = packed[ps][1];
       } else {   // 4 valid channels (pyramid heads: Cout = 4)
-        if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(op) = uint2{packed[ps][0][0], packed[ps][0][1]};
+        if constexpr (sizeof(TS) == 2) *reinterpret_cast<uint2*>(op) = uint2{packed[ps][0][0], packed[ps][0][1]};
         else *reinterpret_cast<u32x4*>(op) = packed[ps][0];
       }
     }
@@ -751,17 +779,17 @@ inline int n_steps(int C0, int C1, int taps, int CK) { return (fd_cdiv(C0, CK) +
 unsigned long long* g_dbg = nullptr;  // instrumented builds only: device buffer of 8 counters per workgroup (fd_debug_buffer)
 #endif
 
-template <typename T, int WM, int WN, int MT, int NT, bool CW = false>
+template <typename T, int WM, int WN, int MT, int NT, bool CW = false, bool MIXED = false>
 int set_attr() {
   using G = Geo<WM, WN, MT, NT, CW>;
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, WM, WN, MT, NT, false, CW>),
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, WM, WN, MT, NT, false, CW, MIXED>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, WM, WN, MT, NT, true, CW>),
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, WM, WN, MT, NT, true, CW, MIXED>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
   return FD_OK;
 }
 
-template <typename T, int WM, int WN, int MT, int NT, bool CW = false>
+template <typename T, int WM, int WN, int MT, int NT, bool CW = false, bool MIXED = false>
 int launch_conv(ConvArgs a, hipStream_t st) {
   using G = Geo<WM, WN, MT, NT, CW>;
   a.tiles_h = fd_cdiv(a.H, G::TH);
@@ -769,8 +797,8 @@ int launch_conv(ConvArgs a, hipStream_t st) {
   a.tiles_n = fd_cdiv(a.Cout, G::BN);
   const long long nblk = (long long)a.B * a.tiles_h * a.tiles_w * a.tiles_n;
   FD_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
-  if (a.skip) hipLaunchKernelGGL((conv_mfma_kernel<T, WM, WN, MT, NT, true, CW>), dim3((unsigned)nblk), dim3(G::NTH), G::LDS_BYTES, st, a);
-  else hipLaunchKernelGGL((conv_mfma_kernel<T, WM, WN, MT, NT, false, CW>), dim3((unsigned)nblk), dim3(G::NTH), G::LDS_BYTES, st, a);
+  if (a.skip) hipLaunchKernelGGL((conv_mfma_kernel<T, WM, WN, MT, NT, true, CW, MIXED>), dim3((unsigned)nblk), dim3(G::NTH), G::LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((conv_mfma_kernel<T, WM, WN, MT, NT, false, CW, MIXED>), dim3((unsigned)nblk), dim3(G::NTH), G::LDS_BYTES, st, a);
   FD_LAUNCH_CHECK();
   return FD_OK;
 }
@@ -794,6 +822,13 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int bn_hint, bool chunk_rin
   return launch_conv<T, 2, 4, 4, 2>(a, st);                                               // 8 waves, BN = 256
 }
 
+// f32 storage around bf16 MFMA operands (FD_F32 | FD_BF16_OPERANDS): the three default widths
+int dispatch_conv_mixed(const ConvArgs& a, hipStream_t st) {
+  if (a.Cout <= 32) return launch_conv<bf16, 4, 1, 2, 1, false, true>(a, st);
+  if (a.Cout <= 128) return launch_conv<bf16, 4, 2, 2, 2, false, true>(a, st);
+  return launch_conv<bf16, 2, 4, 4, 2, false, true>(a, st);
+}
+
 }  // namespace
 
 // hipFuncSetAttribute (dynamic LDS above 64 KiB) is a per-device property: done once per device, thread-safe
@@ -807,6 +842,7 @@ int fd_conv_init_attributes() {
   if (known && done_dev[dev]) return FD_OK;
   FD_TRY((set_attr<bf16, 4, 1, 2, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 1, true>())); FD_TRY((set_attr<bf16, 4, 1, 2, 1, true>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2>()));
   FD_TRY((set_attr<float, 4, 1, 2, 1>())); FD_TRY((set_attr<float, 4, 2, 2, 1>())); FD_TRY((set_attr<float, 4, 2, 2, 2>())); FD_TRY((set_attr<float, 2, 4, 4, 2>()));
+  FD_TRY((set_attr<bf16, 4, 1, 2, 1, false, true>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2, false, true>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2, false, true>()));
   FD_TRY(fd_wino_init_attributes());
   FD_TRY(fd_head_init_attributes());
   if (known) done_dev[dev] = true;
@@ -822,6 +858,7 @@ extern "C" int fd_conv_stats_tiles(int H, int W) { return fd_cdiv(H, 16) * fd_cd
 
 extern "C" long long fd_conv_packed_bytes(int Cout, int C0, int C1, int ksize, int S0, int S1, int wdtype) {
   if (wdtype & FD_WINOGRAD) return fd_wino_supported(Cout, C0, C1, S0, S1, ksize) && (wdtype & 0xff) == FD_BF16 ? fd_wino_packed_bytes(Cout, C0, C1, S0, S1) : 0;
+  if (wdtype == (FD_F32 | FD_BF16_OPERANDS)) wdtype = FD_BF16;   // weights follow the OPERAND type
   const int CK = wdtype == FD_BF16 ? 32 : 16;
   // + 1 KiB slack: the DMA of a partial last 1-KiB piece (BN = 32 configuration) over-reads past the final slab
   return (long long)(n_steps(C0, C1, ksize * ksize, CK) + n_steps(S0, S1, 1, CK)) * cout_pad(Cout) * WROWB + 1024;
@@ -837,6 +874,7 @@ extern "C" int fd_conv_pack_weights(const float* w, const float* w_sc, void* pac
                "fd_conv_pack_weights: FD_WINOGRAD needs bf16 storage, ksize 3, Cout %% 128 == 0 and channel counts %% 32 == 0");
     return fd_wino_pack_weights(w, w_sc, packed, Cout, C0, C1, S0, S1, fd_stream(stream));
   }
+  if (wdtype == (FD_F32 | FD_BF16_OPERANDS)) wdtype = FD_BF16;   // weights follow the OPERAND type
   FD_REQUIRE(wdtype == FD_BF16 || wdtype == FD_F32, "fd_conv_pack_weights: bad dtype");
   const int taps = ksize * ksize, CoutPad = cout_pad(Cout), CK = wdtype == FD_BF16 ? 32 : 16;
   hipStream_t st = fd_stream(stream);
@@ -860,6 +898,8 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   FD_REQUIRE(in0 && packed_w && out, "fd_conv2d: null pointer");
   FD_REQUIRE(ksize == 1 || ksize == 3, "fd_conv2d: ksize must be 1 or 3 (got %d)", ksize);
   const bool wino = (dtype & FD_WINOGRAD) != 0;
+  const bool mixed = (dtype & FD_BF16_OPERANDS) != 0;
+  FD_REQUIRE(!mixed || dtype == (FD_F32 | FD_BF16_OPERANDS), "fd_conv2d: FD_BF16_OPERANDS goes with FD_F32 storage and the default direct configuration only");
   const int tile = dtype & FD_TILE_MASK;
   const int bn_hint = (tile == FD_TILE_BN32 || tile == FD_TILE_BN32_CHUNK) ? 32 : (tile == FD_TILE_BN64 || tile == FD_TILE_BN64_CHUNK) ? 64 : tile == FD_TILE_BN128 ? 128 : 0;
   FD_REQUIRE(tile == 0 || bn_hint > 0, "fd_conv2d: bad FD_TILE_* flag");
@@ -888,7 +928,7 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   if (S1) a.seg[ns++] = Seg{sc1, S1, -1, 1};
   a.nseg = ns;
   a.affine = affine; a.affC = C0 + C1;
-  a.w = packed_w; a.w_bytes = fd_conv_packed_bytes(Cout, C0, C1, ksize, S0, S1, dtype | (wino ? FD_WINOGRAD : 0));
+  a.w = packed_w; a.w_bytes = fd_conv_packed_bytes(Cout, C0, C1, ksize, S0, S1, dtype | (wino ? FD_WINOGRAD : 0) | (mixed ? FD_BF16_OPERANDS : 0));
   a.bias = bias; a.bias_rows = bias_rows; a.skip = skip; a.scale = scale; a.out = out; a.Cout = Cout; a.CoutPad = cout_pad(Cout);
   a.stats = stats; a.B = B; a.H = H; a.W = W;
 #ifdef FD_TIMING2
@@ -897,6 +937,7 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   FD_REQUIRE(a.w_bytes < (1ll << 31), "fd_conv2d: packed weights exceed 2 GiB");
   FD_REQUIRE(affine == nullptr || (C0 + C1) * 8 <= AFF_BYTES, "fd_conv2d: at most %d activated input channels", AFF_BYTES / 8);
   if (wino) return fd_wino_launch(a, fd_stream(stream));
+  if (mixed) return dispatch_conv_mixed(a, fd_stream(stream));
 #ifndef FD_NO_HEAD_KERNEL
   if (bn_hint == 0 && fd_head_supported(a, ksize, dtype)) return fd_head_launch(a, fd_stream(stream));
 #endif

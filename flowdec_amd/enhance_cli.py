@@ -180,7 +180,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--i-min", type=int, default=None)
     p.add_argument("--i-max", type=int, default=None)
     p.add_argument("--rtf", action="store_true")
-    p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32", "mixed"])
     p.add_argument("--seed", type=int, default=None, help="seed of the initial-noise generator (default: nondeterministic like the reference)")
     return p
 
@@ -229,7 +229,7 @@ def main(argv=None, model: Optional[FlowModel] = None) -> int:
             if not os.path.exists(out_path) or not args.skip_existing:
                 y, sr = load_wav(path)
                 # one image must stay below 2 GiB (32-bit buffer offsets of the conv kernel): ~43 s in bf16, ~21 s in fp32
-                max_seconds = min(MAX_SECONDS, 20.0) if args.precision == "fp32" else MAX_SECONDS
+                max_seconds = min(MAX_SECONDS, 20.0) if args.precision != "bf16" else MAX_SECONDS
                 if y.shape[-1] / sr <= max_seconds:
                     if sr != model.sampling_rate:
                         print("RESAMPLING from", sr, "to", model.sampling_rate)

@@ -100,8 +100,8 @@ class NCSNpp(nn.Module):
             unsupported.append("output layer other than 1x1 without bias")
         if unsupported:
             raise NotImplementedError("flowdec_amd.NCSNpp: unsupported configuration: " + "; ".join(unsupported))
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if precision not in ("bf16", "fp32", "mixed"):
+            raise ValueError("precision must be 'bf16', 'fp32' or 'mixed' (f32 activations / residual stream, bf16 MFMA operands)")
         if conv_algo not in CONV_ALGOS or (conv_algo not in ("direct", "auto") and precision != "bf16"):
             raise ValueError(f"conv_algo must be one of {sorted(CONV_ALGOS)} (the Winograd kernel exists for precision='bf16' only)")
         if precision != "bf16":
@@ -153,7 +153,8 @@ class NCSNpp(nn.Module):
         cfg.num_res_blocks = self.num_res_blocks
         cfg.n_fft, cfg.hop = self._stft_cfg["n_fft"], self._stft_cfg["hop"]
         cfg.alpha, cfg.beta = self._stft_cfg["alpha"], self._stft_cfg["beta"]
-        cfg.act_dtype = (L.FD_BF16 | CONV_ALGOS[self.conv_algo]) if self.precision == "bf16" else L.FD_F32
+        cfg.act_dtype = (L.FD_BF16 | CONV_ALGOS[self.conv_algo]) if self.precision == "bf16" else \
+            (L.FD_F32 | L.FD_BF16_OPERANDS if self.precision == "mixed" else L.FD_F32)
         return cfg
 
     def invalidate(self):

@@ -45,6 +45,10 @@ extern "C" {
  * FD_TILE_BN64_CHUNK for images of at most 16 tiles of 16 x 16 pixels, Winograd up to 96 tiles (the low-resolution levels), direct
  * otherwise.  Independent of the batch size, so that a clip gives the same bits alone and inside any batch. */
 #define FD_WINOGRAD_AUTO 0x400
+/* fd_conv_pack_weights / fd_conv2d / fd_model_config.act_dtype, with FD_F32 only: "bf16 operands, f32 residual stream" -- activations,
+ * skip tensors and outputs stay f32 in memory; a convolution rounds its (activated) input to bf16 at the LDS store, its weights are
+ * packed as bf16, accumulation is f32.  Direct kernel, default workgroup widths. */
+#define FD_BF16_OPERANDS 0x10000
 /* fd_conv2d only (direct kernel): output channels per workgroup, 32 / 64 / 128 instead of the default min(256, padded Cout).  Narrow
  * workgroups put a SMALL image on more compute units (latency) at the price of re-activating the input once per workgroup
  * (throughput).  The convolution result is bit-identical for every width (same K order per output); the per-tile statistics
@@ -213,7 +217,7 @@ typedef struct fd_model_config {
   int n_fft;             /* 1534 */
   int hop;               /* 384 */
   float alpha, beta;     /* 0.3, 0.33 */
-  int act_dtype;         /* FD_BF16 (bf16 storage + bf16 MFMA) [| FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY] or FD_F32 (f32 storage + exact f32 MFMA) */
+  int act_dtype;         /* FD_BF16 (bf16 storage + bf16 MFMA) [| FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY], FD_F32 (f32 storage + exact f32 MFMA) or FD_F32 | FD_BF16_OPERANDS */
 } fd_model_config;
 
 int fd_model_create(const fd_model_config* cfg, fd_model** out);

@@ -333,3 +333,47 @@ def test_conv2d_tile_widths(case):
         out, st = run(bn)
         assert torch.equal(out, ref), (name, bn)
         assert torch.allclose(st[:, :, :Cout], ref_st[:, :, :Cout], rtol=1e-4, atol=1e-3), (name, bn)
+
+
+def test_mixed_precision_mode():
+    """precision='mixed' (FD_F32 | FD_BF16_OPERANDS): f32 activations / residual stream / skip tensors, conv inputs rounded to bf16 at
+    the LDS store, bf16 weights, f32 accumulation -- the "bf16 operands, f32 residual stream" mode of VERDICT r1 item 4.  One conv
+    against the f64 convolution of the bf16-rounded operands (only accumulation-order error is left), then the full-width network
+    against the reference goldens G10 / G17."""
+    from flowdec_amd import ops
+    import flowdec_amd
+    g = torch.Generator(device="cuda").manual_seed(11)
+    B, H, W, C0, C1, Cout, S = 2, 24, 40, 64, 32, 256, 64
+    Cin = C0 + C1
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / (Cin * 9) ** 0.5).bfloat16().float()
+    a = 1 + 0.2 * torch.randn(B, Cin, device="cuda", generator=g)
+    d = 0.3 * torch.randn(B, Cin, device="cuda", generator=g)
+    xs = torch.randn(B, H, W, S, device="cuda", generator=g)
+    ws = (torch.randn(Cout, S, 1, 1, device="cuda", generator=g) / S ** 0.5).bfloat16().float()
+    bias = torch.randn(Cout, device="cuda", generator=g)
+    sk = torch.randn(B, H, W, Cout, device="cuda", generator=g)
+    v = x * a[:, None, None, :] + d[:, None, None, :]
+    act = (v * torch.sigmoid(v)).bfloat16().double()
+    ref = torch.nn.functional.conv2d(act.permute(0, 3, 1, 2), w.double(), padding=1) + \
+        torch.nn.functional.conv2d(xs.bfloat16().double().permute(0, 3, 1, 2), ws.double())
+    ref = ((ref + bias.double()[None, :, None, None]).permute(0, 2, 3, 1) + sk.double()) * 0.7071
+    pw = ops.pack_conv_weight(w, C0=C0, dtype=torch.float32, w_sc=ws, bf16_operands=True)
+    out, st = ops.conv2d(x[..., :C0].contiguous(), pw, Cout, 3, x1=x[..., C0:].contiguous(), affine=torch.stack([a, d], -1).contiguous(), bias=bias,
+                         skip=sk, scale=0.7071, sc0=xs, want_stats=True, bf16_operands=True)
+    assert out.dtype == torch.float32
+    err = float((out.double() - ref).norm() / ref.norm())
+    report("conv2d[mixed: f32 storage, bf16 operands]", err, 1e-3)     # bf16 rounding flips of silu() near ties + f32 accumulation order
+    assert err < 1e-3
+    rs = torch.stack([ref.sum((1, 2)), (ref ** 2).sum((1, 2))], -1)
+    assert float((st.double().sum(1)[:, :Cout] - rs).abs().max() / rs.abs().max()) < 1e-3
+
+    g10 = load_golden("g10_ncsnpp_nf64.npz")
+    m = flowdec_amd.from_preset("flowdec_75m", precision="mixed")
+    m.load_state_dict({k: torch.from_numpy(v_) for k, v_ in O.random_state_dict(seed=int(g10["seed"]), nf=64).items()}, strict=False)
+    m = m.cuda()
+    o = m(cu(g10["x"]), cu(g10["y"]), torch.tensor([0.5], device="cuda"))
+    check("ncsnpp_nf64[mixed]", o.cpu().numpy(), g10["out"], TOL_FWD["mixed"])
+    g17 = load_golden("g17_enhance_nf64.npz")
+    xh = m.enhance(torch.from_numpy(g17["y"]), N=6, solver="euler", noise=torch.from_numpy(g17["noise"]))
+    check("enhance_nf64[euler,N=6,mixed]", xh.numpy(), g17["euler_N6"], TOL_WAVE_FULL["mixed"])

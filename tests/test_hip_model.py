@@ -19,9 +19,9 @@ pytestmark = pytest.mark.gpu
 # round 2: the bf16 waveform tolerance is the measured error x 1.3 (DESIGN section 5 states it as the path's contract):
 #   nf = 8 toy model (random weights, very sensitive): 8.5-9.9e-2 measured -> 0.13
 #   full width (nf = 64) against the reference's own enhance() (golden G17): 1.8e-2 (Euler 6) / 2.3e-2 (midpoint 3) -> 0.031
-TOL_FWD = {"fp32": 2e-4, "bf16": 3e-2}
+TOL_FWD = {"fp32": 2e-4, "bf16": 3e-2, "mixed": 1.1e-2}   # mixed: measured 8.1e-3 x 1.3
 TOL_WAVE = {"fp32": 5e-4, "bf16": 1.3e-1}
-TOL_WAVE_FULL = {"fp32": 5e-4, "bf16": 3.1e-2}
+TOL_WAVE_FULL = {"fp32": 5e-4, "bf16": 3.1e-2, "mixed": 1.7e-2}   # measured x 1.3
 
 _cache = {}
 
