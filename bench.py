@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 TRAFFIC_FILE = "r02_conv_traffic.json"
 REF_CPU_FILE = "r02_reference_cpu_timing.json"
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "mixed": 2500.0}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "mixed": 2500.0, "bf16x3": 2500.0 / 3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBPS = 8000.0
 
 
@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=2.0, help="clip length")
     ap.add_argument("--N", type=int, default=6)
     ap.add_argument("--solver", default="euler")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "mixed"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "mixed", "bf16x3"])
     ap.add_argument("--conv-algo", default="auto", choices=["direct", "winograd", "winograd_lowres", "auto", "latency"])
     ap.add_argument("--preset", default="flowdec_75m")
     ap.add_argument("--no-graph", action="store_true")

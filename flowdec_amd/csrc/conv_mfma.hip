@@ -87,8 +87,9 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 // MIXED configurations (f32 storage, bf16 MFMA operands): the 8 channels of one LDS slot are 32 bytes of f32 in memory; they are
 // activated in f32 and rounded to bf16 HERE, at the LDS store -- the only rounding of the residual stream on its way into a conv.
+// low = true: the SECOND term of the two-term bf16 split y = bf16(y) + bf16(y - bf16(y)) (SPLIT configurations, see below).
 template <bool ACT>
-__device__ __forceinline__ u32x4 wide_slot(u32x4 lo, u32x4 hi, const char* ad) {
+__device__ __forceinline__ u32x4 wide_slot(u32x4 lo, u32x4 hi, const char* ad, bool low = false) {
   u32x4 out;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -99,6 +100,7 @@ __device__ __forceinline__ u32x4 wide_slot(u32x4 lo, u32x4 hi, const char* ad) {
       y0 = fd_silu(fmaf(y0, a[0], a[1]));
       y1 = fd_silu(fmaf(y1, a[2], a[3]));
     }
+    if (low) { y0 -= (float)(bf16)y0; y1 -= (float)(bf16)y1; }
     bf16x2 r = {(bf16)y0, (bf16)y1};
     out[j] = __builtin_bit_cast(unsigned, r);
   }
@@ -150,13 +152,20 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <typename T, int WM, int WN, int MT, int NT, bool SKIP, bool CW = false, bool MIXED = false>
+// MIXED: 0 = storage type == operand type; 1 = f32 storage, bf16 operands; 2 (SPLIT) = f32 storage, every operand as the two-term bf16
+// split x = hi + lo and every product as hi*hi + hi*lo + lo*hi (three bf16 MFMAs, f32 accumulation: 16 mantissa bits per operand,
+// ~1e-5 per product instead of bf16's 4e-3 -- the f32-tolerance mode at 3x the bf16 MFMA work instead of the f32 MFMA's 16x).  A K
+// step is then 16 channels: LDS row = [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15], so the two "k-halves" of the pipeline below are
+// the hi and the lo fragments of the step.
+template <typename T, int WM, int WN, int MT, int NT, bool SKIP, bool CW = false, int MIXED = 0>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) {
   using G = Geo<WM, WN, MT, NT, CW>;
-  using TS = std::conditional_t<MIXED, float, T>;   // storage type of activations / residual / output (T: MFMA operand type)
+  using TS = std::conditional_t<MIXED != 0, float, T>;   // storage type of activations / residual / output (T: MFMA operand type)
+  constexpr bool SPLIT = MIXED == 2;
   static_assert(!MIXED || sizeof(T) == 2, "MIXED = f32 storage around bf16 MFMA operands");
+  static_assert(!(SPLIT && CW), "no chunk-ring SPLIT configuration");
   constexpr int EPS = Math<T>::EPS;
-  constexpr int CK = 4 * EPS;
+  constexpr int CK = SPLIT ? 16 : 4 * EPS;   // channels per K chunk (one 64-byte LDS row)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const hbuf = smem;
   char* const wbuf = smem + 2 * G::HALO_BYTES;
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     const TS* src = reinterpret_cast<const TS*>(sg.src) + (size_t)b * img_elems * sg.C;
     nsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<TS*>(src), 0, (int)(img_elems * sg.C * sizeof(TS)), 0x00020000);
     nC = sg.C;
-    const int c = ch * CK + q * EPS;
+    const int c = SPLIT ? ch * CK + (q & 1) * 8 : ch * CK + q * EPS;   // SPLIT: slots 0,1 = hi, 2,3 = lo of the same 16 channels
     nchan_ok = c < sg.C;
     nc = nchan_ok ? c : 0;
     naff = sg.aff_off >= 0 ? (sg.aff_off + nc) * 8 : -1;  // byte offset of this slot's (a,d) pairs in the LDS table
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   };
   auto store_halo_slot = [&](int i, int buf) {
     u32x4 v = hreg[i];
-    if constexpr (MIXED) v = naff >= 0 ? wide_slot<true>(hreg[i], hreg_hi[i], afftab + naff) : wide_slot<false>(hreg[i], hreg_hi[i], afftab);
+    if constexpr (MIXED) v = naff >= 0 ? wide_slot<true>(hreg[i], hreg_hi[i], afftab + naff, SPLIT && q >= 2) : wide_slot<false>(hreg[i], hreg_hi[i], afftab, SPLIT && q >= 2);
     else if (naff >= 0) v = transform_slot<T, EPS>(v, afftab + naff);
     if (!(nchan_ok && ((pvalid >> i) & 1u))) v = u32x4{0u, 0u, 0u, 0u};  // zero padding AFTER the activation
     if ((hexist >> i) & 1u) *reinterpret_cast<u32x4*>(hbuf + buf * G::HALO_BYTES + hlds[i]) = v;
@@ -338,6 +347,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   };
 
   u32x4 wfA[NT], pfA[MT], wfB[NT], pfB[MT];
+  u32x4 wfC[SPLIT ? NT : 1];   // SPLIT: the next step's hi weight fragments land here while this step's are still live
   auto read_frags = [&](u32x4 (&wf)[NT], u32x4 (&pf)[MT], const char* hb, const char* wb, int off, int ks) {
 #pragma unroll
     for (int nj = 0; nj < NT; ++nj) wf[nj] = *reinterpret_cast<const u32x4*>(wb + wbase[ks][nj]);
@@ -371,6 +381,39 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     }
 #endif
   };
+  // SPLIT schedule of one step (sets: wfA = w_hi, pfA = p_hi, wfB = w_lo, pfB = p_lo, wfC = next w_hi):
+  //   phase A: read p_lo(s)                              || w_hi*p_hi, w_lo*p_hi     (p_hi and w_lo are dead afterwards)
+  //   phase B: read w_hi(s+1) -> wfC, p_hi(s+1), w_lo(s+1) || w_hi*p_lo             then wfA = wfC
+  auto read_w = [&](u32x4 (&wf)[NT], const char* wb, int ks) {
+#pragma unroll
+    for (int nj = 0; nj < NT; ++nj) wf[nj] = *reinterpret_cast<const u32x4*>(wb + wbase[ks][nj]);
+  };
+  auto read_p = [&](u32x4 (&pf)[MT], const char* hb, int off, int ks) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) pf[mi] = *reinterpret_cast<const u32x4*>(hb + pbase[mi] + off + 32 * ks);
+  };
+  auto mma_pair = [&](const u32x4 (&w0)[NT], const u32x4 (&w1)[NT], const u32x4 (&pf)[MT]) {   // phase A: both weight halves x p_hi
+#pragma unroll
+    for (int nj = 0; nj < NT; ++nj)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        Math<T>::mma(acc[mi][nj], w0[nj], pf[mi]);
+        Math<T>::mma(acc[mi][nj], w1[nj], pf[mi]);
+      }
+#pragma unroll
+    for (int k = 0; k < 2 * MT * NT; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+      __builtin_amdgcn_sched_group_barrier(0x004, 4, 0);   // 4 SALU
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
+    }
+  };
+  auto take_next = [&]() {
+#pragma unroll
+    for (int nj = 0; nj < (SPLIT ? NT : 0); ++nj) wfA[nj] = wfC[nj];
+  };
 
   int step = 0, hcur = 0;   // step = running (chunk, tap) index = index of the weight slab in K order
   int fetch = 0;            // next slab to DMA; slab i lives in ring slot i % NWBUF
@@ -402,6 +445,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const unsigned long long t2_first = __builtin_amdgcn_s_memtime();
 #endif
   read_frags(wfA, pfA, hbuf, wbuf, n9 > 0 ? 0 : CENTER, 0);  // (the k-half ks = 1 is addressed by passing hb + 32 / wb + 32)
+  if constexpr (SPLIT) read_w(wfB, wbuf, 1);
 
   int cs = 0, cch = 0;  // (segment, chunk) cursor
   auto advance = [&](int& s_, int& ch_) {
@@ -508,8 +552,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         for (int k = 0; k < G::HPG; ++k)
           if ((tap - 3) / 2 * G::HPG + k < G::HITER) store_halo_slot((tap - 3) / 2 * G::HPG + k, hcur ^ 1);
       }
-      read_frags(wfB, pfB, hb, wb, imm, 1);
-      mma_all(wfA, pfA);
+      if constexpr (SPLIT) { read_p(pfB, hb, imm, 1); mma_pair(wfA, wfB, pfA); }
+      else { read_frags(wfB, pfB, hb, wb, imm, 1); mma_all(wfA, pfA); }
       if (barrier_here) {
         // everything issued after the previous barrier has landed and is published; all reads of the finished group's
         // slabs are complete, so their ring slots are refilled with the next slabs in K order
@@ -525,9 +569,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #pragma unroll
         for (int k = 0; k < G::HITER; ++k) load_halo_slot(k);
       }
-      if (tap < 8) read_frags(wfA, pfA, hb, wbn, imm_next, 0);
-      else read_frags(wfA, pfA, hbn, wbn, first_off_next, 0);
-      mma_all(wfB, pfB);
+      if constexpr (SPLIT) {
+        read_w(wfC, wbn, 0);
+        if (tap < 8) read_p(pfA, hb, imm_next, 0);
+        else read_p(pfA, hbn, first_off_next, 0);
+        read_w(wfB, wbn, 1);
+        mma_all(wfA, pfB);
+        take_next();
+      } else {
+        if (tap < 8) read_frags(wfA, pfA, hb, wbn, imm_next, 0);
+        else read_frags(wfA, pfA, hbn, wbn, first_off_next, 0);
+        mma_all(wfB, pfB);
+      }
       ++step;
     }
     hcur ^= 1;
@@ -543,14 +596,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     // the next 1-tap chunk's halo: loaded and published within this step
 #pragma unroll
     for (int k = 0; k < G::HITER; ++k) load_halo_slot(k);
-    read_frags(wfB, pfB, hb, wb, CENTER, 1);
-    mma_all(wfA, pfA);
+    if constexpr (SPLIT) { read_p(pfB, hb, CENTER, 1); mma_pair(wfA, wfB, pfA); }
+    else { read_frags(wfB, pfB, hb, wb, CENTER, 1); mma_all(wfA, pfA); }
 #pragma unroll
     for (int k = 0; k < G::HITER; ++k) store_halo_slot(k, hcur ^ 1);
     block_sync();
     if constexpr (!CW) fetch_slabs(1);   // (CW: all shortcut slabs are already in the ring -- the launcher guarantees n1 <= NWBUF)
-    read_frags(wfA, pfA, hbn, wbn, CENTER, 0);
-    mma_all(wfB, pfB);
+    if constexpr (SPLIT) {
+      read_w(wfC, wbn, 0);
+      read_p(pfA, hbn, CENTER, 0);
+      read_w(wfB, wbn, 1);
+      mma_all(wfA, pfB);
+      take_next();
+    } else {
+      read_frags(wfA, pfA, hbn, wbn, CENTER, 0);
+      mma_all(wfB, pfB);
+    }
     ++step; hcur ^= 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -771,6 +832,35 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, char* __restric
   }
 }
 
+// SPLIT packing: steps of 16 channels; row = [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15] (bf16), w = hi + lo to 16 mantissa bits
+__global__ void pack_weights_split_kernel(const float* __restrict__ w, char* __restrict__ dst, int Cout, int CoutPad, int C0, int C1,
+                                          int taps, long long step0) {
+  constexpr int CK = 16;
+  const int nchunk0 = (C0 + CK - 1) / CK, nchunks = nchunk0 + (C1 + CK - 1) / CK;
+  const long long total = (long long)nchunks * taps * CoutPad * CK;
+  const int Cin = C0 + C1;
+  bf16* d = reinterpret_cast<bf16*>(dst + step0 * CoutPad * WROWB);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % CK);
+    long long r = i / CK;
+    const long long row = r;                       // (chunk * taps + tap) * CoutPad + n
+    const int n = (int)(r % CoutPad); r /= CoutPad;
+    const int tap = (int)(r % taps);
+    const int chunk = (int)(r / taps);
+    float v = 0.f;
+    if (n < Cout) {
+      int c;
+      if (chunk < nchunk0) { c = chunk * CK + k; if (c >= C0) c = -1; }
+      else { c = (chunk - nchunk0) * CK + k; c = (c < C1) ? C0 + c : -1; }
+      if (c >= 0) v = w[((size_t)n * Cin + c) * taps + tap];
+    }
+    const bf16 hi = (bf16)v, lo = (bf16)(v - (float)hi);
+    const int sw = (n >> 2) & 3;
+    d[row * 32 + (((k >> 3) ^ sw) * 8) + (k & 7)] = hi;
+    d[row * 32 + (((2 + (k >> 3)) ^ sw) * 8) + (k & 7)] = lo;
+  }
+}
+
 inline int pad_to(int x, int a) { return (x + a - 1) / a * a; }
 inline int cout_pad(int Cout) { return Cout <= 32 ? 32 : (Cout <= 128 ? 128 : pad_to(Cout, 256)); }
 inline int n_steps(int C0, int C1, int taps, int CK) { return (fd_cdiv(C0, CK) + fd_cdiv(C1, CK)) * taps; }
@@ -779,7 +869,7 @@ inline int n_steps(int C0, int C1, int taps, int CK) { return (fd_cdiv(C0, CK) +
 unsigned long long* g_dbg = nullptr;  // instrumented builds only: device buffer of 8 counters per workgroup (fd_debug_buffer)
 #endif
 
-template <typename T, int WM, int WN, int MT, int NT, bool CW = false, bool MIXED = false>
+template <typename T, int WM, int WN, int MT, int NT, bool CW = false, int MIXED = 0>
 int set_attr() {
   using G = Geo<WM, WN, MT, NT, CW>;
   FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, WM, WN, MT, NT, false, CW, MIXED>),
@@ -789,7 +879,7 @@ int set_attr() {
   return FD_OK;
 }
 
-template <typename T, int WM, int WN, int MT, int NT, bool CW = false, bool MIXED = false>
+template <typename T, int WM, int WN, int MT, int NT, bool CW = false, int MIXED = 0>
 int launch_conv(ConvArgs a, hipStream_t st) {
   using G = Geo<WM, WN, MT, NT, CW>;
   a.tiles_h = fd_cdiv(a.H, G::TH);
@@ -824,9 +914,15 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int bn_hint, bool chunk_rin
 
 // f32 storage around bf16 MFMA operands (FD_F32 | FD_BF16_OPERANDS): the three default widths
 int dispatch_conv_mixed(const ConvArgs& a, hipStream_t st) {
-  if (a.Cout <= 32) return launch_conv<bf16, 4, 1, 2, 1, false, true>(a, st);
-  if (a.Cout <= 128) return launch_conv<bf16, 4, 2, 2, 2, false, true>(a, st);
-  return launch_conv<bf16, 2, 4, 4, 2, false, true>(a, st);
+  if (a.Cout <= 32) return launch_conv<bf16, 4, 1, 2, 1, false, 1>(a, st);
+  if (a.Cout <= 128) return launch_conv<bf16, 4, 2, 2, 2, false, 1>(a, st);
+  return launch_conv<bf16, 2, 4, 4, 2, false, 1>(a, st);
+}
+// two-term bf16 split (FD_F32 | FD_BF16X3_OPERANDS)
+int dispatch_conv_split(const ConvArgs& a, hipStream_t st) {
+  if (a.Cout <= 32) return launch_conv<bf16, 4, 1, 2, 1, false, 2>(a, st);
+  if (a.Cout <= 128) return launch_conv<bf16, 4, 2, 2, 2, false, 2>(a, st);
+  return launch_conv<bf16, 2, 4, 4, 2, false, 2>(a, st);
 }
 
 }  // namespace
@@ -842,7 +938,8 @@ int fd_conv_init_attributes() {
   if (known && done_dev[dev]) return FD_OK;
   FD_TRY((set_attr<bf16, 4, 1, 2, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 1, true>())); FD_TRY((set_attr<bf16, 4, 1, 2, 1, true>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2>()));
   FD_TRY((set_attr<float, 4, 1, 2, 1>())); FD_TRY((set_attr<float, 4, 2, 2, 1>())); FD_TRY((set_attr<float, 4, 2, 2, 2>())); FD_TRY((set_attr<float, 2, 4, 4, 2>()));
-  FD_TRY((set_attr<bf16, 4, 1, 2, 1, false, true>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2, false, true>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2, false, true>()));
+  FD_TRY((set_attr<bf16, 4, 1, 2, 1, false, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2, false, 1>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2, false, 1>()));
+  FD_TRY((set_attr<bf16, 4, 1, 2, 1, false, 2>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2, false, 2>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2, false, 2>()));
   FD_TRY(fd_wino_init_attributes());
   FD_TRY(fd_head_init_attributes());
   if (known) done_dev[dev] = true;
@@ -859,7 +956,8 @@ extern "C" int fd_conv_stats_tiles(int H, int W) { return fd_cdiv(H, 16) * fd_cd
 extern "C" long long fd_conv_packed_bytes(int Cout, int C0, int C1, int ksize, int S0, int S1, int wdtype) {
   if (wdtype & FD_WINOGRAD) return fd_wino_supported(Cout, C0, C1, S0, S1, ksize) && (wdtype & 0xff) == FD_BF16 ? fd_wino_packed_bytes(Cout, C0, C1, S0, S1) : 0;
   if (wdtype == (FD_F32 | FD_BF16_OPERANDS)) wdtype = FD_BF16;   // weights follow the OPERAND type
-  const int CK = wdtype == FD_BF16 ? 32 : 16;
+  const int CK = wdtype == FD_BF16 ? 32 : 16;                    // (FD_F32 | FD_BF16X3_OPERANDS: 16 channels per step, hi + lo per row)
+  FD_REQUIRE(wdtype == FD_BF16 || wdtype == FD_F32 || wdtype == (FD_F32 | FD_BF16X3_OPERANDS), "fd_conv_packed_bytes: bad dtype");
   // + 1 KiB slack: the DMA of a partial last 1-KiB piece (BN = 32 configuration) over-reads past the final slab
   return (long long)(n_steps(C0, C1, ksize * ksize, CK) + n_steps(S0, S1, 1, CK)) * cout_pad(Cout) * WROWB + 1024;
 }
@@ -875,13 +973,16 @@ extern "C" int fd_conv_pack_weights(const float* w, const float* w_sc, void* pac
     return fd_wino_pack_weights(w, w_sc, packed, Cout, C0, C1, S0, S1, fd_stream(stream));
   }
   if (wdtype == (FD_F32 | FD_BF16_OPERANDS)) wdtype = FD_BF16;   // weights follow the OPERAND type
-  FD_REQUIRE(wdtype == FD_BF16 || wdtype == FD_F32, "fd_conv_pack_weights: bad dtype");
+  const bool split = wdtype == (FD_F32 | FD_BF16X3_OPERANDS);
+  FD_REQUIRE(wdtype == FD_BF16 || wdtype == FD_F32 || split, "fd_conv_pack_weights: bad dtype");
   const int taps = ksize * ksize, CoutPad = cout_pad(Cout), CK = wdtype == FD_BF16 ? 32 : 16;
   hipStream_t st = fd_stream(stream);
   auto run = [&](const float* src, int c0, int c1, int tp, long long step0) {
     const long long total = (long long)n_steps(c0, c1, tp, CK) * CoutPad * CK;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    if (wdtype == FD_BF16)
+    if (split)
+      hipLaunchKernelGGL(pack_weights_split_kernel, dim3(blocks), dim3(256), 0, st, src, (char*)packed, Cout, CoutPad, c0, c1, tp, step0);
+    else if (wdtype == FD_BF16)
       hipLaunchKernelGGL(pack_weights_kernel<bf16>, dim3(blocks), dim3(256), 0, st, src, (char*)packed, Cout, CoutPad, c0, c1, tp, step0);
     else
       hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, st, src, (char*)packed, Cout, CoutPad, c0, c1, tp, step0);
@@ -898,8 +999,9 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   FD_REQUIRE(in0 && packed_w && out, "fd_conv2d: null pointer");
   FD_REQUIRE(ksize == 1 || ksize == 3, "fd_conv2d: ksize must be 1 or 3 (got %d)", ksize);
   const bool wino = (dtype & FD_WINOGRAD) != 0;
-  const bool mixed = (dtype & FD_BF16_OPERANDS) != 0;
-  FD_REQUIRE(!mixed || dtype == (FD_F32 | FD_BF16_OPERANDS), "fd_conv2d: FD_BF16_OPERANDS goes with FD_F32 storage and the default direct configuration only");
+  const bool mixed = (dtype & FD_BF16_OPERANDS) != 0, split = (dtype & FD_BF16X3_OPERANDS) != 0;
+  FD_REQUIRE(!(mixed || split) || dtype == (FD_F32 | FD_BF16_OPERANDS) || dtype == (FD_F32 | FD_BF16X3_OPERANDS),
+             "fd_conv2d: FD_BF16_OPERANDS / FD_BF16X3_OPERANDS go with FD_F32 storage and the default direct configuration only");
   const int tile = dtype & FD_TILE_MASK;
   const int bn_hint = (tile == FD_TILE_BN32 || tile == FD_TILE_BN32_CHUNK) ? 32 : (tile == FD_TILE_BN64 || tile == FD_TILE_BN64_CHUNK) ? 64 : tile == FD_TILE_BN128 ? 128 : 0;
   FD_REQUIRE(tile == 0 || bn_hint > 0, "fd_conv2d: bad FD_TILE_* flag");
@@ -928,7 +1030,7 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   if (S1) a.seg[ns++] = Seg{sc1, S1, -1, 1};
   a.nseg = ns;
   a.affine = affine; a.affC = C0 + C1;
-  a.w = packed_w; a.w_bytes = fd_conv_packed_bytes(Cout, C0, C1, ksize, S0, S1, dtype | (wino ? FD_WINOGRAD : 0) | (mixed ? FD_BF16_OPERANDS : 0));
+  a.w = packed_w; a.w_bytes = fd_conv_packed_bytes(Cout, C0, C1, ksize, S0, S1, dtype | (wino ? FD_WINOGRAD : 0) | (mixed ? FD_BF16_OPERANDS : 0) | (split ? FD_BF16X3_OPERANDS : 0));
   a.bias = bias; a.bias_rows = bias_rows; a.skip = skip; a.scale = scale; a.out = out; a.Cout = Cout; a.CoutPad = cout_pad(Cout);
   a.stats = stats; a.B = B; a.H = H; a.W = W;
 #ifdef FD_TIMING2
@@ -938,6 +1040,7 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   FD_REQUIRE(affine == nullptr || (C0 + C1) * 8 <= AFF_BYTES, "fd_conv2d: at most %d activated input channels", AFF_BYTES / 8);
   if (wino) return fd_wino_launch(a, fd_stream(stream));
   if (mixed) return dispatch_conv_mixed(a, fd_stream(stream));
+  if (split) return dispatch_conv_split(a, fd_stream(stream));
 #ifndef FD_NO_HEAD_KERNEL
   if (bn_hint == 0 && fd_head_supported(a, ksize, dtype)) return fd_head_launch(a, fd_stream(stream));
 #endif

@@ -222,7 +222,7 @@ int pack_conv(fd_model* m, const std::string& name, int Cout, int C0, int C1, in
   FD_TRY(upload_f32(m, name, &src));
   if (!sc_name.empty()) FD_TRY(upload_f32(m, sc_name, &sc));
   void* dst = nullptr;
-  algo |= m->cfg.act_dtype & FD_BF16_OPERANDS;   // mixed mode: bf16 weights for f32 activations
+  algo |= m->cfg.act_dtype & (FD_BF16_OPERANDS | FD_BF16X3_OPERANDS);   // mixed / split modes: bf16 weights for f32 activations
   const long long bytes = fd_conv_packed_bytes(Cout, C0, C1, ks, S0, S1, m->dt | algo);
   FD_REQUIRE(bytes > 0, "internal: no packing for conv '%s'", name.c_str());
   FD_HIP(hipMalloc(&dst, (size_t)bytes));
@@ -292,7 +292,7 @@ struct Fwd {
   int conv(const Tens& a, const Tens* b, size_t aff, const Tens* s0, const Tens* s1, const void* w, const float* bias, int bias_rows,
            const Tens* skip, float scale, Tens& out, int ks, bool want_stats, bool wino = false, const void* w_wino = nullptr) {
     int tile = 0;
-    const int opflag = m ? (m->cfg.act_dtype & FD_BF16_OPERANDS) : 0;
+    const int opflag = m ? (m->cfg.act_dtype & (FD_BF16_OPERANDS | FD_BF16X3_OPERANDS)) : 0;
     const int px_tiles = fd_cdiv(out.H, 16) * fd_cdiv(out.W, 16);
     const bool latency = m && (m->cfg.act_dtype & FD_LOW_LATENCY) && dt == FD_BF16;
     const bool autosel = m && (m->cfg.act_dtype & FD_WINOGRAD_AUTO) && dt == FD_BF16;
@@ -674,10 +674,10 @@ extern "C" int fd_model_create(const fd_model_config* cfg, fd_model** out) {
   FD_REQUIRE(cfg && out, "fd_model_create: null pointer");
   FD_REQUIRE(cfg->nf >= 8 && cfg->nf % 8 == 0 && cfg->nf <= 64, "fd_model_create: nf must be a multiple of 8 in [8, 64] (got %d)", cfg->nf);
   FD_REQUIRE(cfg->num_levels >= 1 && cfg->num_levels <= 8 && cfg->num_res_blocks >= 1, "fd_model_create: bad level / block counts");
-  FD_REQUIRE(((cfg->act_dtype & 0xff) == FD_BF16 && !(cfg->act_dtype & FD_BF16_OPERANDS)) || cfg->act_dtype == FD_F32 ||
-                 cfg->act_dtype == (FD_F32 | FD_BF16_OPERANDS),
-             "fd_model_create: act_dtype must be FD_BF16 [| FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY], FD_F32 or "
-             "FD_F32 | FD_BF16_OPERANDS");
+  FD_REQUIRE(((cfg->act_dtype & 0xff) == FD_BF16 && !(cfg->act_dtype & (FD_BF16_OPERANDS | FD_BF16X3_OPERANDS))) || cfg->act_dtype == FD_F32 ||
+                 cfg->act_dtype == (FD_F32 | FD_BF16_OPERANDS) || cfg->act_dtype == (FD_F32 | FD_BF16X3_OPERANDS),
+             "fd_model_create: act_dtype must be FD_BF16 [| FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY], FD_F32, "
+             "FD_F32 | FD_BF16_OPERANDS or FD_F32 | FD_BF16X3_OPERANDS");
   FD_REQUIRE(cfg->n_fft > 0 && cfg->n_fft % 2 == 0 && cfg->hop > 0, "fd_model_create: bad STFT geometry");
   for (int i = 0; i < cfg->num_levels; ++i) {
     const int ch = cfg->nf * cfg->ch_mult[i];

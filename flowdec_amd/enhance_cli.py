@@ -180,7 +180,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--i-min", type=int, default=None)
     p.add_argument("--i-max", type=int, default=None)
     p.add_argument("--rtf", action="store_true")
-    p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32", "mixed"])
+    p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32", "mixed", "bf16x3"])
     p.add_argument("--seed", type=int, default=None, help="seed of the initial-noise generator (default: nondeterministic like the reference)")
     return p
 

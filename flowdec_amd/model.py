@@ -100,8 +100,9 @@ class NCSNpp(nn.Module):
             unsupported.append("output layer other than 1x1 without bias")
         if unsupported:
             raise NotImplementedError("flowdec_amd.NCSNpp: unsupported configuration: " + "; ".join(unsupported))
-        if precision not in ("bf16", "fp32", "mixed"):
-            raise ValueError("precision must be 'bf16', 'fp32' or 'mixed' (f32 activations / residual stream, bf16 MFMA operands)")
+        if precision not in ("bf16", "fp32", "mixed", "bf16x3"):
+            raise ValueError("precision must be 'bf16', 'fp32', 'mixed' (f32 activations / residual stream, bf16 MFMA operands) or 'bf16x3' "
+                             "(f32 storage, two-term bf16 split operands: f32-mode tolerances on the bf16 matrix cores)")
         if conv_algo not in CONV_ALGOS or (conv_algo not in ("direct", "auto") and precision != "bf16"):
             raise ValueError(f"conv_algo must be one of {sorted(CONV_ALGOS)} (the Winograd kernel exists for precision='bf16' only)")
         if precision != "bf16":
@@ -154,7 +155,7 @@ class NCSNpp(nn.Module):
         cfg.n_fft, cfg.hop = self._stft_cfg["n_fft"], self._stft_cfg["hop"]
         cfg.alpha, cfg.beta = self._stft_cfg["alpha"], self._stft_cfg["beta"]
         cfg.act_dtype = (L.FD_BF16 | CONV_ALGOS[self.conv_algo]) if self.precision == "bf16" else \
-            (L.FD_F32 | L.FD_BF16_OPERANDS if self.precision == "mixed" else L.FD_F32)
+            (L.FD_F32 | {"mixed": L.FD_BF16_OPERANDS, "bf16x3": L.FD_BF16X3_OPERANDS, "fp32": 0}[self.precision])
         return cfg
 
     def invalidate(self):

@@ -49,6 +49,10 @@ extern "C" {
  * skip tensors and outputs stay f32 in memory; a convolution rounds its (activated) input to bf16 at the LDS store, its weights are
  * packed as bf16, accumulation is f32.  Direct kernel, default workgroup widths. */
 #define FD_BF16_OPERANDS 0x10000
+/* same places, with FD_F32 only: every conv operand as the two-term bf16 split x = hi + lo (16 mantissa bits) and every product as
+ * hi*hi + hi*lo + lo*hi on the bf16 matrix cores, f32 accumulation -- results within the f32 mode's tolerances (a conv is ~1e-5 from
+ * the f64 convolution) at 3x the bf16 MFMA work instead of the f32 MFMA's 16x. */
+#define FD_BF16X3_OPERANDS 0x20000
 /* fd_conv2d only (direct kernel): output channels per workgroup, 32 / 64 / 128 instead of the default min(256, padded Cout).  Narrow
  * workgroups put a SMALL image on more compute units (latency) at the price of re-activating the input once per workgroup
  * (throughput).  The convolution result is bit-identical for every width (same K order per output); the per-tile statistics
@@ -217,7 +221,7 @@ typedef struct fd_model_config {
   int n_fft;             /* 1534 */
   int hop;               /* 384 */
   float alpha, beta;     /* 0.3, 0.33 */
-  int act_dtype;         /* FD_BF16 (bf16 storage + bf16 MFMA) [| FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY], FD_F32 (f32 storage + exact f32 MFMA) or FD_F32 | FD_BF16_OPERANDS */
+  int act_dtype;         /* FD_BF16 (bf16 storage + bf16 MFMA) [| FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY], FD_F32 (f32 storage + exact f32 MFMA), FD_F32 | FD_BF16_OPERANDS or FD_F32 | FD_BF16X3_OPERANDS */
 } fd_model_config;
 
 int fd_model_create(const fd_model_config* cfg, fd_model** out);

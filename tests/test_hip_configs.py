@@ -377,3 +377,46 @@ def test_mixed_precision_mode():
     g17 = load_golden("g17_enhance_nf64.npz")
     xh = m.enhance(torch.from_numpy(g17["y"]), N=6, solver="euler", noise=torch.from_numpy(g17["noise"]))
     check("enhance_nf64[euler,N=6,mixed]", xh.numpy(), g17["euler_N6"], TOL_WAVE_FULL["mixed"])
+
+
+def test_bf16x3_precision_mode():
+    """precision='bf16x3' (FD_F32 | FD_BF16X3_OPERANDS): f32 storage, every conv operand as hi + lo bf16 pair, three bf16 MFMAs per
+    product.  Must meet the FP32 mode's tolerances: one conv against the f64 convolution of the UNROUNDED operands, then the
+    full-width network against the reference goldens G10 (one forward) and G17 (enhance) at TOL_FWD / TOL_WAVE_FULL['fp32']."""
+    from flowdec_amd import ops
+    import flowdec_amd
+    g = torch.Generator(device="cuda").manual_seed(12)
+    for (B, H, W, C0, C1, Cout, S, k) in [(2, 24, 40, 64, 32, 256, 64, 3), (1, 20, 16, 8, 0, 64, 0, 3), (2, 16, 16, 128, 0, 4, 0, 3), (1, 16, 32, 64, 0, 128, 0, 1)]:
+        Cin = C0 + C1
+        x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+        w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5
+        a = 1 + 0.2 * torch.randn(B, Cin, device="cuda", generator=g)
+        d = 0.3 * torch.randn(B, Cin, device="cuda", generator=g)
+        v = (x * a[:, None, None, :] + d[:, None, None, :]).double()
+        ref = torch.nn.functional.conv2d((v * torch.sigmoid(v)).permute(0, 3, 1, 2), w.double(), padding=k // 2)
+        xs = ws = None
+        if S:
+            xs = torch.randn(B, H, W, S, device="cuda", generator=g)
+            ws = torch.randn(Cout, S, 1, 1, device="cuda", generator=g) / S ** 0.5
+            ref = ref + torch.nn.functional.conv2d(xs.double().permute(0, 3, 1, 2), ws.double())
+        bias = torch.randn(Cout, device="cuda", generator=g)
+        sk = torch.randn(B, H, W, Cout, device="cuda", generator=g)
+        ref = ((ref + bias.double()[None, :, None, None]).permute(0, 2, 3, 1) + sk.double()) * 0.7071
+        pw = ops.pack_conv_weight(w, C0=C0, dtype=torch.float32, w_sc=ws, bf16_operands="x3")
+        out = ops.conv2d(x[..., :C0].contiguous(), pw, Cout, k, x1=x[..., C0:].contiguous() if C1 else None, affine=torch.stack([a, d], -1).contiguous(),
+                         bias=bias, skip=sk, scale=0.7071, sc0=xs, bf16_operands="x3")
+        err = float((out.double() - ref).norm() / ref.norm())
+        report(f"conv2d[bf16x3,{Cin}->{Cout},k{k}]", err, 5e-5)
+        assert out.dtype == torch.float32 and err < 5e-5, err
+
+    g10 = load_golden("g10_ncsnpp_nf64.npz")
+    m = flowdec_amd.from_preset("flowdec_75m", precision="bf16x3")
+    m.load_state_dict({k_: torch.from_numpy(v_) for k_, v_ in O.random_state_dict(seed=int(g10["seed"]), nf=64).items()}, strict=False)
+    m = m.cuda()
+    o = m(cu(g10["x"]), cu(g10["y"]), torch.tensor([0.5], device="cuda"))
+    check("ncsnpp_nf64[bf16x3]", o.cpu().numpy(), g10["out"], TOL_FWD["fp32"])
+    g17 = load_golden("g17_enhance_nf64.npz")
+    xh = m.enhance(torch.from_numpy(g17["y"]), N=6, solver="euler", noise=torch.from_numpy(g17["noise"]))
+    check("enhance_nf64[euler,N=6,bf16x3]", xh.numpy(), g17["euler_N6"], TOL_WAVE_FULL["fp32"])
+    xm = m.enhance(torch.from_numpy(g17["y"]), N=3, solver="midpoint", noise=torch.from_numpy(g17["noise"]))
+    check("enhance_nf64[midpoint,N=3,bf16x3]", xm.numpy(), g17["midpoint_N3"], TOL_WAVE_FULL["fp32"])
