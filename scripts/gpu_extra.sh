@@ -8,6 +8,8 @@ import json,sys
 d=json.load(open('$O/bench_$name.json')); r=d.get('roofline',{})
 print('$name', round(d['value'],2), 'x', round(d['ms_per_step'],1), 'ms', round(r.get('achieved',0),1), 'TF', d['config']['workload'][:70])" ; }
 run fp32 --precision fp32 --steps 2 --warmup 2
+run bf16x3 --precision bf16x3 --steps 3 --warmup 2
+run mixed --precision mixed --steps 3 --warmup 2
 run cfg3 --preset flowdec_25s --batch 32 --solver midpoint --N 3 --steps 2 --warmup 2
 run cfg2_direct --conv-algo direct
 run b1_direct --batch 1 --seconds 1 --steps 20 --warmup 3 --conv-algo direct
