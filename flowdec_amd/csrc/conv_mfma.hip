@@ -259,29 +259,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       glds16(src0 + (size_t)sl * p.CoutPad * WROWB + pce * 1024, (unsigned)(2 * G::HALO_BYTES + (sl % G::NWBUF) * G::W_LDS + pce * 1024));
     }
   };
-  auto dma_w = [&](int step, int buf) {
-    // straight-line code (no exec masking, no branches): the slab is copied in NPIECE 1-KiB pieces, every wave issues
-    // PER_WAVE of them; surplus slots re-copy another piece (identical bytes), and a partial last piece over-reads into
-    // the next slab / the 1 KiB slack of the packed buffer and lands in the padding of the (1 KiB-rounded) LDS buffer.
-    constexpr int NPIECE = G::W_LDS / 1024;
-    constexpr int NW = G::NTH / 64;
-    constexpr int PER_WAVE = G::DMA_PER_WAVE;
-    const char* src = reinterpret_cast<const char*>(p.w) + ((size_t)step * p.CoutPad + n0) * WROWB + (t & 63) * 16;
-    char* dst = wbuf + buf * G::W_LDS;
-    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-#pragma unroll
-    for (int k = 0; k < PER_WAVE; ++k) {
-      const int pce = (wv + k * NW) % NPIECE;
-#ifdef FD_EXP_DMASAME   // experiment: every piece re-reads the first KiB of the buffer (cache-hot) -> isolates the memory-side cost
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(p.w) + (t & 63) * 16),
-                                       (__attribute__((address_space(3))) void*)(dst + pce * 1024), 16, 0, 0);
-      continue;
-#endif
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pce * 1024),
-                                       (__attribute__((address_space(3))) void*)(dst + pce * 1024), 16, 0, 0);
-    }
-  };
-
   // ---- per-lane fragment coordinates ---------------------------------------------------------------------------
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave - wm * WN;
@@ -416,15 +393,38 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   };
 
   int step = 0, hcur = 0;   // step = running (chunk, tap) index = index of the weight slab in K order
-  int fetch = 0;            // next slab to DMA; slab i lives in ring slot i % NWBUF
+  int fetch = 0;            // CW: next slab to DMA; slab i lives in ring slot i % NWBUF
   const int last_step = nsteps - 1;
   auto slot_of = [&](int i) { return wbuf + (i % G::NWBUF) * G::W_LDS; };
-  auto fetch_slabs = [&](int n) {
-#ifdef FD_EXP_NODMA
-    if (fetch >= G::NWBUF) { fetch += n; return; }
-#endif
-    if constexpr (CW) { dma_chunk(fetch, n, last_step); fetch += n; return; }
-    for (int k = 0; k < n; ++k) { dma_w(fetch <= last_step ? fetch : last_step, fetch % G::NWBUF); ++fetch; }
+  // Weight stream of the tap-pair ring (non-CW).  A slab (BN rows x 64 B, contiguous in global memory = the LDS image) is copied
+  // in 1-KiB pieces by direct-to-LDS DMA; every wave issues DMA_PER_WAVE of them (surplus issues re-copy another piece; a partial
+  // last piece over-reads into the next slab and lands in the padding of the 1-KiB-rounded LDS slot).  ONE wave-uniform pointer
+  // walks the slabs in K order and the per-lane part of the address never changes, so a slab costs two scalar adds; the pointer
+  // simply runs past the last slab (fd_conv_packed_bytes pads the buffer by NWBUF slabs: what lands is never read).
+  constexpr unsigned WOFF = 2 * G::HALO_BYTES;   // LDS byte offset of the ring
+  const char* wfetch = reinterpret_cast<const char*>(p.w) + (size_t)n0 * WROWB;
+  const size_t slab_stride = (size_t)p.CoutPad * WROWB;
+  int dma_pce[G::DMA_PER_WAVE];        // the 1-KiB pieces of a slab this wave copies (wave-uniform)
+  unsigned dma_voff[G::DMA_PER_WAVE];  // per-lane byte offset inside the slab
+  {
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+#pragma unroll
+    for (int j = 0; j < G::DMA_PER_WAVE; ++j) {
+      dma_pce[j] = (wv + j * (G::NTH / 64)) % (G::W_LDS / 1024);
+      dma_voff[j] = (unsigned)(dma_pce[j] * 1024 + (t & 63) * 16);
+    }
+  }
+  auto fetch_to = [&](unsigned dst_off) {   // next slab in K order -> LDS byte offset dst_off
+#pragma unroll
+    for (int j = 0; j < G::DMA_PER_WAVE; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wfetch + dma_voff[j]),
+                                       (__attribute__((address_space(3))) void*)(smem + dst_off + dma_pce[j] * 1024), 16, 0, 0);
+    wfetch += slab_stride;
+    asm volatile("" : "+s"(wfetch));   // keep the walk scalar and sequential (hipcc otherwise pre-computes the vector addresses of a whole chunk)
+  };
+  auto fetch_slabs = [&](int n) {   // CW only
+    dma_chunk(fetch, n, last_step);
+    fetch += n;
   };
   // Prologue: all global traffic of the first step is issued at once (first halo, weight ring, affine table) so that the
   // block pays ONE memory round trip before its first MFMA; the affine table (needed by the halo transform only) is
@@ -432,7 +432,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   next_chunk(0, 0);
 #pragma unroll
   for (int i = 0; i < G::HITER; ++i) load_halo_slot(i);
-  fetch_slabs(G::NWBUF);
+  if constexpr (CW) fetch_slabs(G::NWBUF);
+  else {
+#pragma unroll
+    for (int k = 0; k < G::NWBUF; ++k) fetch_to(WOFF + k * G::W_LDS);
+  }
   if (p.affine) {  // affine table of image b: [affC] x (a, d)
     const float* ap = p.affine + (size_t)b * p.affC * 2;
     for (int i = t; i < p.affC / 2; i += G::NTH) *reinterpret_cast<f32x4*>(afftab + i * 16) = *reinterpret_cast<const f32x4*>(ap + i * 4);
@@ -530,13 +534,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     const char* hb = hbuf + hcur * G::HALO_BYTES;
     const char* hbn = hbuf + (hcur ^ 1) * G::HALO_BYTES;
     const int first_off_next = (i == n9 - 1) ? CENTER : 0;
+    // ring slots of this chunk, computed once: tap t reads slot wso[t & 3]; 9 = 1 (mod 4), so the pattern turns by one per chunk
+    unsigned wso[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wso[k] = WOFF + ((step + k) & 3) * G::W_LDS;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int imm = ((tap / 3) * PITCH + (tap % 3)) * ROWB;
       const int imm_next = (((tap + 1) / 3) * PITCH + ((tap + 1) % 3)) * ROWB;
       const bool barrier_here = (tap & 1) || tap == 8;   // last tap of its group
-      const char* wb = slot_of(step);
-      const char* wbn = slot_of(step + 1);
+      const char* wb = smem + wso[tap & 3];
+      const char* wbn = smem + wso[(tap + 1) & 3];
       // ---- phase A: [store halo slot] | read frags(s, ks=1) || MFMA(s, ks=0)
       // Every wait of this loop is a full drain (the barriers' explicit vmcnt(0), and hipcc's own wait before the first
       // use of a halo register is a vmcnt(0) as well as soon as LDS-DMAs are in flight), so the schedule keeps the
@@ -558,7 +566,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         // everything issued after the previous barrier has landed and is published; all reads of the finished group's
         // slabs are complete, so their ring slots are refilled with the next slabs in K order
         block_sync();
-        fetch_slabs(tap == 8 ? 1 : 2);
+        // the slabs of steps s + 3 (and s + 4): steps 0..3 were fetched by the prologue, every barrier moves on by its group size
+        if (tap == 8) fetch_to(wso[0]);
+        else { fetch_to(wso[(tap + 3) & 3]); fetch_to(wso[(tap + 4) & 3]); }
       }
       // ---- phase B: [load halo slot] | read frags(s+1, ks=0) || MFMA(s, ks=1)
 #ifdef FD_EXP_NOHALO
@@ -601,7 +611,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #pragma unroll
     for (int k = 0; k < G::HITER; ++k) store_halo_slot(k, hcur ^ 1);
     block_sync();
-    if constexpr (!CW) fetch_slabs(1);   // (CW: all shortcut slabs are already in the ring -- the launcher guarantees n1 <= NWBUF)
+    if constexpr (!CW) fetch_to(WOFF + (step & 3) * G::W_LDS);   // slab of step + 4 into the slot this step has just finished with
+                                                                   // (CW: all shortcut slabs are already in the ring -- the launcher guarantees n1 <= NWBUF)
     if constexpr (SPLIT) {
       read_w(wfC, wbn, 0);
       read_p(pfA, hbn, CENTER, 0);
@@ -959,7 +970,8 @@ extern "C" long long fd_conv_packed_bytes(int Cout, int C0, int C1, int ksize, i
   const int CK = wdtype == FD_BF16 ? 32 : 16;                    // (FD_F32 | FD_BF16X3_OPERANDS: 16 channels per step, hi + lo per row)
   FD_REQUIRE(wdtype == FD_BF16 || wdtype == FD_F32 || wdtype == (FD_F32 | FD_BF16X3_OPERANDS), "fd_conv_packed_bytes: bad dtype");
   // + 1 KiB slack: the DMA of a partial last 1-KiB piece (BN = 32 configuration) over-reads past the final slab
-  return (long long)(n_steps(C0, C1, ksize * ksize, CK) + n_steps(S0, S1, 1, CK)) * cout_pad(Cout) * WROWB + 1024;
+  // + 4 slabs: the kernel's slab pointer runs up to a ring length past the last step without a clamp (what it fetches there is never read)
+  return (long long)(n_steps(C0, C1, ksize * ksize, CK) + n_steps(S0, S1, 1, CK) + 4) * cout_pad(Cout) * WROWB + 1024;
 }
 
 extern "C" int fd_conv_pack_weights(const float* w, const float* w_sc, void* packed, int Cout, int C0, int C1, int ksize, int S0,
