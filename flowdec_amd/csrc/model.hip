@@ -3,6 +3,7 @@
 // fixed-step ODE loop (model.py:503-515; torchdyn fixed-step semantics restated) with hipGraph capture, and
 // FlowModel.enhance (model.py:476-528).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -124,6 +125,10 @@ struct fd_model {
   std::map<GraphKey, hipGraphExec_t> graphs;
   std::set<GraphKey> seen;          // keys that ran once eagerly: a solve is captured at its SECOND sighting
   int normalize = 1;                // front end: 1 = per-clip max-abs normalisation ('noisy'), 0 = 'none'
+  // second stream for the side branches of one network evaluation (time embedding, pyramid-head chain): forked from / joined into
+  // the caller's stream with events, also inside a graph capture (parallel branches of the captured graph)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // profiling of the dominant kernel (conv MFMA)
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -257,6 +262,32 @@ struct Fwd {
   int B, F, T, dt, esz;
 
   void* ptr(size_t off) const { return dry ? nullptr : base + off; }
+  // ---- side branch: work that the main chain does not need right away runs on m->side between fork() and back(), and the main
+  // stream waits for it at join().  Buffers a side branch frees go to `deferred` and are released at the join: until then the
+  // arena may not hand them to a kernel of the main stream.  Off in profiling mode (per-kernel event timing) and for the planner.
+  hipStream_t st_main = nullptr;
+  std::vector<size_t> deferred;
+  bool side_plan() const { return m && m->side; }                 // memory discipline: identical for the planner and every run
+  bool side_ok() const { return !dry && side_plan() && !m->profiling; }   // the streams really fork
+  int fork() {
+    if (!side_ok()) return FD_OK;
+    st_main = st;
+    FD_HIP(hipEventRecord(m->ev_fork, st_main));
+    FD_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    st = m->side;
+    return FD_OK;
+  }
+  void back() { if (side_ok()) st = st_main; }
+  int join() {
+    if (side_ok()) {
+      FD_HIP(hipEventRecord(m->ev_join, m->side));
+      FD_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
+    }
+    for (size_t off : deferred) arena.release(off);
+    deferred.clear();
+    return FD_OK;
+  }
+  void release_later(size_t off, bool on_side) { if (on_side) deferred.push_back(off); else arena.release(off); }
   Tens talloc(int C, int H, int W) { Tens t; t.C = C; t.H = H; t.W = W; t.off = arena.alloc((size_t)B * H * W * C * esz); return t; }
   void tfree(Tens& t) {
     if (t.off != (size_t)-1) arena.release(t.off);
@@ -387,11 +418,14 @@ struct Fwd {
     const fd_model_config& c = m->cfg;
     const int R = c.num_levels, nrb = c.num_res_blocks;
     const auto& mods = m->mods;
-    if (!dry) {
+    const bool side = side_plan();
+    if (!dry) {   // time embedding + the 22 Dense_0 biases: needed by the first ResBlock only -> beside the input packing / first conv
+      if (side) FD_TRY(fork());
       FD_TRY(fd_time_embedding_impl(t, t_imm, nt, m->dev_f32["backbone.all_modules.0.W"], c.nf, m->dev_f32["backbone.all_modules.1.weight"],
                                     m->dev_f32["backbone.all_modules.1.bias"], m->dev_f32["backbone.all_modules.2.weight"],
                                     m->dev_f32["backbone.all_modules.2.bias"], m->temb, st));
       FD_TRY(fd_temb_bias_batched(m->jobs_dev, m->njobs, m->temb, nt, m->temb_dim, st));
+      if (side) back();
     }
     size_t mi = 3;
     Tens in4 = talloc(8, F, T);   // 4 real channels + 4 zero channels (MFMA conv needs Cin % 8 == 0)
@@ -405,6 +439,7 @@ struct Fwd {
       if (!dry && m->profiling) m->prof_flops -= 2.0 * B * F * T * (double)md.cout * 4 * 9;  // the 4 padding channels are not algorithmic work
       hs.push_back(h0);
     }
+    if (side) FD_TRY(join());   // the time-embedding biases are ready
     Tens pyr_in = in4;  // input pyramid (owned here)
     Tens h;
     for (int lvl = 0; lvl < R; ++lvl) {
@@ -448,6 +483,9 @@ struct Fwd {
       }
       const Mod& gn = mods[mi++];
       const Mod& head = mods[mi++];
+      // The head chain (GroupNorm + 3x3 conv to 4 channels + FIR-up of the running pyramid) only meets the main chain again at the
+      // output layer: it runs on the side stream next to the up-sampling ResBlock that reads the same h.
+      if (side) FD_TRY(fork());
       size_t aff;
       FD_TRY(gn_affine(h, nullptr, gn.gn0_g, gn.gn0_b, &aff));
       Tens pnew = talloc(4, h.H, h.W);
@@ -455,17 +493,22 @@ struct Fwd {
         Tens pu = talloc(4, h.H, h.W);
         if (!dry) FD_TRY(fir(ptr(pyramid.off), nullptr, ptr(pu.off), nullptr, pyramid.H, pyramid.W, 4, +1));
         FD_TRY(conv(h, nullptr, aff, nullptr, nullptr, head.w0, head.b_f32, 1, &pu, 1.f, pnew, 3, false));
-        tfree(pu); tfree(pyramid);
+        release_later(pu.off, side); release_later(pyramid.off, side);
+        pu.off = pyramid.off = (size_t)-1;
       } else {
         FD_TRY(conv(h, nullptr, aff, nullptr, nullptr, head.w0, head.b_f32, 1, nullptr, 1.f, pnew, 3, false));
       }
-      arena.release(aff);
+      release_later(aff, side);
       pyramid = pnew; have_pyr = true;
+      if (side) back();
       if (lvl != 0) {
         Tens o;
         FD_TRY(resblock(mods[mi++], h, nullptr, nt, o));
+        if (side) FD_TRY(join());   // the head has read h; its scratch goes back to the arena
         tfree(h);
         h = o;
+      } else if (side) {
+        FD_TRY(join());
       }
     }
     tfree(h);
@@ -700,6 +743,9 @@ extern "C" void fd_model_destroy(fd_model* m) {
   for (auto& e : m->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : m->ev_fir) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   fd_stft_plan_destroy(m->stft);
+  if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+  if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+  if (m->side) (void)hipStreamDestroy(m->side);
   delete m;
 }
 
@@ -843,6 +889,14 @@ extern "C" int fd_model_finalize(fd_model* m, void* stream) {
   m->dev_allocs.push_back(m->sigma_dev);
   FD_HIP(hipMemcpy(m->sigma_dev, m->sigma_host.data(), sizeof(double) * m->sigma_n, hipMemcpyHostToDevice));
   FD_TRY(fd_stft_plan_create(m->cfg.n_fft, m->cfg.hop, &m->stft));
+  {
+    const char* e = getenv("FLOWDEC_SIDE_STREAM");   // =0: everything on the caller's stream
+    if (!(e && e[0] == '0')) {
+      FD_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+      FD_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+      FD_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    }
+  }
   FD_HIP(hipStreamSynchronize(st));
   m->host.clear();
   m->finalized = true;
