@@ -111,7 +111,7 @@ __device__ __forceinline__ u32x4 wide_slot(u32x4 lo, u32x4 hi, const char* ad, b
 // CW ("chunk-resident weights", the low-latency configuration): the ring holds the slabs of TWO whole chunks (18 slots), the K loop
 // has ONE barrier per chunk and every slab is requested a full chunk before its first use -- on a small grid the tap-pair ring below
 // makes every barrier group wait for one memory round trip (measured: 31 us for a 256 -> 256 convolution whatever the tile width).
-template <int WM, int WN, int MT, int NT, bool CW = false>
+template <int WM, int WN, int MT, int NT, bool CW = false, bool SH = false>
 struct Geo {
   static constexpr int NTH = 64 * WM * WN;
   static constexpr int NP = WM * MT;       // 4x8-pixel patches per tile, arranged (NP/2) x 2
@@ -126,7 +126,8 @@ struct Geo {
   // amortised over twice as many MFMAs per wave.  After each barrier the slots freed by the finished group are refilled by
   // DMA with the next slabs in K order.
   static constexpr int NWBUF = CW ? 18 : 4;
-  static constexpr int MAIN_BYTES = 2 * HALO_BYTES + NWBUF * W_LDS + AFF_BYTES;
+  static constexpr int NHB = SH ? 1 : 2;   // halo buffers (SH: one -- the configuration that fits two workgroups per CU)
+  static constexpr int MAIN_BYTES = NHB * HALO_BYTES + NWBUF * W_LDS + AFF_BYTES;
   // epilogue staging: one M-tile row of the block (WM * 32 pixels) x BN floats (+16 B pad per pixel)
   static constexpr int EP_PIX = WM * 32;
   static constexpr int EP_ROWB = BN * 4 + 16;
@@ -157,9 +158,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 // ~1e-5 per product instead of bf16's 4e-3 -- the f32-tolerance mode at 3x the bf16 MFMA work instead of the f32 MFMA's 16x).  A K
 // step is then 16 channels: LDS row = [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15], so the two "k-halves" of the pipeline below are
 // the hi and the lo fragments of the step.
-template <typename T, int WM, int WN, int MT, int NT, bool SKIP, bool CW = false, int MIXED = 0>
+template <typename T, int WM, int WN, int MT, int NT, bool SKIP, bool CW = false, int MIXED = 0, bool SH = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) {
-  using G = Geo<WM, WN, MT, NT, CW>;
+  using G = Geo<WM, WN, MT, NT, CW, SH>;
+  static_assert(!SH || (!CW && MIXED == 0), "single-halo configuration: plain storage, tap-pair ring");
   using TS = std::conditional_t<MIXED != 0, float, T>;   // storage type of activations / residual / output (T: MFMA operand type)
   constexpr bool SPLIT = MIXED == 2;
   static_assert(!MIXED || sizeof(T) == 2, "MIXED = f32 storage around bf16 MFMA operands");
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   constexpr int CK = SPLIT ? 16 : 4 * EPS;   // channels per K chunk (one 64-byte LDS row)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const hbuf = smem;
-  char* const wbuf = smem + 2 * G::HALO_BYTES;
+  char* const wbuf = smem + G::NHB * G::HALO_BYTES;
   char* const afftab = wbuf + G::NWBUF * G::W_LDS;
 
 #ifdef FD_TIMING2   // light phase timing (3 timestamps per wave, no waits added inside the loop)
@@ -238,13 +240,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(nsrd, off, 0, FD_HALO_AUX);
     if constexpr (MIXED) hreg_hi[i] = __builtin_amdgcn_raw_buffer_load_b128(nsrd, off + 16, 0, FD_HALO_AUX);
   };
-  auto store_halo_slot = [&](int i, int buf) {
+  // the LDS image of slot i, in place: silu(a*x+d) (or the storage -> operand conversion), zero padding AFTER the activation
+  auto convert_slot = [&](int i) {
     u32x4 v = hreg[i];
     if constexpr (MIXED) v = naff >= 0 ? wide_slot<true>(hreg[i], hreg_hi[i], afftab + naff, SPLIT && q >= 2) : wide_slot<false>(hreg[i], hreg_hi[i], afftab, SPLIT && q >= 2);
     else if (naff >= 0) v = transform_slot<T, EPS>(v, afftab + naff);
-    if (!(nchan_ok && ((pvalid >> i) & 1u))) v = u32x4{0u, 0u, 0u, 0u};  // zero padding AFTER the activation
-    if ((hexist >> i) & 1u) *reinterpret_cast<u32x4*>(hbuf + buf * G::HALO_BYTES + hlds[i]) = v;
+    if (!(nchan_ok && ((pvalid >> i) & 1u))) v = u32x4{0u, 0u, 0u, 0u};
+    hreg[i] = v;
   };
+  auto put_slot = [&](int i, int buf) {
+    if ((hexist >> i) & 1u) *reinterpret_cast<u32x4*>(hbuf + buf * G::HALO_BYTES + hlds[i]) = hreg[i];
+  };
+  auto store_halo_slot = [&](int i, int buf) { convert_slot(i); put_slot(i, buf); };
   // Weight slab of one step: BN rows x 80 B, contiguous in global memory with exactly the LDS image -> copied by
   // direct-to-LDS DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB per wave instruction, destination =
   // wave-uniform base + lane * 16).  No VGPR staging, no ds_write.
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     for (int j = wv; j < n * NPIECE; j += NW) {
       const int sl = first + j / NPIECE, pce = j % NPIECE;
       if (sl > last) break;
-      glds16(src0 + (size_t)sl * p.CoutPad * WROWB + pce * 1024, (unsigned)(2 * G::HALO_BYTES + (sl % G::NWBUF) * G::W_LDS + pce * 1024));
+      glds16(src0 + (size_t)sl * p.CoutPad * WROWB + pce * 1024, (unsigned)(G::NHB * G::HALO_BYTES + (sl % G::NWBUF) * G::W_LDS + pce * 1024));
     }
   };
   // ---- per-lane fragment coordinates ---------------------------------------------------------------------------
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // last piece over-reads into the next slab and lands in the padding of the 1-KiB-rounded LDS slot).  ONE wave-uniform pointer
   // walks the slabs in K order and the per-lane part of the address never changes, so a slab costs two scalar adds; the pointer
   // simply runs past the last slab (fd_conv_packed_bytes pads the buffer by NWBUF slabs: what lands is never read).
-  constexpr unsigned WOFF = 2 * G::HALO_BYTES;   // LDS byte offset of the ring
+  constexpr unsigned WOFF = G::NHB * G::HALO_BYTES;   // LDS byte offset of the ring
   const char* wfetch = reinterpret_cast<const char*>(p.w) + (size_t)n0 * WROWB;
   const size_t slab_stride = (size_t)p.CoutPad * WROWB;
   int dma_pce[G::DMA_PER_WAVE];        // the 1-KiB pieces of a slab this wave copies (wave-uniform)
@@ -558,7 +565,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       if (tap == 3 || tap == 5 || tap == 7) {
 #pragma unroll
         for (int k = 0; k < G::HPG; ++k)
-          if ((tap - 3) / 2 * G::HPG + k < G::HITER) store_halo_slot((tap - 3) / 2 * G::HPG + k, hcur ^ 1);
+          if ((tap - 3) / 2 * G::HPG + k < G::HITER) {
+            if constexpr (SH) convert_slot((tap - 3) / 2 * G::HPG + k);   // single halo buffer: kept in registers until it is free
+            else store_halo_slot((tap - 3) / 2 * G::HPG + k, hcur ^ 1);
+          }
       }
       if constexpr (SPLIT) { read_p(pfB, hb, imm, 1); mma_pair(wfA, wfB, pfA); }
       else { read_frags(wfB, pfB, hb, wb, imm, 1); mma_all(wfA, pfA); }
@@ -569,6 +579,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         // the slabs of steps s + 3 (and s + 4): steps 0..3 were fetched by the prologue, every barrier moves on by its group size
         if (tap == 8) fetch_to(wso[0]);
         else { fetch_to(wso[(tap + 3) & 3]); fetch_to(wso[(tap + 4) & 3]); }
+        if constexpr (SH) {
+          if (tap == 8) {   // every wave has read its last fragment of this chunk (block_sync drains the LDS reads): the buffer is free
+#pragma unroll
+            for (int k = 0; k < G::HITER; ++k) put_slot(k, 0);
+          }
+        }
       }
       // ---- phase B: [load halo slot] | read frags(s+1, ks=0) || MFMA(s, ks=1)
 #ifdef FD_EXP_NOHALO
@@ -586,6 +602,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         read_w(wfB, wbn, 1);
         mma_all(wfA, pfB);
         take_next();
+      } else if constexpr (SH) {
+        if (tap < 8) read_frags(wfA, pfA, hb, wbn, imm_next, 0);
+        mma_all(wfB, pfB);
+        if (tap == 8) {   // the next halo is published; its first fragments are read behind the barrier (one exposed LDS round trip per chunk)
+          lds_barrier();
+          read_frags(wfA, pfA, hb, wbn, first_off_next, 0);
+        }
       } else {
         if (tap < 8) read_frags(wfA, pfA, hb, wbn, imm_next, 0);
         else read_frags(wfA, pfA, hbn, wbn, first_off_next, 0);
@@ -593,7 +616,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       }
       ++step;
     }
-    hcur ^= 1;
+    if constexpr (!SH) hcur ^= 1;
   }
   for (int i = 0; i < n1; ++i) {
     const bool m1 = step + 1 < nsteps;
@@ -609,10 +632,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     if constexpr (SPLIT) { read_p(pfB, hb, CENTER, 1); mma_pair(wfA, wfB, pfA); }
     else { read_frags(wfB, pfB, hb, wb, CENTER, 1); mma_all(wfA, pfA); }
 #pragma unroll
-    for (int k = 0; k < G::HITER; ++k) store_halo_slot(k, hcur ^ 1);
+    for (int k = 0; k < G::HITER; ++k) { if constexpr (SH) convert_slot(k); else store_halo_slot(k, hcur ^ 1); }
     block_sync();
     if constexpr (!CW) fetch_to(WOFF + (step & 3) * G::W_LDS);   // slab of step + 4 into the slot this step has just finished with
                                                                    // (CW: all shortcut slabs are already in the ring -- the launcher guarantees n1 <= NWBUF)
+    if constexpr (SH) {   // the single buffer is free now: publish the next chunk's pixels, then read its fragments behind a barrier
+#pragma unroll
+      for (int k = 0; k < G::HITER; ++k) put_slot(k, 0);
+      mma_all(wfB, pfB);
+      lds_barrier();
+      read_frags(wfA, pfA, hb, wbn, CENTER, 0);
+      ++step;
+      continue;
+    }
     if constexpr (SPLIT) {
       read_w(wfC, wbn, 0);
       read_p(pfA, hbn, CENTER, 0);
@@ -880,26 +912,26 @@ inline int n_steps(int C0, int C1, int taps, int CK) { return (fd_cdiv(C0, CK) +
 unsigned long long* g_dbg = nullptr;  // instrumented builds only: device buffer of 8 counters per workgroup (fd_debug_buffer)
 #endif
 
-template <typename T, int WM, int WN, int MT, int NT, bool CW = false, int MIXED = 0>
+template <typename T, int WM, int WN, int MT, int NT, bool CW = false, int MIXED = 0, bool SH = false>
 int set_attr() {
-  using G = Geo<WM, WN, MT, NT, CW>;
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, WM, WN, MT, NT, false, CW, MIXED>),
+  using G = Geo<WM, WN, MT, NT, CW, SH>;
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, WM, WN, MT, NT, false, CW, MIXED, SH>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, WM, WN, MT, NT, true, CW, MIXED>),
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, WM, WN, MT, NT, true, CW, MIXED, SH>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
   return FD_OK;
 }
 
-template <typename T, int WM, int WN, int MT, int NT, bool CW = false, int MIXED = 0>
+template <typename T, int WM, int WN, int MT, int NT, bool CW = false, int MIXED = 0, bool SH = false>
 int launch_conv(ConvArgs a, hipStream_t st) {
-  using G = Geo<WM, WN, MT, NT, CW>;
+  using G = Geo<WM, WN, MT, NT, CW, SH>;
   a.tiles_h = fd_cdiv(a.H, G::TH);
   a.tiles_w = fd_cdiv(a.W, G::TW);
   a.tiles_n = fd_cdiv(a.Cout, G::BN);
   const long long nblk = (long long)a.B * a.tiles_h * a.tiles_w * a.tiles_n;
   FD_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
-  if (a.skip) hipLaunchKernelGGL((conv_mfma_kernel<T, WM, WN, MT, NT, true, CW, MIXED>), dim3((unsigned)nblk), dim3(G::NTH), G::LDS_BYTES, st, a);
-  else hipLaunchKernelGGL((conv_mfma_kernel<T, WM, WN, MT, NT, false, CW, MIXED>), dim3((unsigned)nblk), dim3(G::NTH), G::LDS_BYTES, st, a);
+  if (a.skip) hipLaunchKernelGGL((conv_mfma_kernel<T, WM, WN, MT, NT, true, CW, MIXED, SH>), dim3((unsigned)nblk), dim3(G::NTH), G::LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((conv_mfma_kernel<T, WM, WN, MT, NT, false, CW, MIXED, SH>), dim3((unsigned)nblk), dim3(G::NTH), G::LDS_BYTES, st, a);
   FD_LAUNCH_CHECK();
   return FD_OK;
 }
@@ -909,8 +941,9 @@ int launch_conv(ConvArgs a, hipStream_t st) {
 template <typename T>
 int dispatch_conv(const ConvArgs& a, hipStream_t st, int bn_hint, bool chunk_ring) {
   int bn = a.Cout <= 32 ? 32 : (a.Cout <= 128 ? 128 : 256);
-  if (bn_hint > 0 && bn_hint < bn) bn = bn_hint;
+  if (bn_hint > 0 && bn_hint < bn) bn = bn_hint;   // (bn_hint < 0: FD_TILE_DUO128, below)
   if constexpr (sizeof(T) == 2) {
+    if (bn_hint == -128 && a.Cout % 128 == 0) return launch_conv<T, 2, 2, 4, 2, false, 0, true>(a, st);   // FD_TILE_DUO128
     if (chunk_ring && bn <= 64) {   // low-latency configurations: bf16, at most 18 folded-shortcut (or 1x1) steps
       int n1 = 0;
       for (int s = 0; s < a.nseg; ++s) if (a.seg[s].taps == 1) n1 += fd_cdiv(a.seg[s].C, 32);
@@ -947,7 +980,7 @@ int fd_conv_init_attributes() {
   std::lock_guard<std::mutex> lock(mu);
   const bool known = dev >= 0 && dev < 64;
   if (known && done_dev[dev]) return FD_OK;
-  FD_TRY((set_attr<bf16, 4, 1, 2, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 1, true>())); FD_TRY((set_attr<bf16, 4, 1, 2, 1, true>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2>()));
+  FD_TRY((set_attr<bf16, 4, 1, 2, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 1, true>())); FD_TRY((set_attr<bf16, 4, 1, 2, 1, true>())); FD_TRY((set_attr<bf16, 2, 2, 4, 2, false, 0, true>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2>()));
   FD_TRY((set_attr<float, 4, 1, 2, 1>())); FD_TRY((set_attr<float, 4, 2, 2, 1>())); FD_TRY((set_attr<float, 4, 2, 2, 2>())); FD_TRY((set_attr<float, 2, 4, 4, 2>()));
   FD_TRY((set_attr<bf16, 4, 1, 2, 1, false, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2, false, 1>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2, false, 1>()));
   FD_TRY((set_attr<bf16, 4, 1, 2, 1, false, 2>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2, false, 2>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2, false, 2>()));
@@ -1015,8 +1048,8 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   FD_REQUIRE(!(mixed || split) || dtype == (FD_F32 | FD_BF16_OPERANDS) || dtype == (FD_F32 | FD_BF16X3_OPERANDS),
              "fd_conv2d: FD_BF16_OPERANDS / FD_BF16X3_OPERANDS go with FD_F32 storage and the default direct configuration only");
   const int tile = dtype & FD_TILE_MASK;
-  const int bn_hint = (tile == FD_TILE_BN32 || tile == FD_TILE_BN32_CHUNK) ? 32 : (tile == FD_TILE_BN64 || tile == FD_TILE_BN64_CHUNK) ? 64 : tile == FD_TILE_BN128 ? 128 : 0;
-  FD_REQUIRE(tile == 0 || bn_hint > 0, "fd_conv2d: bad FD_TILE_* flag");
+  const int bn_hint = tile == FD_TILE_DUO128 ? -128 : (tile == FD_TILE_BN32 || tile == FD_TILE_BN32_CHUNK) ? 32 : (tile == FD_TILE_BN64 || tile == FD_TILE_BN64_CHUNK) ? 64 : tile == FD_TILE_BN128 ? 128 : 0;
+  FD_REQUIRE(tile == 0 || bn_hint != 0, "fd_conv2d: bad FD_TILE_* flag");
   dtype &= 0xff;
   FD_REQUIRE(!wino || (dtype == FD_BF16 && fd_wino_supported(Cout, C0, C1, S0, S1, ksize)),
              "fd_conv2d: FD_WINOGRAD needs bf16 storage, ksize 3, Cout %% 128 == 0 and channel counts %% 32 == 0");

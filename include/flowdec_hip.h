@@ -63,6 +63,7 @@ extern "C" {
 #define FD_TILE_BN64_CHUNK 0x4000 /* 64 + the weight slabs of two whole 32-channel chunks resident in LDS: one barrier and one memory
                                      round trip per chunk instead of per tap pair (bf16; falls back to FD_TILE_BN64 otherwise) */
 #define FD_TILE_BN32_CHUNK 0x5000 /* same with 32-channel workgroups (4 waves) */
+#define FD_TILE_DUO128 0x6000 /* 4 waves x (128 px x 64 cout) with ONE halo buffer: 70 KiB of LDS, two workgroups per CU (bf16, Cout % 128 == 0) */
 #define FD_TILE_MASK 0xf000
 /* fd_model_config.act_dtype only: low-latency schedule for ONE short clip -- both packings are kept (as with FD_WINOGRAD_AUTO) and
  * every convolution picks kernel and workgroup width by its IMAGE size (never by the batch size): FD_TILE_BN32_CHUNK for images of

@@ -27,7 +27,7 @@ SHAPES = [  # name, H, W, C0, C1, Cout, skip, S
 def main(B=1, iters=50, rounds=3, scale_w=1):
     g = torch.Generator(device="cuda").manual_seed(1)
     print(f"B = {B}; per-launch microseconds (min over {rounds} rounds of {iters} back-to-back launches)")
-    print(f"{'shape':22s} {'bn256':>8s} {'bn128':>8s} {'bn64':>8s} {'bn64c':>8s} {'bn32':>8s} {'bn32c':>8s} {'wino':>8s}")
+    print(f"{'shape':22s} {'bn256':>8s} {'duo':>8s} {'bn128':>8s} {'bn64':>8s} {'bn64c':>8s} {'bn32':>8s} {'bn32c':>8s} {'wino':>8s}")
     for name, H, W, C0, C1, Cout, skip, S in SHAPES:
         W *= scale_w
         Cin = C0 + C1
@@ -45,7 +45,7 @@ def main(B=1, iters=50, rounds=3, scale_w=1):
         from flowdec_amd import _lib as L
         lib = L.load()
         fs, outs = {}, {}
-        for key in (256, 128, 64, "64c", 32, "32c", "wino"):
+        for key in (256, "duo", 128, 64, "64c", 32, "32c", "wino"):
             wino = key == "wino"
             if not wino and not isinstance(key, str) and key > Cout:
                 continue
@@ -88,7 +88,7 @@ def main(B=1, iters=50, rounds=3, scale_w=1):
                 e1.record()
                 torch.cuda.synchronize()
                 best[k] = min(best[k], e0.elapsed_time(e1) / iters * 1e3)
-        print(f"{name:22s} " + " ".join(f"{best[k]:8.1f}" if k in best else f"{'-':>8s}" for k in (256, 128, 64, "64c", 32, "32c", "wino")), flush=True)
+        print(f"{name:22s} " + " ".join(f"{best[k]:8.1f}" if k in best else f"{'-':>8s}" for k in (256, "duo", 128, 64, "64c", 32, "32c", "wino")), flush=True)
 
 
 if __name__ == "__main__":

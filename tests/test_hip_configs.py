@@ -329,7 +329,7 @@ def test_conv2d_tile_widths(case):
     run = lambda bn: ops.conv2d(x0, pw, Cout, k, x1=x1, affine=aff, bias=bias, skip=sk, scale=0.7071, sc0=sc0, sc1=sc1, want_stats=True, tile_bn=bn)
     ref, ref_st = run(0)
     assert torch.isfinite(ref.float()).all()
-    for bn in (128, 64, 32, "64c", "32c"):
+    for bn in (128, 64, 32, "64c", "32c", "duo"):
         out, st = run(bn)
         assert torch.equal(out, ref), (name, bn)
         assert torch.allclose(st[:, :, :Cout], ref_st[:, :, :Cout], rtol=1e-4, atol=1e-3), (name, bn)
