@@ -23,6 +23,15 @@
 //   * epilogue: accumulators are transposed through LDS so that global traffic (skip read, output write) is
 //     16 B per lane and fully coalesced; bias / skip / scale are applied there, and per-channel sum / sum of
 //     squares of the f32 result are reduced per tile for the consumer GroupNorm (deterministic, no atomics).
+//
+// One kernel template, several configurations (all of them run the same K order per output, so the convolution result is the same
+// bits whatever the workgroup shape; DESIGN.md section 4 has the measurements behind each):
+//   <WM, WN, MT, NT>  wave grid and MFMA tiles per wave: 8 waves x (128 px x 64 cout) = BN 256 by default, narrower ones for few output
+//                     channels and for small grids (FD_TILE_*);
+//   CW                chunk-resident weight ring + fragments two phases ahead, one barrier per chunk (the low-latency configurations);
+//   MIXED = 1 / 2     f32 storage around bf16 operands: rounded once at the LDS store (FD_BF16_OPERANDS), or split as hi + lo with three
+//                     MFMAs per product (FD_BF16X3_OPERANDS: the f32-tolerance mode on the bf16 matrix cores);
+//   SH                one halo buffer instead of two: 70 KiB of LDS, two workgroups per CU (FD_TILE_DUO128; measured, not scheduled).
 #include <string.h>
 
 #include <mutex>
