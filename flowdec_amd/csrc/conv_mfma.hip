@@ -705,6 +705,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   float ssum[8], ssq[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) ssum[j] = ssq[j] = 0.f;
+  const bool interior = h0 + G::TH <= H && w0 + G::TW <= W && n0 + G::BN <= p.Cout;   // workgroup-uniform
 
 #ifdef FD_TIMING2
   unsigned long long t2_e1 = 0, t2_e2 = 0, t2_e3 = 0;
@@ -757,61 +758,77 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     // stores (hipcc puts a vmcnt(0) in front of the first use of a residual value) would drain the previous store at full
     // memory latency.  For the same reason the residual input is a compile-time property of the kernel (SKIP): launches
     // without it have no load, hence no wait, anywhere in the epilogue.
-    u32x4 packed[G::NPASS][sizeof(TS) == 2 ? 1 : 2];
+    // The sweep is VALU-bound (~1450 vector instructions per wave and tile, of which a third were the edge handling): tiles that lie
+    // inside the image with a full set of output channels -- all but the last row / column of tiles -- take a path without the
+    // per-pixel validity factor, the channel-count selects and the predicated stores.
+    auto sweep = [&](auto fast_tag) {
+      constexpr bool FAST = decltype(fast_tag)::value;
+      u32x4 packed[G::NPASS][sizeof(TS) == 2 ? 1 : 2];
 #pragma unroll
-    for (int ps = 0; ps < G::NPASS; ++ps) {
-      const int pp = prow_e + ps * G::PPASS;
-      const float* sp = reinterpret_cast<const float*>(stage + pp * G::EP_ROWB) + oct * 8;
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
-      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      if constexpr (SKIP) {
-        if constexpr (sizeof(TS) == 2) {
-          const bf16x8 sk = __builtin_bit_cast(bf16x8, skraw[ps][0]);   // (the upper 4 lanes are zero in the 4-channel case)
+      for (int ps = 0; ps < G::NPASS; ++ps) {
+        const int pp = prow_e + ps * G::PPASS;
+        const float* sp = reinterpret_cast<const float*>(stage + pp * G::EP_ROWB) + oct * 8;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if constexpr (SKIP) {
+          if constexpr (sizeof(TS) == 2) {
+            const bf16x8 sk = __builtin_bit_cast(bf16x8, skraw[ps][0]);   // (the upper 4 lanes are zero in the 4-channel case)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += (float)sk[j];
-        } else {
-          const f32x4 s0 = __builtin_bit_cast(f32x4, skraw[ps][0]);
+            for (int j = 0; j < 8; ++j) v[j] += (float)sk[j];
+          } else {
+            const f32x4 s0 = __builtin_bit_cast(f32x4, skraw[ps][0]);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += s0[j];
-          if (n_cnt == 8) {
-            const f32x4 s1 = __builtin_bit_cast(f32x4, skraw[ps][1]);
+            for (int j = 0; j < 4; ++j) v[j] += s0[j];
+            if (FAST || n_cnt == 8) {
+              const f32x4 s1 = __builtin_bit_cast(f32x4, skraw[ps][1]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[4 + j] += s1[j];
+              for (int j = 0; j < 4; ++j) v[4 + j] += s1[j];
+            }
           }
         }
-      }
-      const float keep = ovalid[ps] ? 1.f : 0.f;   // pixels outside the image do not enter the statistics
+        if constexpr (FAST) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        v[j] = (v[j] + bv[j]) * p.scale;
-        const float w = j < n_cnt ? v[j] * keep : 0.f;
-        ssum[j] += w; ssq[j] = fmaf(w, w, ssq[j]);
-      }
-      if constexpr (sizeof(TS) == 2) {
-        bf16x8 tv;
+          for (int j = 0; j < 8; ++j) {
+            v[j] = (v[j] + bv[j]) * p.scale;
+            ssum[j] += v[j]; ssq[j] = fmaf(v[j], v[j], ssq[j]);
+          }
+        } else {
+          const float keep = ovalid[ps] ? 1.f : 0.f;   // pixels outside the image do not enter the statistics
 #pragma unroll
-        for (int j = 0; j < 8; ++j) tv[j] = (bf16)v[j];
-        packed[ps][0] = __builtin_bit_cast(u32x4, tv);
-      } else {
-        packed[ps][0] = __builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]});
-        packed[ps][1] = __builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]});
-      }
-    }
+          for (int j = 0; j < 8; ++j) {
+            v[j] = (v[j] + bv[j]) * p.scale;
+            const float w = j < n_cnt ? v[j] * keep : 0.f;
+            ssum[j] += w; ssq[j] = fmaf(w, w, ssq[j]);
+          }
+        }
+        if constexpr (sizeof(TS) == 2) {
+          bf16x8 tv;
 #pragma unroll
-    for (int ps = 0; ps < G::NPASS; ++ps) {
-      if (!ovalid[ps]) continue;
-      TS* op = out + oaddr[ps];
+          for (int j = 0; j < 8; ++j) tv[j] = (bf16)v[j];
+          packed[ps][0] = __builtin_bit_cast(u32x4, tv);
+        } else {
+          packed[ps][0] = __builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]});
+          packed[ps][1] = __builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]});
+        }
+      }
+#pragma unroll
+      for (int ps = 0; ps < G::NPASS; ++ps) {
+        if (!FAST && !ovalid[ps]) continue;
+        TS* op = out + oaddr[ps];
 #ifdef FD_EXP_NOSTORE
-      if (packed[ps][0][0] == 0x12345678u)
+        if (packed[ps][0][0] == 0x12345678u)
 #endif
-      if (n_cnt == 8) {
-        *reinterpret_cast<u32x4*>(op) = packed[ps][0];
-        if constexpr (sizeof(TS) == 4) *(reinterpret_cast<u32x4*>(op) + 1) = packed[ps][1];
-      } else {   // 4 valid channels (pyramid heads: Cout = 4)
-        if constexpr (sizeof(TS) == 2) *reinterpret_cast<uint2*>(op) = uint2{packed[ps][0][0], packed[ps][0][1]};
-        else *reinterpret_cast<u32x4*>(op) = packed[ps][0];
+        if (FAST || n_cnt == 8) {
+          *reinterpret_cast<u32x4*>(op) = packed[ps][0];
+          if constexpr (sizeof(TS) == 4) *(reinterpret_cast<u32x4*>(op) + 1) = packed[ps][1];
+        } else {   // 4 valid channels (pyramid heads: Cout = 4)
+          if constexpr (sizeof(TS) == 2) *reinterpret_cast<uint2*>(op) = uint2{packed[ps][0][0], packed[ps][0][1]};
+          else *reinterpret_cast<u32x4*>(op) = packed[ps][0];
+        }
       }
-    }
+    };
+    if (interior) sweep(std::true_type{});
+    else sweep(std::false_type{});
 #ifdef FD_TIMING2
     if (mi == 0) t2_e2 = __builtin_amdgcn_s_memtime();
     if (mi == MT - 1) t2_e3 = __builtin_amdgcn_s_memtime();
