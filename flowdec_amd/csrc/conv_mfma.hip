@@ -789,6 +789,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         if constexpr (FAST) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
+            // the statistics take the ROUNDED product, as the edge path below does (there the validity factor stands between the
+            // multiply and the add): without this hipcc contracts (v + b) * scale + sum into an fma of the unrounded product
+#pragma clang fp contract(off)
             v[j] = (v[j] + bv[j]) * p.scale;
             ssum[j] += v[j]; ssq[j] = fmaf(v[j], v[j], ssq[j]);
           }
