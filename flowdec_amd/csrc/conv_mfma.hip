@@ -42,6 +42,7 @@
 namespace {
 
 using namespace fdconv;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <typename T>
 struct Math;
@@ -787,13 +788,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
           }
         }
         if constexpr (FAST) {
+          // two channels per instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: the same IEEE operations, half the issue slots).
+          // The statistics take the ROUNDED product, as the edge path below does (there the validity factor stands between the
+          // multiply and the add): without contract(off) hipcc fuses (v + b) * scale + sum into an fma of the unrounded product.
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            // the statistics take the ROUNDED product, as the edge path below does (there the validity factor stands between the
-            // multiply and the add): without this hipcc contracts (v + b) * scale + sum into an fma of the unrounded product
+          for (int k = 0; k < 4; ++k) {
 #pragma clang fp contract(off)
-            v[j] = (v[j] + bv[j]) * p.scale;
-            ssum[j] += v[j]; ssq[j] = fmaf(v[j], v[j], ssq[j]);
+            f32x2 x = {v[2 * k], v[2 * k + 1]};
+            const f32x2 b2 = {bv[2 * k], bv[2 * k + 1]}, sc2 = {p.scale, p.scale};
+            f32x2 s1 = {ssum[2 * k], ssum[2 * k + 1]}, s2 = {ssq[2 * k], ssq[2 * k + 1]};
+            x = (x + b2) * sc2;
+            s1 += x;
+            s2 = __builtin_elementwise_fma(x, x, s2);
+            v[2 * k] = x[0]; v[2 * k + 1] = x[1];
+            ssum[2 * k] = s1[0]; ssum[2 * k + 1] = s1[1];
+            ssq[2 * k] = s2[0]; ssq[2 * k + 1] = s2[1];
           }
         } else {
           const float keep = ovalid[ps] ? 1.f : 0.f;   // pixels outside the image do not enter the statistics
