@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--stats", type=int, default=1)
+    ap.add_argument("--operands", default="", choices=["", "mixed", "x3"], help="with --dtype fp32: bf16 / split-bf16 MFMA operands")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -44,12 +45,13 @@ def main():
         x0 = torch.randn(B, H, W, C0, device="cuda", generator=g).to(dt)
         x1 = torch.randn(B, H, W, C1, device="cuda", generator=g).to(dt) if C1 else None
         w = torch.randn(Cout, C0 + C1, k, k, device="cuda", generator=g) / ((C0 + C1) * k * k) ** 0.5
-        pw = ops.pack_conv_weight(w, C0=C0, dtype=dt)
+        opnd = {"": False, "mixed": True, "x3": "x3"}[a.operands]
+        pw = ops.pack_conv_weight(w, C0=C0, dtype=dt, bf16_operands=opnd)
         affine = torch.stack([1 + 0.1 * torch.randn(B, C0 + C1, device="cuda", generator=g),
                               0.1 * torch.randn(B, C0 + C1, device="cuda", generator=g)], -1).contiguous() if aff else None
         bias = torch.randn(Cout, device="cuda", generator=g)
         sk = torch.randn(B, H, W, Cout, device="cuda", generator=g).to(dt) if skip else None
-        f = lambda: ops.conv2d(x0, pw, Cout, k, x1=x1, affine=affine, bias=bias, skip=sk, scale=0.7071, want_stats=bool(a.stats) and Cout > 4)
+        f = lambda: ops.conv2d(x0, pw, Cout, k, x1=x1, affine=affine, bias=bias, skip=sk, scale=0.7071, want_stats=bool(a.stats) and Cout > 4, bf16_operands=opnd)
         f(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
