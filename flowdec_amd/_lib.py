@@ -18,6 +18,8 @@ FD_WINOGRAD_LOWRES = 0x200
 FD_WINOGRAD_AUTO = 0x400
 FD_LOW_LATENCY = 0x800
 FD_BF16_OPERANDS = 0x10000  # with FD_F32: f32 storage, bf16 MFMA operands (precision='mixed')
+FD_NO_SIDE_STREAM = 0x40000  # fd_model_config.act_dtype: side branches stay on the caller's stream
+FD_EBUSY = -5
 FD_BF16X3_OPERANDS = 0x20000  # with FD_F32: operands as hi + lo bf16 pairs, three bf16 MFMAs per product (precision='bf16x3')
 FD_TILE = {0: 0, 32: 0x1000, 64: 0x2000, 128: 0x3000, "64c": 0x4000, "32c": 0x5000, "duo": 0x6000}  # fd_conv2d: output channels per workgroup (0 = default)
 SOLVERS = {"euler": 0, "midpoint": 1, "heun2": 2, "heun2_eulerlast": 3}

@@ -326,9 +326,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   auto block_sync = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifndef FD_EXP_NOBARRIER
     __builtin_amdgcn_s_barrier();
-#endif
     asm volatile("" ::: "memory");
   };
   // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence as well: it waits for vmcnt(0), i.e. for
@@ -503,19 +501,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #pragma unroll
       for (int ph = 0; ph < 18; ++ph) {
         const int tap = ph >> 1;
-#ifdef FD_EXP_CW_NOHALO   // experiments (timing only, wrong results): no halo traffic at all / no activation
-        if (false)
-#endif
         if (ph == 2) {
 #pragma unroll
           for (int k = 0; k < G::HITER; ++k) load_halo_slot(k);
         }
-#ifdef FD_EXP_CW_NOACT
-        naff = -1;
-#endif
-#ifdef FD_EXP_CW_NOHALO
-        if (false)
-#endif
         if ((ph & 1) == 0 && tap >= 4 && tap <= 6) {
 #pragma unroll
           for (int k = 0; k < G::HPG; ++k)
@@ -568,10 +557,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       // YOUNGEST vector-memory instruction at every wait point about two taps old: all halo loads are issued together
       // with the weight DMAs right after barrier 1 and converted / stored one group of slots at a time in the phases
       // that end with barriers 3, 5 and 7 (published long before the first read in phase B of tap 8).
-#ifdef FD_EXP_NOHALO
-      if (false) {}
-      else
-#endif
       if (tap == 3 || tap == 5 || tap == 7) {
 #pragma unroll
         for (int k = 0; k < G::HPG; ++k)
@@ -597,10 +582,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         }
       }
       // ---- phase B: [load halo slot] | read frags(s+1, ks=0) || MFMA(s, ks=1)
-#ifdef FD_EXP_NOHALO
-      if (false) {}
-      else
-#endif
       if (tap == 1) {
 #pragma unroll
         for (int k = 0; k < G::HITER; ++k) load_halo_slot(k);
@@ -672,19 +653,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 
 #ifdef FD_TIMING2
   const unsigned long long t2_loop = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef FD_EXP_NOEPI   // experiment: bound what a free epilogue would give (keeps the accumulators alive)
-  {
-    float sacc = 0.f;
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-      for (int nj = 0; nj < NT; ++nj)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc += acc[mi][nj][r];
-    if (sacc == 1234.567f) reinterpret_cast<float*>(p.out)[t] = sacc;
-    return;
-  }
 #endif
   // ---- epilogue ------------------------------------------------------------------------------------------------------
   // MT rounds; in round mi every wave stages its acc[mi][*] (32 pixels x NT*32 couts, f32) to LDS as
@@ -827,9 +795,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       for (int ps = 0; ps < G::NPASS; ++ps) {
         if (!FAST && !ovalid[ps]) continue;
         TS* op = out + oaddr[ps];
-#ifdef FD_EXP_NOSTORE
-        if (packed[ps][0][0] == 0x12345678u)
-#endif
         if (FAST || n_cnt == 8) {
           *reinterpret_cast<u32x4*>(op) = packed[ps][0];
           if constexpr (sizeof(TS) == 4) *(reinterpret_cast<u32x4*>(op) + 1) = packed[ps][1];

@@ -241,8 +241,9 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino_kernel(ConvArgs p) {
     if constexpr (A) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(afftab + naff + 16 * j);
       r = pack_f16(fd_silu(fmaf(x0, a[0], a[1])), fd_silu(fmaf(x1, a[2], a[3])));
-    } else {   // raw input (activated / resampled upstream, or the shortcut input): clamp to the fp16 range
-      r = pack_f16(__builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f));
+    } else {   // raw input (activated / resampled upstream, or the shortcut input): saturate at HALF the fp16 range, so that the
+               // transform z[a] +- z[b] (packed fp16) cannot overflow to inf either.  Dynamic-range contract: DESIGN.md section 5.
+      r = pack_f16(__builtin_amdgcn_fmed3f(x0, -32752.f, 32752.f), __builtin_amdgcn_fmed3f(x1, -32752.f, 32752.f));
     }
     // zero padding AFTER the activation -- as an AND: a select around the SiLU becomes a divergent branch per word, and a branch
     // ends the basic block the MFMA interleave works in
@@ -633,7 +634,10 @@ inline long long wino_steps(int C0, int C1, int spc) { return (long long)(fd_cdi
 }  // namespace
 
 bool fd_wino_supported(int Cout, int C0, int C1, int S0, int S1, int ksize) {
-  return ksize == 3 && Cout > 0 && Cout % BN == 0 && C0 > 0 && C0 % CK == 0 && C1 % CK == 0 && S0 % CK == 0 && S1 % CK == 0;
+  // Cout: multiples of 128 whose padded width equals the direct kernel's statistics stride (fd_conv_cout_pad: 128, then multiples of
+  // 256) -- the per-tile GroupNorm partials of both kernels share one layout [B][tiles][fd_conv_cout_pad(Cout)][2]
+  return ksize == 3 && Cout > 0 && Cout % BN == 0 && pad_to(Cout, BN) == fd_conv_cout_pad(Cout) && C0 > 0 && C0 % CK == 0 && C1 % CK == 0 &&
+         S0 % CK == 0 && S1 % CK == 0;
 }
 
 long long fd_wino_packed_bytes(int Cout, int C0, int C1, int S0, int S1) {

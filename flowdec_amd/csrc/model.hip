@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <set>
 #include <string>
@@ -140,7 +141,24 @@ struct fd_model {
   size_t ev_fir_used = 0;
   double prof_fir_bytes = 0.0;
   static constexpr int MAX_NT = 256;
+  // One enqueueing call at a time per model: the entry points below share the model's scratch (time-embedding biases, graph cache,
+  // side stream, profiling events).  A second thread entering while one is inside gets FD_EBUSY instead of corrupting that state;
+  // callers that want concurrency create one fd_model per thread (weights are ~50 MB).  The reference's own native ops are
+  // stateless and re-entrant (upfirdn2d_kernel.cu:224-231) -- so are fd_upfirdn2d / fd_conv2d / the other operator-level calls.
+  std::atomic_flag busy = ATOMIC_FLAG_INIT;
 };
+
+namespace {
+struct BusyGuard {
+  fd_model* m; bool ok;
+  explicit BusyGuard(fd_model* mm) : m(mm), ok(mm && !mm->busy.test_and_set(std::memory_order_acquire)) {}
+  ~BusyGuard() { if (ok) m->busy.clear(std::memory_order_release); }
+};
+}  // namespace
+#define FD_MODEL_ENTER(m, fn)                                                                                                   \
+  FD_REQUIRE(m, fn ": null model");                                                                                             \
+  BusyGuard fd_busy_guard_(m);                                                                                                  \
+  if (!fd_busy_guard_.ok) return fd_set_error(FD_EBUSY, fn ": the model is serving a call of another thread (one enqueueing call at a time per fd_model)")
 
 namespace {
 
@@ -329,7 +347,9 @@ struct Fwd {
     const bool autosel = m && (m->cfg.act_dtype & FD_WINOGRAD_AUTO) && dt == FD_BF16;
     if (latency && px_tiles <= 24 && out.C >= 64) tile = FD_TILE_BN32_CHUNK;
     else if (autosel && px_tiles <= 16 && out.C >= 64) tile = FD_TILE_BN64_CHUNK;   // the 96 x 32 level: 18.5 us vs 22.6 (Winograd) at 8 clips, 17.1 vs 21.9 at one
-    else if (w_wino && (auto_wino(out) || (latency && px_tiles <= 512 && !s0))) { w = w_wino; wino = true; }
+    // (never with a folded 1x1 shortcut: its input is the UN-NORMALISED residual stream, which the Winograd kernel would narrow to
+    // the fp16 range; GroupNorm+SiLU outputs and their FIR-resampled versions are bounded)
+    else if (w_wino && !s0 && (auto_wino(out) || (latency && px_tiles <= 512))) { w = w_wino; wino = true; }
     if (want_stats) {
       out.tiles = fd_conv_stats_tiles(out.H, out.W);
       out.stride = fd_conv_cout_pad(out.C);
@@ -717,10 +737,19 @@ extern "C" int fd_model_create(const fd_model_config* cfg, fd_model** out) {
   FD_REQUIRE(cfg && out, "fd_model_create: null pointer");
   FD_REQUIRE(cfg->nf >= 8 && cfg->nf % 8 == 0 && cfg->nf <= 64, "fd_model_create: nf must be a multiple of 8 in [8, 64] (got %d)", cfg->nf);
   FD_REQUIRE(cfg->num_levels >= 1 && cfg->num_levels <= 8 && cfg->num_res_blocks >= 1, "fd_model_create: bad level / block counts");
-  FD_REQUIRE(((cfg->act_dtype & 0xff) == FD_BF16 && !(cfg->act_dtype & (FD_BF16_OPERANDS | FD_BF16X3_OPERANDS))) || cfg->act_dtype == FD_F32 ||
-                 cfg->act_dtype == (FD_F32 | FD_BF16_OPERANDS) || cfg->act_dtype == (FD_F32 | FD_BF16X3_OPERANDS),
+  const int act_nos = cfg->act_dtype & ~FD_NO_SIDE_STREAM;
+  FD_REQUIRE(((act_nos & 0xff) == FD_BF16 && !(act_nos & (FD_BF16_OPERANDS | FD_BF16X3_OPERANDS))) || act_nos == FD_F32 ||
+                 act_nos == (FD_F32 | FD_BF16_OPERANDS) || act_nos == (FD_F32 | FD_BF16X3_OPERANDS),
              "fd_model_create: act_dtype must be FD_BF16 [| FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY], FD_F32, "
              "FD_F32 | FD_BF16_OPERANDS or FD_F32 | FD_BF16X3_OPERANDS");
+  {
+    const int algo = cfg->act_dtype & (FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY);
+    FD_REQUIRE((algo & (algo - 1)) == 0, "fd_model_create: at most one of FD_WINOGRAD / FD_WINOGRAD_LOWRES / FD_WINOGRAD_AUTO / FD_LOW_LATENCY (got 0x%x)", algo);
+    FD_REQUIRE(algo == 0 || (cfg->act_dtype & 0xff) == FD_BF16, "fd_model_create: the convolution-algorithm flags go with FD_BF16 storage");
+    FD_REQUIRE((cfg->act_dtype & FD_TILE_MASK) == 0, "fd_model_create: FD_TILE_* selects the workgroup width of ONE fd_conv2d launch, not of a model");
+    FD_REQUIRE((cfg->act_dtype & ~(0xff | FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY | FD_BF16_OPERANDS | FD_BF16X3_OPERANDS |
+                                  FD_NO_SIDE_STREAM)) == 0, "fd_model_create: unknown bits in act_dtype (0x%x)", cfg->act_dtype);
+  }
   FD_REQUIRE(cfg->n_fft > 0 && cfg->n_fft % 2 == 0 && cfg->hop > 0, "fd_model_create: bad STFT geometry");
   for (int i = 0; i < cfg->num_levels; ++i) {
     const int ch = cfg->nf * cfg->ch_mult[i];
@@ -889,13 +918,10 @@ extern "C" int fd_model_finalize(fd_model* m, void* stream) {
   m->dev_allocs.push_back(m->sigma_dev);
   FD_HIP(hipMemcpy(m->sigma_dev, m->sigma_host.data(), sizeof(double) * m->sigma_n, hipMemcpyHostToDevice));
   FD_TRY(fd_stft_plan_create(m->cfg.n_fft, m->cfg.hop, &m->stft));
-  {
-    const char* e = getenv("FLOWDEC_SIDE_STREAM");   // =0: everything on the caller's stream
-    if (!(e && e[0] == '0')) {
-      FD_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
-      FD_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-      FD_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
-    }
+  if (!(m->cfg.act_dtype & FD_NO_SIDE_STREAM)) {   // (a config bit, not process state: FD_NO_SIDE_STREAM keeps everything on the caller's stream)
+    FD_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    FD_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    FD_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
   }
   FD_HIP(hipStreamSynchronize(st));
   m->host.clear();
@@ -910,6 +936,7 @@ extern "C" size_t fd_model_workspace_bytes(const fd_model* m, int B, int T_pad) 
 
 extern "C" int fd_ncsnpp_forward(fd_model* m, const float* x, const float* y, const float* t, int nt, float* v, int B, int T_pad, void* ws,
                                  size_t ws_bytes, void* stream) {
+  FD_MODEL_ENTER(m, "fd_ncsnpp_forward");
   FD_TRY(check_ready(m));
   FD_REQUIRE(x && y && t && v && ws, "fd_ncsnpp_forward: null pointer");
   FD_TRY(check_shape(m, B, T_pad));
@@ -923,6 +950,7 @@ extern "C" int fd_ncsnpp_forward(fd_model* m, const float* x, const float* y, co
 
 extern "C" int fd_ode_solve(fd_model* m, const float* Y, const float* noise, float sigma_fac, int N, int solver, float* X_out, float* traj, int B,
                             int T_pad, void* ws, size_t ws_bytes, int use_graph, void* stream) {
+  FD_MODEL_ENTER(m, "fd_ode_solve");
   FD_TRY(check_ready(m));
   FD_REQUIRE(Y && noise && X_out && ws, "fd_ode_solve: null pointer");
   FD_REQUIRE(N >= 1, "fd_ode_solve: N must be >= 1");
@@ -961,6 +989,7 @@ extern "C" size_t fd_ode_adaptive_workspace_bytes(const fd_model* m, int B, int 
 
 extern "C" int fd_ode_solve_adaptive(fd_model* m, const float* Y, const float* noise, float sigma_fac, int N, float atol, float rtol, float* X_out,
                                      float* traj, int* nfe_out, int B, int T_pad, void* ws, size_t ws_bytes, void* stream) {
+  FD_MODEL_ENTER(m, "fd_ode_solve_adaptive");
   FD_TRY(check_ready(m));
   FD_REQUIRE(Y && noise && X_out && ws, "fd_ode_solve_adaptive: null pointer");
   FD_REQUIRE(N >= 1 && atol > 0.f && rtol >= 0.f, "fd_ode_solve_adaptive: need N >= 1, atol > 0, rtol >= 0");
@@ -1075,6 +1104,7 @@ extern "C" size_t fd_enhance_normfac_offset(const fd_model* m, int B, int L) {
 
 extern "C" int fd_enhance(fd_model* m, const float* y, const float* noise, float sigma_fac, int N, int solver, float* x_hat, int B, int L, void* ws,
                           size_t ws_bytes, int use_graph, void* stream) {
+  FD_MODEL_ENTER(m, "fd_enhance");
   FD_TRY(check_ready(m));
   FD_REQUIRE(y && noise && x_hat && ws, "fd_enhance: null pointer");
   FD_REQUIRE(N >= 1 && solver_nfe(solver, N) > 0, "fd_enhance: bad N / solver");
@@ -1134,6 +1164,7 @@ extern "C" int fd_score_num_draws(const fd_score_config* c) {
 
 extern "C" int fd_score_enhance(fd_model* m, const float* y, const float* noise, const fd_score_config* c, float* x_hat, int B, int L, void* ws,
                                 size_t ws_bytes, int use_graph, void* stream) {
+  FD_MODEL_ENTER(m, "fd_score_enhance");
   FD_REQUIRE(c && noise, "fd_score_enhance: null pointer");
   FD_REQUIRE(c->N >= 1, "fd_score_enhance: N must be >= 1");
   FD_REQUIRE(c->predictor >= FD_PREDICTOR_REVERSE_DIFFUSION && c->predictor <= FD_PREDICTOR_NONE, "fd_score_enhance: unknown predictor id %d", c->predictor);
@@ -1154,6 +1185,7 @@ extern "C" int fd_score_enhance(fd_model* m, const float* y, const float* noise,
 // reverse-diffusion predictor step used for the final denoising (predictors.py:61-71 with t = eps).
 extern "C" int fd_score_eval(fd_model* m, const float* x, const float* Y, float t, const fd_score_config* c, int mode, float* out, int B,
                              int T_pad, void* ws, size_t ws_bytes, void* stream) {
+  FD_MODEL_ENTER(m, "fd_score_eval");
   FD_TRY(check_ready(m));
   FD_REQUIRE(x && Y && c && out && ws, "fd_score_eval: null pointer");
   FD_REQUIRE(mode >= FD_SCORE_DRIFT_PF && mode <= FD_SCORE_DENOISE, "fd_score_eval: unknown mode %d", mode);
@@ -1175,6 +1207,7 @@ extern "C" int fd_score_eval(fd_model* m, const float* x, const float* Y, float 
 
 extern "C" int fd_regression_enhance(fd_model* m, const float* y, float* x_hat, int B, int L, void* ws, size_t ws_bytes, int use_graph,
                                      void* stream) {
+  FD_MODEL_ENTER(m, "fd_regression_enhance");
   GraphKey key; key.kind = 4;
   return enhance_common(m, "fd_regression_enhance", y, x_hat, B, L, ws, ws_bytes, key, use_graph, stream,
                         [&](float* Y, float* X, int Tp, void* rest, size_t rest_bytes, hipStream_t st) {

@@ -11,13 +11,21 @@ Checkpoints: a Lightning `.ckpt` (dict with `_pl_ema_state_dict` and/or `state_d
 holding the resolved config: callbacks/ema.py:201-215, model.py:100,119) or a bare state_dict.  `--ema` (default)
 selects the EMA weights exactly like `demo.ipynb` cell 2.
 
-Not bit-identical to the reference in ONE place: resampling of non-48 kHz input uses scipy.signal.resample_poly
-(torchaudio is not a dependency); 48 kHz files -- the codec's native rate -- are untouched.
+Non-48 kHz input is resampled with a restatement of torchaudio.functional.resample(..., lowpass_filter_width=64)
+(enhance.py:118; torchaudio itself is not a dependency): `sinc_resample_kernel` / `resample` below.
+
+Length limit: the reference skips files longer than 30 s.  One image of the conv kernel must stay below 2 GiB (32-bit buffer
+offsets), which the f32-storage precisions (fp32 / mixed / bf16x3) reach at ~21 s: with those, files between 20 s and
+30 s are skipped WITH a message that says so and the exit status is 3 (the reference would have processed them).
 """
 import argparse
 import contextlib
 import glob
+import math
 import os
+import re
+import sys
+from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -26,29 +34,53 @@ import torch
 from .model import BACKBONE_FINAL_NO_ATTN, AmplitudeCompressedComplexSTFT, FlowModel, NCSNpp, from_preset
 
 MAX_SECONDS = 30.0  # enhance.py:115
+PRECISION_NOTE = {   # printed at start-up so that a log says which arithmetic produced the files
+    "bf16": "bf16 storage and MFMA operands, f32 accumulation; ~2e-2 relative waveform error vs the fp32 reference on random weights",
+    "mixed": "f32 residual stream, bf16 MFMA operands; ~1.3e-2",
+    "bf16x3": "f32 storage, split-bf16 operands (3 MFMAs per product): meets the fp32 tolerances (~3e-5)",
+    "fp32": "exact f32 MFMA (~6e-6); slowest",
+}
 
 
 # ------------------------------------------------------------------------------------------------
 # file lists / wav I/O
 # ------------------------------------------------------------------------------------------------
-def read_list(listfile: str) -> Tuple[list, bool]:
-    """enhance.py:146-164: plain list, or pair lists (`a ---> b` or `a,b`) whose SECOND entry is the input."""
-    filenames, from_pairs = [], False
+@dataclass
+class FileList:
+    """A parsed `--files` list: the inputs to enhance and, for pair lists, the clean reference each one belongs to."""
+    inputs: List[str] = field(default_factory=list)
+    clean: Optional[List[str]] = None     # None for a plain list
+
+    @property
+    def from_pairs(self) -> bool:
+        return self.clean is not None
+
+
+_PAIR_SEP = re.compile(r" ---> |,")
+
+
+def read_list(listfile: str) -> FileList:
+    """The list formats of the reference (enhance.py:146-164): one path per line, or pair lines `clean ---> coded` /
+    `clean,coded` of which the SECOND entry is the file to enhance.  A plain line after a pair line is an error there
+    (an assert); here it is a ValueError naming the line."""
+    out = FileList()
     with open(listfile, "r") as f:
-        for line in f:
-            line = line.strip()
-            if not line:
+        for lineno, raw in enumerate(f, 1):
+            entry = raw.strip()
+            if not entry:
                 continue
-            if " ---> " in line:
-                from_pairs = True
-                filenames.append(line.split(" ---> "))
-            elif "," in line:
-                from_pairs = True
-                filenames.append(line.split(","))
+            parts = _PAIR_SEP.split(entry)
+            if len(parts) >= 2:
+                if out.clean is None:
+                    if out.inputs:
+                        raise ValueError(f"{listfile}:{lineno}: pair line after plain paths -- inconsistent file list format")
+                    out.clean = []
+                out.clean.append(parts[0]); out.inputs.append(parts[1])
+            elif out.from_pairs:
+                raise ValueError(f"{listfile}:{lineno}: plain path after pair lines -- inconsistent file list format")
             else:
-                assert not from_pairs, "Inconsistent file list format with and without pairs detected!"
-                filenames.append(line)
-    return filenames, from_pairs
+                out.inputs.append(entry)
+    return out
 
 
 def load_wav(path: str) -> Tuple[torch.Tensor, int]:
@@ -77,11 +109,40 @@ def save_wav(path: str, x: torch.Tensor, sr: int) -> None:
     wavfile.write(path, sr, np.ascontiguousarray(a, dtype=np.float32))
 
 
-def resample(y: torch.Tensor, sr: int, target: int) -> torch.Tensor:
-    from math import gcd
-    from scipy.signal import resample_poly
-    g = gcd(sr, target)
-    return torch.from_numpy(resample_poly(y.numpy(), target // g, sr // g, axis=-1).astype(np.float32))
+def sinc_resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 64, rolloff: float = 0.99):
+    """The polyphase filter bank of torchaudio.functional.resample (resampling_method='sinc_interp_hann', the default), restated
+    from its published definition: with o = orig/gcd, n = new/gcd, f = min(o, n) * rolloff and width = ceil(lpw * o / f),
+    phase i in [0, n) and tap k in [-width, width + o):
+        t = clamp((k / o - i / n) * f, -lpw, lpw);   h[i, k] = sinc(t) * cos^2(pi * t / (2 * lpw)) * f / o      (sinc(t) = sin(pi t)/(pi t))
+    Returns (kernel [n, 2 * width + o] float32 computed in float64 like torchaudio, width, o, n)."""
+    g = math.gcd(int(orig_freq), int(new_freq))
+    o, n = int(orig_freq) // g, int(new_freq) // g
+    f = min(o, n) * rolloff
+    width = math.ceil(lowpass_filter_width * o / f)
+    k = np.arange(-width, width + o, dtype=np.float64)[None, :] / o
+    i = np.arange(0, -n, -1, dtype=np.float64)[:, None] / n
+    t = np.clip((i + k) * f, -lowpass_filter_width, lowpass_filter_width)
+    window = np.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    tp = t * math.pi
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sinc = np.where(tp == 0, 1.0, np.sin(tp) / tp)
+    return (sinc * window * (f / o)).astype(np.float32), width, o, n
+
+
+def resample(y: torch.Tensor, sr: int, target: int, lowpass_filter_width: int = 64, rolloff: float = 0.99) -> torch.Tensor:
+    """torchaudio.functional.resample(y, sr, target, lowpass_filter_width=64) as the reference calls it (enhance.py:118):
+    zero-pad by (width, width + o), correlate with the n-phase filter bank at stride o, interleave the phases, keep
+    ceil(n * L / o) samples.  Host-side float32 (file pre-processing, not on the hot path)."""
+    if int(sr) == int(target):
+        return y
+    kern, width, o, n = sinc_resample_kernel(sr, target, lowpass_filter_width, rolloff)
+    shape = y.shape
+    w = y.reshape(-1, shape[-1]).float()
+    length = w.shape[-1]
+    w = torch.nn.functional.pad(w, (width, width + o))
+    r = torch.nn.functional.conv1d(w[:, None], torch.from_numpy(kern)[:, None], stride=o)       # [num, n, frames]
+    r = r.transpose(1, 2).reshape(w.shape[0], -1)[:, : int(math.ceil(n * length / o))]
+    return r.reshape(*shape[:-1], r.shape[-1])
 
 
 # ------------------------------------------------------------------------------------------------
@@ -190,10 +251,8 @@ def collect_files(files: str, single_file: bool) -> Tuple[List[str], Optional[Li
     if os.path.isfile(files):
         if single_file:
             return [files], None
-        entries, from_pairs = read_list(files)
-        if from_pairs:
-            return [e[1] for e in entries], [e[0] for e in entries]
-        return list(entries), None
+        fl = read_list(files)
+        return fl.inputs, fl.clean
     return sorted(glob.glob(f"{files}/*.wav")), None
 
 
@@ -215,7 +274,10 @@ def main(argv=None, model: Optional[FlowModel] = None) -> int:
     gen = None
     if args.seed is not None:
         gen = torch.Generator(device=model.device).manual_seed(args.seed)
-    n_done = 0
+    n_done = n_over_precision_limit = 0
+    # one image must stay below 2 GiB (32-bit buffer offsets of the conv kernel): ~43 s in bf16, ~21 s with f32 storage
+    max_seconds = MAX_SECONDS if args.precision == "bf16" else min(MAX_SECONDS, 20.0)
+    print(f"flowdec_amd: precision={args.precision} ({PRECISION_NOTE[args.precision]}), solver={args.solver}, N={args.N}")
     with (open(triples_path, "w") if triples_path else contextlib.nullcontext()) as trf, \
             (open(rtf_path, "w") if rtf_path else contextlib.nullcontext()) as rtf_f:
         if rtf_f is not None:
@@ -228,8 +290,6 @@ def main(argv=None, model: Optional[FlowModel] = None) -> int:
             out_path = os.path.join(args.outdir, os.path.basename(path))
             if not os.path.exists(out_path) or not args.skip_existing:
                 y, sr = load_wav(path)
-                # one image must stay below 2 GiB (32-bit buffer offsets of the conv kernel): ~43 s in bf16, ~21 s in fp32
-                max_seconds = min(MAX_SECONDS, 20.0) if args.precision != "bf16" else MAX_SECONDS
                 if y.shape[-1] / sr <= max_seconds:
                     if sr != model.sampling_rate:
                         print("RESAMPLING from", sr, "to", model.sampling_rate)
@@ -247,12 +307,18 @@ def main(argv=None, model: Optional[FlowModel] = None) -> int:
                         print(f"{out_path},{runtime:.5f},{filetime:.5f},{runtime / filetime:.5f}", file=rtf_f)
                     save_wav(out_path, x_hat.cpu(), sr)
                     n_done += 1
+                elif y.shape[-1] / sr <= MAX_SECONDS:
+                    n_over_precision_limit += 1
+                    print(f"Skipping file: {y.shape[-1] / sr:.1f} s exceeds the {max_seconds:g} s limit of precision={args.precision} "
+                          f"(the reference's limit is {MAX_SECONDS:g} s; use --precision bf16 for files up to it):", path)
                 else:
                     print("Skipping file due to length:", path)
             if trf is not None:
                 print(f"{clean[i]} ---> {noisy[i]} ---> {out_path}", file=trf)
+    main.skipped_over_precision_limit = n_over_precision_limit
     return n_done
 
 
 if __name__ == "__main__":
     main()
+    sys.exit(3 if getattr(main, "skipped_over_precision_limit", 0) else 0)

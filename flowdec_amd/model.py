@@ -13,6 +13,7 @@ Lightning / Hydra / torchdyn dependency and no PyTorch compute fallback.
 import ctypes as C
 import math
 import os
+import threading
 from typing import Optional, Sequence
 
 import numpy as np
@@ -81,8 +82,9 @@ class NCSNpp(nn.Module):
                  progressive_input="input_skip", progressive_combine="sum", init_scale=0.0, fourier_scale=16,
                  image_size=256, embedding_type="fourier", dropout=0.0, num_channels=4,
                  output_layer_kwargs: dict = DEFAULT_OUTPUTLAYER_KWARGS, bottleneck_attn: bool = True,
-                 precision: str = "bf16", conv_algo: str = "auto"):
+                 precision: str = "bf16", conv_algo: str = "auto", side_stream: bool = True):
         super().__init__()
+        self.side_stream = bool(side_stream)   # fork the time embedding / pyramid-head chain onto a second stream (FD_NO_SIDE_STREAM when False)
         ch_mult = tuple(ch_mult)
         all_res = [image_size // (2 ** i) for i in range(len(ch_mult))]
         unsupported = []
@@ -143,6 +145,7 @@ class NCSNpp(nn.Module):
         self._sigma_y = None
         self._stft_cfg = dict(n_fft=1534, hop=384, alpha=0.3, beta=0.33)
         self._normalize = True
+        self._native_lock = threading.RLock()
 
     # -- native handle management ----------------------------------------------------------------
     def _config_struct(self):
@@ -156,6 +159,8 @@ class NCSNpp(nn.Module):
         cfg.alpha, cfg.beta = self._stft_cfg["alpha"], self._stft_cfg["beta"]
         cfg.act_dtype = (L.FD_BF16 | CONV_ALGOS[self.conv_algo]) if self.precision == "bf16" else \
             (L.FD_F32 | {"mixed": L.FD_BF16_OPERANDS, "bf16x3": L.FD_BF16X3_OPERANDS, "fp32": 0}[self.precision])
+        if not self.side_stream:
+            cfg.act_dtype |= L.FD_NO_SIDE_STREAM
         return cfg
 
     def invalidate(self):
@@ -170,6 +175,18 @@ class NCSNpp(nn.Module):
         except Exception:
             pass
 
+    # copy.deepcopy / pickling (EMA copies, torch.save of the module): the native handle, its workspaces and the lock stay behind;
+    # the copy repacks lazily on first use
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_handle"], st["_handle_sig"], st["_ws"] = None, None, {}
+        st.pop("_native_lock", None)
+        return st
+
+    def __setstate__(self, st):
+        super().__setstate__(st)
+        self._native_lock = threading.RLock()
+
     def _load_from_state_dict(self, *a, **k):
         super()._load_from_state_dict(*a, **k)
         self._handle_sig = None  # parameters changed -> repack lazily
@@ -177,7 +194,7 @@ class NCSNpp(nn.Module):
     def _sig(self):
         p = next(self.parameters())
         sig_sigma = None if self._sigma_y is None else (self._sigma_y.data_ptr(), self._sigma_y._version)
-        return (p.device, self.precision, self.conv_algo, bool(self._normalize), tuple(sorted(self._stft_cfg.items())), sig_sigma,
+        return (p.device, self.precision, self.conv_algo, self.side_stream, bool(self._normalize), tuple(sorted(self._stft_cfg.items())), sig_sigma,
                 tuple(q._version for q in self.parameters()))
 
     def handle(self):
@@ -228,6 +245,10 @@ class NCSNpp(nn.Module):
 
     # -- reference API -----------------------------------------------------------------------------
     def forward(self, x, y, t):
+        with self._native_lock:
+            return self._forward(x, y, t)
+
+    def _forward(self, x, y, t):
         """x, y: complex64 [B, 1, F, T]; t: [1] or [B]  ->  complex64 [B, 1, F, T] (ncsnpp.py:254-399)."""
         L.require_cuda(x, y, t)
         if x.shape != y.shape or x.ndim != 4 or x.shape[1] != 1:
@@ -246,6 +267,20 @@ class NCSNpp(nn.Module):
             L.check(lib.fd_ncsnpp_forward(h, L.ptr(torch.view_as_real(x)), L.ptr(torch.view_as_real(y)), L.ptr(t), t.numel(),
                                           L.ptr(torch.view_as_real(out)), B, T, L.ptr(ws), ws.numel(), L.stream()))
         return out
+
+
+def _serialized(fn):
+    """One native call at a time per model: the packed model, its workspace, its I/O staging buffers and its hipGraph cache are
+    shared state (the C ABI answers a concurrent call with FD_EBUSY).  The reference's nn.Module can be called from several threads;
+    this lock keeps that working -- calls queue up instead of failing."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        bb = self if isinstance(self, NCSNpp) else self.backbone
+        with bb._native_lock:
+            return fn(self, *args, **kwargs)
+    return wrapper
 
 
 # ------------------------------------------------------------------------------------------------
@@ -363,35 +398,56 @@ def _info_from_ws(lib, h, ws, B, Lw, T, squeeze_dims):
     return dict(orig_length=Lw, normfac=normfac, undo_pad_fn=(lambda Y_, T=T: Y_[..., :T]), squeeze_dims=squeeze_dims)
 
 
-def _preprocess(model, y):
-    """EnhancementModel._preprocess (model.py:129-163): [L] / [1, L] / [B, 1, L] waveform -> (Y [B, 1, F, T_pad] complex64 with the
-    frame axis zero-padded to a multiple of 64, preprocess_info)."""
+def _preprocess(model, y, x=None, comp_eps=None):
+    """EnhancementModel._preprocess (model.py:129-163): [L] / [1, L] / [B, 1, L] waveform(s) -> the reference's 3-tuple
+    (Y, X, preprocess_info): Y [B, 1, F, T_pad] complex64 with the frame axis zero-padded to a multiple of 64, X the same
+    features of the optional clean waveform `x` normalised by y's factor (None when x is None)."""
     from . import ops
+    if comp_eps is not None:
+        raise NotImplementedError("flowdec_amd: comp_eps (a training-time regulariser, feature_extractors.py:124-125) is not supported")
+    if x is not None and x.shape != y.shape:
+        raise RuntimeError(f"x and y must have the same shape (got {tuple(x.shape)} vs {tuple(y.shape)})")   # model.py:141
     dev = model.device
     squeeze_dims = 0
     while y.ndim < 3:
         y = y.unsqueeze(0); squeeze_dims += 1
+        x = x.unsqueeze(0) if x is not None else x
     if y.ndim != 3 or y.shape[1] != 1:
         raise RuntimeError(f"expected [L], [1, L] or [B, 1, L] waveforms (got {tuple(y.shape)})")
     B, Lw = y.shape[0], y.shape[-1]
+    cfg = model.feature_extractor._cfg()
     with torch.cuda.device(dev):
-        Y, normfac, T = ops.stft_compress(y.reshape(B, Lw).to(dev, torch.float32).contiguous(), normalize=model.normalize_mode == "noisy",
-                                          **model.feature_extractor._cfg())
+        Y, normfac, T = ops.stft_compress(y.reshape(B, Lw).to(dev, torch.float32).contiguous(), normalize=model.normalize_mode == "noisy", **cfg)
+        X = None
+        if x is not None:   # x / normfac(y) (util/other.py:79-81), then the same feature extractor and padding, without a second normalisation
+            xn = x.reshape(B, Lw).to(dev, torch.float32) / normfac.reshape(B, 1)
+            X, _, _ = ops.stft_compress(xn.contiguous(), normalize=False, **cfg)
     info = dict(orig_length=Lw, normfac=normfac.reshape(B, 1, 1), undo_pad_fn=(lambda Y_, T=T: Y_[..., :T]), squeeze_dims=squeeze_dims)
-    return Y, info
+    return Y, X, info
 
 
-def _postprocess(model, X_hat, preprocess_info):
-    """EnhancementModel._postprocess (model.py:165-190): undo padding, invert the features, restore the level and the rank."""
+def _postprocess(model, X_hat, preprocess_info, inv_kwargs=None, batch_filter=None):
+    """EnhancementModel._postprocess (model.py:165-190): undo padding, invert the features, [select batch items,] restore the
+    level and the rank.  `inv_kwargs` is forwarded to the feature extractor's invert like the reference does; the native
+    inverse has no optional arguments, so a non-empty dict is rejected instead of being silently ignored."""
     from . import ops
-    T = preprocess_info["undo_pad_fn"](X_hat).shape[-1]   # frames before pad_spec
-    Lw = preprocess_info["orig_length"]
+    I = preprocess_info
+    assert {"orig_length", "normfac", "undo_pad_fn", "squeeze_dims"} <= I.keys()   # model.py:180
+    if inv_kwargs:
+        raise NotImplementedError(f"flowdec_amd: feature_extractor.invert takes no extra arguments (got {sorted(inv_kwargs)})")
+    T = I["undo_pad_fn"](X_hat).shape[-1]   # frames before pad_spec
+    Lw = I["orig_length"]
     B = X_hat.shape[0]
     Xp = X_hat.to(torch.complex64).contiguous()             # the kernel reads the first T frames of the (padded) frame axis
+    normfac = I["normfac"]   # [B, 1, 1] tensor ('noisy') or the float 1.0 of normalize_mode='none' (util/other.py:70)
+    normfac = normfac.reshape(-1).float() if torch.is_tensor(normfac) else torch.full((1,), float(normfac))
+    normfac = normfac.expand(B) if normfac.numel() == 1 else normfac
     with torch.cuda.device(Xp.device):
-        x_hat = ops.decompress_istft(Xp, T, Lw, preprocess_info["normfac"].reshape(B).float().contiguous(), **model.feature_extractor._cfg())
+        x_hat = ops.decompress_istft(Xp, T, Lw, normfac.to(Xp.device).contiguous(), **model.feature_extractor._cfg())
     x_hat = x_hat.reshape(B, 1, Lw)
-    for _ in range(preprocess_info["squeeze_dims"]):
+    if batch_filter is not None:   # model.py:185-187 (x * normfac commutes with selecting batch items)
+        x_hat = x_hat[torch.as_tensor(batch_filter, device=x_hat.device)]
+    for _ in range(I["squeeze_dims"]):
         x_hat = x_hat.squeeze(0)
     return x_hat
 
@@ -432,11 +488,11 @@ class FlowModel(nn.Module):
         return self.backbone.handle()
 
     # EnhancementModel._preprocess / _postprocess (model.py:129-190) as stand-alone calls
-    def _preprocess(self, y):
-        return _preprocess(self, y)
+    def _preprocess(self, y, x=None, comp_eps=None):
+        return _preprocess(self, y, x, comp_eps)
 
-    def _postprocess(self, X_hat, preprocess_info):
-        return _postprocess(self, X_hat, preprocess_info)
+    def _postprocess(self, X_hat, preprocess_info, inv_kwargs=None, batch_filter=None):
+        return _postprocess(self, X_hat, preprocess_info, inv_kwargs, batch_filter)
 
     def _io_buffers(self, B, Lw, Tp, F, dev):
         key = (B, Lw, str(dev))
@@ -460,6 +516,7 @@ class FlowModel(nn.Module):
         return torch.randn(shape, dtype=torch.complex64, device=dev, generator=generator)
 
     @torch.no_grad()
+    @_serialized
     def enhance(self, y, return_preprocess_info: bool = False, N: int = 50, solver: str = "euler", with_grad: bool = False,
                 sigma_fac: float = 1.0, return_traj: bool = False, noise=None, generator=None, use_graph: bool = True, **kwargs):
         """Enhances a coded/noisy waveform y (model.py:476-528).  y: [L], [1, L] or [B, 1, L]."""
@@ -614,11 +671,11 @@ class _WaveModel(nn.Module):
         self.backbone, self.feature_extractor = backbone, feature_extractor
         self._io, self._side_stream = {}, None
 
-    def _preprocess(self, y):
-        return _preprocess(self, y)
+    def _preprocess(self, y, x=None, comp_eps=None):
+        return _preprocess(self, y, x, comp_eps)
 
-    def _postprocess(self, X_hat, preprocess_info):
-        return _postprocess(self, X_hat, preprocess_info)
+    def _postprocess(self, X_hat, preprocess_info, inv_kwargs=None, batch_filter=None):
+        return _postprocess(self, X_hat, preprocess_info, inv_kwargs, batch_filter)
 
     @property
     def device(self):
@@ -633,6 +690,7 @@ class _WaveModel(nn.Module):
         self.backbone._normalize = self.normalize_mode == "noisy"
         return self.backbone.handle()
 
+    @_serialized
     def _wave_call(self, y, n_draws, noise, generator, launch, return_preprocess_info=False):
         """launch(lib, h, y_dev [B, L], noise_dev [n_draws, B, 1, F, Tp] | None, out [B, L], ws) on a capture-safe side stream."""
         dev = self.device
@@ -729,6 +787,7 @@ class ScoreModel(_WaveModel):
         return self._wave_call(y, n_draws, noise, generator, launch, return_preprocess_info)
 
 
+    @_serialized
     def _enhance_ode(self, y, N=None, denoise=True, noise=None, generator=None, rtol=1e-5, atol=1e-5, method="RK45", eps=None,
                      return_nfe: bool = False, return_preprocess_info: bool = False, **ignored):
         """sampler_type='ode' (sampling/__init__.py:75-146): the probability-flow ODE integrated by scipy.integrate.solve_ivp

@@ -14,6 +14,12 @@
  *  - Activation tensors are NHWC ([B][H][W][C], H = frequency bins, W = time frames) in the storage
  *    type given by `dtype` (FD_F32 or FD_BF16).  Spectrogram / ODE-state tensors at the model boundary
  *    use the reference layout: complex64 [B][1][F=768][T] (interleaved re,im), float32 waveforms [B][L].
+ *  - Threading.  The operator-level calls (fd_upfirdn2d, fd_fused_bias_act, fd_conv2d, fd_fir_resample, fd_gn_*, fd_stft_*, ...)
+ *    keep no state and are re-entrant from any number of threads, like the reference's ops (upfirdn2d_kernel.cu:224-231).  An
+ *    fd_model holds scratch that its enqueueing calls share (time-embedding biases, hipGraph cache, side stream, profiling events):
+ *    it serves ONE enqueueing call at a time.  A second thread that enters fd_ncsnpp_forward / fd_ode_solve[_adaptive] / fd_enhance /
+ *    fd_score_* / fd_regression_enhance while another is inside gets FD_EBUSY (nothing is enqueued, nothing is corrupted); use one
+ *    fd_model per thread for concurrent solves.  "Inside" is the host-side enqueue only -- the GPU work itself is asynchronous.
  */
 #ifndef FLOWDEC_HIP_H
 #define FLOWDEC_HIP_H
@@ -30,6 +36,7 @@ extern "C" {
 #define FD_ERUNTIME (-2) /* HIP runtime error (message has hipGetErrorString) */
 #define FD_ENOMEM (-3)   /* caller-provided workspace too small */
 #define FD_ESTATE (-4)   /* model not finalised / parameter missing */
+#define FD_EBUSY (-5)    /* the fd_model is inside an enqueueing call of another thread (see "Threading" below) */
 
 #define FD_F32 0
 #define FD_BF16 1
@@ -69,6 +76,10 @@ extern "C" {
  * every convolution picks kernel and workgroup width by its IMAGE size (never by the batch size): FD_TILE_BN32_CHUNK for images of
  * at most 24 tiles, Winograd up to 512 tiles (unless a 1x1 shortcut is folded in), direct otherwise. */
 #define FD_LOW_LATENCY 0x800
+/* fd_model_config.act_dtype only: keep the side branches of a network evaluation (time embedding, pyramid-head chain) on the caller's
+ * stream instead of forking them onto the model's second stream (default: forked; inside a graph capture they become parallel
+ * branches of the graph).  Results are bit-identical either way. */
+#define FD_NO_SIDE_STREAM 0x40000
 
 /* solver ids (flowdec/model.py:487 'euler'/'midpoint' via torchdyn; sampling/solvers.py:15-57) */
 #define FD_SOLVER_EULER 0

@@ -29,15 +29,17 @@ def synthetic_ckpt(nf=8, seed=8, with_hp=True):
 def test_read_list_formats(tmp_path):
     from flowdec_amd.enhance_cli import collect_files, read_list
     a = tmp_path / "plain.txt"; a.write_text("x/a.wav\n\nx/b.wav\n")
-    assert read_list(str(a)) == (["x/a.wav", "x/b.wav"], False)
+    fl = read_list(str(a))
+    assert fl.inputs == ["x/a.wav", "x/b.wav"] and fl.clean is None and not fl.from_pairs
     b = tmp_path / "pairs.txt"; b.write_text("c/a.wav ---> n/a.wav\nc/b.wav,n/b.wav\n")
-    files, pairs = read_list(str(b))
-    assert pairs and files == [["c/a.wav", "n/a.wav"], ["c/b.wav", "n/b.wav"]]
+    fl = read_list(str(b))
+    assert fl.from_pairs and fl.inputs == ["n/a.wav", "n/b.wav"] and fl.clean == ["c/a.wav", "c/b.wav"]
     assert collect_files(str(b), False) == (["n/a.wav", "n/b.wav"], ["c/a.wav", "c/b.wav"])   # second entry is the input
     assert collect_files(str(a), True) == ([str(a)], None)
-    bad = tmp_path / "bad.txt"; bad.write_text("c/a.wav,n/a.wav\nplain.wav\n")
-    with pytest.raises(AssertionError):
-        read_list(str(bad))
+    for name, text in (("bad1.txt", "c/a.wav,n/a.wav\nplain.wav\n"), ("bad2.txt", "plain.wav\nc/a.wav ---> n/a.wav\n")):
+        bad = tmp_path / name; bad.write_text(text)
+        with pytest.raises(ValueError, match=r":2: .*inconsistent"):     # the reference asserts (enhance.py:162)
+            read_list(str(bad))
     (tmp_path / "d").mkdir()
     for n in ("b.wav", "a.wav", "c.txt"):
         (tmp_path / "d" / n).write_bytes(b"")
@@ -55,6 +57,41 @@ def test_wav_roundtrip_and_resample(tmp_path):
     z, sr2 = load_wav(str(tmp_path / "i16.wav"))
     assert sr2 == 16000 and float((z - x).abs().max()) < 1e-4
     assert resample(z, 16000, 48000).shape == (1, 14400)
+
+
+def test_sinc_resampler_matches_torchaudio_definition():
+    """enhance.py:118: torchaudio.functional.resample(y, sr, 48000, lowpass_filter_width=64).  torchaudio is absent, so the
+    restated filter bank is checked (a) against the closed-form Hann-windowed sinc evaluated independently in float64 at
+    every (phase, tap), (b) for its structural constants (width, taps, DC gain), and (c) end to end: a band-limited tone
+    resampled 16 k -> 48 k and 44.1 k -> 48 k must equal the analytically resampled tone, and the output length must be
+    ceil(n * L / o)."""
+    import math
+    from flowdec_amd.enhance_cli import resample, sinc_resample_kernel
+    for sr, lpw in ((16000, 64), (44100, 64), (96000, 64), (16000, 6)):
+        k, width, o, n = sinc_resample_kernel(sr, 48000, lowpass_filter_width=lpw)
+        g = math.gcd(sr, 48000)
+        assert (o, n) == (sr // g, 48000 // g)
+        f = min(o, n) * 0.99
+        assert width == math.ceil(lpw * o / f) and k.shape == (n, 2 * width + o) and k.dtype == np.float32
+        ref = np.zeros(k.shape)
+        for i in range(n):                                  # the definition, one scalar at a time (float64)
+            for j in range(0, k.shape[1], 7 if k.size > 40000 else 1):
+                t = ((j - width) / o - i / n) * f
+                t = max(-lpw, min(lpw, t))
+                sinc = 1.0 if t == 0 else math.sin(math.pi * t) / (math.pi * t)
+                ref[i, j] = sinc * math.cos(math.pi * t / lpw / 2) ** 2 * f / o
+                assert abs(k[i, j] - ref[i, j]) <= 1e-7, (sr, i, j)
+        assert np.allclose(k.sum(1), 1.0, atol=2e-3)        # every phase passes DC
+    for sr, L in ((16000, 4000), (44100, 4410), (8000, 999)):
+        tt = np.arange(L) / sr
+        x = torch.from_numpy((0.5 * np.sin(2 * np.pi * 440.0 * tt)).astype(np.float32))[None]
+        y = resample(x, sr, 48000)
+        g = math.gcd(sr, 48000)
+        assert y.shape == (1, math.ceil((48000 // g) * L / (sr // g)))
+        want = 0.5 * np.sin(2 * np.pi * 440.0 * np.arange(y.shape[-1]) / 48000)
+        m = slice(600, y.shape[-1] - 600)                    # away from the zero-padded ends
+        assert float(np.abs(y[0].numpy()[m] - want[m]).max()) < 2e-3
+    assert resample(x, 48000, 48000) is x
 
 
 def test_checkpoint_reader_cpu():

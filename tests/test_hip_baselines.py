@@ -14,6 +14,10 @@ from test_oracle_golden import SCORE_CASES
 
 pytestmark = pytest.mark.gpu
 _cache = {}
+# measured x 1.3 (profiles/r02_parity_report.txt: PC sampler bf16 9.0e-4 .. 1.18e-3 over the four cases, regression bf16 2.76e-2;
+# fp32 8.5e-7 / 3.8e-6), like the G9 / G17 tolerances -- a 2x regression of either baseline fails
+TOL_SCORE = {"fp32": 5e-6, "bf16": 1.6e-3}
+TOL_REGRESSION = {"fp32": 2e-5, "bf16": 3.6e-2}
 
 
 def baseline(kind, prec):
@@ -48,7 +52,7 @@ def test_score_enhance_golden(case, prec):
     n = m.num_draws(kw["N"], kw["predictor"], kw["corrector"], kw.get("corrector_steps", 1))
     out = m.enhance(torch.from_numpy(g["y"]), noise=golden_noise(g, n), **kw)
     assert out.shape == g[case].shape and out.device.type == "cpu"
-    check(f"score_{case}[{prec}]", out.numpy(), g[case], TOL_WAVE[prec])
+    check(f"score_{case}[{prec}]", out.numpy(), g[case], TOL_SCORE[prec])
 
 
 def test_score_graph_equals_eager_and_batch_independent():
@@ -84,7 +88,7 @@ def test_regression_enhance_golden(prec):
     g = load_golden("g13_score_nf8.npz")
     m = baseline("regression", prec)
     out = m.enhance(torch.from_numpy(g["y"]))
-    check(f"regression[{prec}]", out.numpy(), g["regression"], TOL_WAVE[prec])
+    check(f"regression[{prec}]", out.numpy(), g["regression"], TOL_REGRESSION[prec])
     assert torch.equal(m.enhance(torch.from_numpy(g["y"][0, 0])), out[0, 0])   # 1-D input path
 
 

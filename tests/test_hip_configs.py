@@ -133,8 +133,8 @@ def test_preprocess_postprocess_golden():
     silent clip, and as a round trip."""
     g = load_golden("g3_pad_norm.npz")
     m = make_model(8, 8, "fp32")
-    Y, info = m._preprocess(torch.from_numpy(g["y"]))
-    assert set(info) == {"orig_length", "normfac", "undo_pad_fn", "squeeze_dims"} and Y.shape == (2, 1, 768, int(g["padded_T"]))
+    Y, X, info = m._preprocess(torch.from_numpy(g["y"]))                                     # the reference's 3-tuple (model.py:163)
+    assert X is None and set(info) == {"orig_length", "normfac", "undo_pad_fn", "squeeze_dims"} and Y.shape == (2, 1, 768, int(g["padded_T"]))
     assert np.array_equal(info["normfac"].cpu().numpy(), g["normfac"])                       # bit exact, silence guard included
     assert float(torch.view_as_real(Y[..., int(g["orig_T"]):]).abs().max()) == 0.0           # zero padding of the frame axis
     assert info["undo_pad_fn"](Y).shape[-1] == int(g["orig_T"])
@@ -144,8 +144,21 @@ def test_preprocess_postprocess_golden():
     x = m._postprocess(Y, info)
     assert x.shape == (2, 1, 4800)
     check("_postprocess_roundtrip", x.cpu().numpy(), g["y"], 1e-4)
-    x1 = m._postprocess(*m._preprocess(torch.from_numpy(g["y"][0, 0])))                       # 1-D in -> 1-D out
-    assert x1.shape == (4800,)
+    Y1, _, info1 = m._preprocess(torch.from_numpy(g["y"][0, 0]))                              # 1-D in -> 1-D out
+    assert m._postprocess(Y1, info1).shape == (4800,)
+    # clean target x: normalised by y's factor, same features (model.py:152-157, util/other.py:79-81)
+    xc = 0.5 * g["y"][:, :, ::-1].copy()
+    Y2, X2, info2 = m._preprocess(torch.from_numpy(g["y"]), x=torch.from_numpy(xc))
+    assert torch.equal(Y2, Y) and X2.shape == Y.shape
+    Xo, _ = O.pad_spec(O.compress(O.stft((xc / g["normfac"]).astype(np.float32)), O.ALPHA, O.BETA))
+    check("_preprocess_x", X2.cpu().numpy(), Xo, 2e-5)
+    # batch_filter (model.py:185-187): only the selected items come back, at their own level
+    xf = m._postprocess(Y, info, batch_filter=[False, True])
+    assert xf.shape == (1, 1, 4800) and torch.equal(xf[0], x[1])
+    with pytest.raises(NotImplementedError):
+        m._postprocess(Y, info, inv_kwargs={"window": None})
+    with pytest.raises(NotImplementedError):
+        m._preprocess(torch.from_numpy(g["y"]), comp_eps=1e-3)
 
 
 def test_normalize_mode_none_vs_oracle():
@@ -275,6 +288,151 @@ def test_conv2d_winograd_rejects_unsupported():
         ops.pack_conv_weight(torch.randn(128, 32, 1, 1, device="cuda"), dtype=torch.bfloat16, winograd=True)   # 1x1
     with pytest.raises(RuntimeError):
         ops.pack_conv_weight(torch.randn(128, 32, 3, 3, device="cuda"), dtype=torch.float32, winograd=True)    # f32 storage
+    with pytest.raises(RuntimeError):   # Cout = 384: padded to 384 by the Winograd packing but to 512 by the statistics layout
+        ops.pack_conv_weight(torch.randn(384, 32, 3, 3, device="cuda"), dtype=torch.bfloat16, winograd=True)
+    ops.pack_conv_weight(torch.randn(512, 32, 3, 3, device="cuda"), dtype=torch.bfloat16, winograd=True)       # 512 = pad_256(512): fine
+
+
+@pytest.mark.parametrize("mag", [1e5, 5e3, 1e-6])
+@pytest.mark.parametrize("case", ["shortcut", "shortcut_cat"])
+def test_conv2d_shortcut_dynamic_range(case, mag):
+    """The folded 1x1 shortcut reads the UN-NORMALISED residual stream.  Direct kernel (what `conv_algo='auto'` runs whenever a
+    shortcut is folded in): bf16 range, parity with the f64 convolution at any magnitude.  Winograd kernel (explicit
+    `conv_algo='winograd'` only): raw inputs saturate at +-32752 (half the fp16 range, so that the packed-fp16 input transform
+    cannot produce inf): exact parity below that, finite above it; 1e-6 inputs lose bits to fp16 subnormals, which is far below
+    the main term."""
+    from flowdec_amd import ops
+    import zlib
+    _, B, H, W, C0, C1, Cout, use_aff, bias_rows, use_skip, S0, S1 = next(c for c in WINO_CASES if c[0] == case)
+    rng = np.random.default_rng(zlib.crc32(f"{case}{mag}".encode()))
+    bf = lambda a: O.round_bf16(np.asarray(a, np.float32))
+    x = bf(rng.standard_normal((B, C0, H, W)))
+    w = bf(rng.standard_normal((Cout, C0, 3, 3)) / np.sqrt(C0 * 9))
+    a = (1 + 0.2 * rng.standard_normal((B, C0))).astype(np.float32)
+    d = (0.3 * rng.standard_normal((B, C0))).astype(np.float32)
+    xin = O.silu(x * a[:, :, None, None] + d[:, :, None, None]).astype(np.float32)
+    xs = bf(mag * rng.standard_normal((B, S0 + S1, H, W)))
+    ws = bf(rng.standard_normal((Cout, S0 + S1, 1, 1)) / np.sqrt(S0 + S1))
+    main = O.conv2d(xin.astype(np.float64), w.astype(np.float64), None)
+    ref = main + O.conv2d(xs.astype(np.float64), ws.astype(np.float64), None)
+    aff = dev(np.stack([a, d], axis=-1))
+    x0 = nhwc(x, torch.bfloat16)
+    sc0, sc1 = nhwc(xs[:, :S0], torch.bfloat16), (nhwc(xs[:, S0:], torch.bfloat16) if S1 else None)
+    outs = {}
+    for algo, wino in (("direct", False), ("winograd", True)):
+        pw = ops.pack_conv_weight(dev(w), C0=C0, dtype=torch.bfloat16, w_sc=dev(ws), S0=S0, winograd=wino)
+        outs[algo] = from_nhwc(ops.conv2d(x0, pw, Cout, 3, affine=aff, sc0=sc0, sc1=sc1, winograd=wino))
+        assert np.isfinite(outs[algo]).all(), f"{algo}: non-finite output at |shortcut| ~ {mag:g}"
+    # the direct kernel rounds the activated main operand to bf16 (2^-9 relative to the MAIN term); at mag = 1e5 the main term is a
+    # 1e-5 fraction of the output, at 1e-6 the shortcut is
+    check(f"conv2d_shortcut_range[direct,{case},{mag:g}]", outs["direct"], ref, 6e-3)
+    if np.abs(xs).max() < 32752.0:   # every sample representable: parity
+        check(f"conv2d_shortcut_range[winograd,{case},{mag:g}]", outs["winograd"], ref, 6e-3)
+    else:                            # saturating, not exact: the documented contract of the explicit Winograd mode
+        assert np.abs(outs["winograd"]).max() <= 32752.0 * np.abs(ws).sum(axis=1).max() + np.abs(main).max() + 1.0
+
+
+def test_auto_keeps_residual_stream_out_of_fp16():
+    """`conv_algo='auto'` (the default) never sends a folded-shortcut convolution to the Winograd kernel: with an input 3e5 times
+    the usual level the un-normalised residual stream is ~1e5-1e6 at every resolution, far outside fp16 -- `auto` must agree with
+    `direct` (they differ only in the shortcut-free convolutions of the low-resolution levels) and with the fp32 mode."""
+    import flowdec_amd
+    g = load_golden("g10_ncsnpp_nf64.npz")
+    sd = {k: torch.from_numpy(v) for k, v in O.random_state_dict(seed=int(g["seed"]), nf=64).items()}
+    outs = {}
+    for prec, algo in (("fp32", "direct"), ("bf16", "direct"), ("bf16", "auto")):
+        m = flowdec_amd.from_preset("flowdec_75m", precision=prec, conv_algo=algo)
+        m.load_state_dict(sd, strict=False)
+        m = m.cuda()
+        outs[prec, algo] = m(cu(g["x"]) * 3e5, cu(g["y"]) * 3e5, torch.tensor([0.5], device="cuda")).cpu().numpy()
+        assert np.isfinite(outs[prec, algo]).all()
+        del m
+    check("ncsnpp_nf64_x3e5[bf16,direct]", outs["bf16", "direct"], outs["fp32", "direct"], TOL_FWD["bf16"])
+    check("ncsnpp_nf64_x3e5[bf16,auto]", outs["bf16", "auto"], outs["fp32", "direct"], TOL_FWD["bf16"])
+
+
+def test_model_create_rejects_flag_combinations():
+    """fd_model_create: at most one convolution-algorithm flag, no FD_TILE_* bits, no unknown bits; FD_NO_SIDE_STREAM is a config
+    bit (not an environment variable) and gives bit-identical results."""
+    import ctypes as C
+    from flowdec_amd import _lib as L
+    lib = L.load()
+
+    def create(act):
+        cfg = L.FdModelConfig()
+        cfg.nf = 8
+        for i, c in enumerate((4, 4, 4, 2)):
+            cfg.ch_mult[i] = c
+        cfg.num_levels, cfg.num_res_blocks, cfg.n_fft, cfg.hop, cfg.alpha, cfg.beta, cfg.act_dtype = 4, 1, 1534, 384, 0.3, 0.33, act
+        h = C.c_void_p()
+        rc = lib.fd_model_create(C.byref(cfg), C.byref(h))
+        if rc == 0:
+            lib.fd_model_destroy(h)
+        return rc
+    assert create(L.FD_BF16 | L.FD_WINOGRAD_AUTO) == 0 and create(L.FD_BF16 | L.FD_NO_SIDE_STREAM) == 0 and create(L.FD_F32) == 0
+    for bad in (L.FD_BF16 | L.FD_WINOGRAD | L.FD_LOW_LATENCY, L.FD_BF16 | L.FD_WINOGRAD_AUTO | L.FD_WINOGRAD_LOWRES,
+                L.FD_BF16 | L.FD_TILE[64], L.FD_BF16 | L.FD_TILE["32c"] | L.FD_WINOGRAD, L.FD_F32 | L.FD_WINOGRAD, L.FD_BF16 | 0x80000):
+        assert create(bad) == -1, hex(bad)
+    m1, m2 = make_model(8, 8, "bf16"), None
+    import flowdec_amd
+    m2 = flowdec_amd.from_preset("flowdec_75m", precision="bf16", nf=8, side_stream=False)
+    m2.load_state_dict(m1.state_dict(), strict=False)
+    m2 = m2.cuda()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(2, 1, 768, 64, dtype=torch.complex64, device="cuda", generator=gen)
+    y = torch.randn(2, 1, 768, 64, dtype=torch.complex64, device="cuda", generator=gen)
+    t = torch.tensor([0.4], device="cuda")
+    assert torch.equal(m1(x, y, t), m2(x, y, t))
+
+
+def test_model_calls_from_two_threads():
+    """One enqueueing call at a time per fd_model (include/flowdec_hip.h "Threading"): the Python module serialises its callers,
+    the C ABI answers a concurrent call with FD_EBUSY -- in neither case is shared state corrupted: every result that comes back
+    is bit-identical to the single-threaded one."""
+    import ctypes as C
+    import threading
+    from flowdec_amd import _lib as L
+    m = make_model(8, 8, "bf16")
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(1, 1, 768, 64, dtype=torch.complex64, device="cuda", generator=gen)
+    y = torch.randn(1, 1, 768, 64, dtype=torch.complex64, device="cuda", generator=gen)
+    t = torch.tensor([0.25], device="cuda")
+    want = m(x, y, t).clone()
+    torch.cuda.synchronize()
+    # (a) the module from two threads: all calls succeed (queued by the lock)
+    res, errs = [], []
+
+    def via_module():
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(10):
+                    o = m(x, y, t); s.synchronize(); res.append(torch.equal(o, want))
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=via_module) for _ in range(2)]
+    [a.start() for a in th]; [a.join() for a in th]
+    assert not errs and len(res) == 20 and all(res)
+    # (b) the raw C entry point from two threads, each with its own output / workspace / stream: a call returns 0 or FD_EBUSY
+    lib, h = L.load(), m.backbone.handle()
+    need = lib.fd_model_workspace_bytes(h, 1, 64)
+    xr, yr = torch.view_as_real(x).contiguous(), torch.view_as_real(y).contiguous()
+    rcs, good = [], []
+
+    def via_abi():
+        ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+        out = torch.empty_like(x)
+        s = torch.cuda.Stream()
+        for _ in range(20):
+            rc = lib.fd_ncsnpp_forward(h, L.ptr(xr), L.ptr(yr), L.ptr(t), 1, L.ptr(torch.view_as_real(out)), 1, 64, L.ptr(ws), ws.numel(),
+                                       C.c_void_p(s.cuda_stream))
+            s.synchronize()
+            rcs.append(rc)
+            if rc == 0:
+                good.append(torch.equal(out, want))
+    th = [threading.Thread(target=via_abi) for _ in range(2)]
+    [a.start() for a in th]; [a.join() for a in th]
+    assert set(rcs) <= {0, L.FD_EBUSY} and rcs.count(0) >= 20 and all(good)
 
 
 @pytest.mark.parametrize("algo", ["winograd", "winograd_lowres", "auto", "latency", "direct"])
