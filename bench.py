@@ -2,13 +2,15 @@
 """bench.py -- FlowDec-75m inference throughput on MI355X (BASELINE.json metric).
 
 One "step" = one pass of the hot path (FlowModel.enhance: STFT -> 6 x NCSN++ inside the Euler solver -> iSTFT) over one
-batch of synthetic clips that is already resident in HBM.  Workload at N = 1 is BASELINE.json configs[1]: FlowDec-75m,
-batch = 8 x 2 s clips @ 48 kHz, 6-step Euler, bf16.
+batch of synthetic clips.  Workload at N = 1 is BASELINE.json configs[1]: FlowDec-75m, batch = 8 x 2 s clips @ 48 kHz, 6-step
+Euler, bf16.  `value` is timed with the inputs already resident in HBM (the bench contract); the same K steps are then timed
+again from PINNED HOST waveforms to host waveforms ("H2D of waveform -> D2H of waveform") and reported next to it
+as `e2e` -- the two differ by the 2 x 6 MB of PCIe copies (< 0.3 ms of ~140).
 
 Multi-GPU: one process per GPU, the GLOBAL batch (default 8 clips per GPU = weak scaling; `--global-batch G`
-fixes the total = strong scaling, e.g. 256 for BASELINE config 4) is sharded by clip with `flowdec_amd.dist.sharded_apply`,
-whose all-gather of the output waveforms over RCCL/xGMI is the only collective and sits INSIDE the timed region.  `value` is
-the whole-job audio-seconds per wall-second (max over ranks).
+fixes the total = strong scaling, e.g. 256 for BASELINE config 4) is sharded by clip with `flowdec_amd.dist.sharded_enhance`
+-- the API a user calls -- whose single all_gather_into_tensor of the output waveforms over RCCL/xGMI is the only collective
+and sits INSIDE the timed region.  `value` is the whole-job audio-seconds per wall-second (max over ranks).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]            # N > 1: re-launches itself under torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -27,39 +29,48 @@ sys.path.insert(0, ROOT)
 
 TRAFFIC_FILE = "r02_conv_traffic.json"
 REF_CPU_FILE = "r02_reference_cpu_timing.json"
+F32_MFMA_PEAK_TFLOPS = 157.3   # dense f32 MFMA (the exact-f32 DFT GEMMs of the STFT front / back end)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "mixed": 2500.0, "bf16x3": 2500.0 / 3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBPS = 8000.0
 
 
 def cpu_baseline():
-    """Times the NumPy oracle (a port of the reference's fp32 CPU path) on a bounded sample of the same workload: ONE
-    vector-field evaluation of the full-width FlowDec-75m NCSN++ on the shape of BASELINE config 1 (one 1 s clip = 126
-    frames padded to 768 x 128), extrapolated to the 6 NFE of the benchmark config (the STFT/iSTFT are < 0.1 %)."""
+    """The same-box CPU baseline: ALL of BASELINE config 1 (FlowDec-75m, one 1 s clip @ 48 kHz, 6-step Euler, fp32: STFT ->
+    6 x full-width NCSN++ -> iSTFT, nothing extrapolated) through oracle/flowdec_oracle_torch.py -- the oracle's restatement of
+    the graph and the solver on PyTorch's CPU kernels (oneDNN conv / GroupNorm, pocketfft STFT), i.e. on the library kernels the
+    reference's own CPU path runs on (the reference's Python cannot travel to this box).  One untimed 1-NFE warm-up (thread
+    pool, oneDNN primitive cache), then one timed enhance."""
     import numpy as np
+    import torch
     from oracle import flowdec_oracle as O
+    from oracle import flowdec_oracle_torch as OT
     rng = np.random.default_rng(0)
-    net = O.NCSNppOracle(O.random_state_dict(seed=64, nf=64), nf=64)
-    shape = (1, 1, 768, 128)
-    x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
-    y = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+    net = OT.NCSNppTorchCPU(O.random_state_dict(seed=64, nf=64), nf=64)
+    y = (0.1 * rng.standard_normal((1, 1, 48000))).astype(np.float32)
+    Tp = O.padded_frames(O.num_frames(48000))
+    noise = ((rng.standard_normal((1, 1, 768, Tp)) + 1j * rng.standard_normal((1, 1, 768, Tp))) / np.sqrt(2)).astype(np.complex64)
+    threads = torch.get_num_threads()
+    OT.enhance(net, y, noise, 0.66, N=1, solver="euler")
     t0 = time.perf_counter()
-    net.forward(x, y, np.array([0.5], np.float32))
+    out = OT.enhance(net, y, noise, 0.66, N=6, solver="euler")
     dt = time.perf_counter() - t0
-    audio_s = 1.0
+    assert np.isfinite(out).all()
+    cpu = "?"
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    sample = ("oracle (NumPy/OpenBLAS fp32 port of the reference CPU path): 1 NFE of full-width NCSN++ on one 1 s clip "
-              f"(BASELINE config 1 shape, 768x128 frames) took {dt:.2f} s; x6 NFE extrapolated to the Euler N=6 config")
+        with open("/proc/cpuinfo") as f:
+            cpu = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "?")
+    except OSError:
+        pass
+    sample = (f"BASELINE config 1 in full (1 clip x 1 s, 6-step Euler = 6 NFE of the full-width NCSN++ + STFT/iSTFT, fp32), oracle on PyTorch CPU "
+              f"kernels (oracle/flowdec_oracle_torch.py): {dt:.2f} s per enhance on {threads} threads of {os.cpu_count()} logical cores ({cpu})")
     ref = os.path.join(ROOT, "profiles", REF_CPU_FILE)
     if os.path.exists(ref):   # the reference implementation itself, measured in the build container (it cannot travel to this box)
         with open(ref) as f:
             r = json.load(f)
-        sample += (f".  Reference implementation (PyTorch CPU, real FlowModel.enhance, config 1, {r['threads']} threads, build container, "
+        sample += (f".  Reference implementation itself (real FlowModel.enhance, PyTorch CPU, config 1, {r['threads']} threads, build container, "
                    f"profiles/{REF_CPU_FILE}): {r['seconds_per_enhance']:.1f} s per enhance = {r['audio_seconds_per_second']:.4f} audio-s/s")
-    return {"value": audio_s / (6 * dt), "unit": "audio-seconds/second", "cores": int(threads), "kind": "port", "sample": sample}
+    return {"value": 1.0 / dt, "unit": "audio-seconds/second", "cores": int(threads), "kind": "port", "sample": sample,
+            "seconds_per_enhance": dt, "cpu_model": cpu}
 
 
 def free_port():
@@ -96,6 +107,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the second timed loop (pinned host waveforms in -> host waveforms out)")
+    ap.add_argument("--no-side-stream", action="store_true", help="FD_NO_SIDE_STREAM: keep the side branches on the launch stream")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --stub-step: launcher / collective test on CPU")
     ap.add_argument("--stub-step", action="store_true", help="replace enhance() by a trivial CPU function (tests of the launcher only)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (with --backend gloo: exercises the N > 1 path on a 1-GPU box)")
@@ -112,7 +125,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     import torch
-    from flowdec_amd.dist import shard_range, sharded_apply
+    from flowdec_amd.dist import shard_range, shard_sizes, sharded_apply, sharded_enhance
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -125,21 +138,28 @@ def main():
     gbatch = args.global_batch if args.global_batch is not None else args.batch * world
     Lw = int(round(args.seconds * 48000))
     lo, hi = shard_range(gbatch, rank, world)
+    stats = {} if world > 1 else None      # per-rank local / gather split (synchronises per step; the N = 1 loop stays asynchronous)
 
     if args.stub_step:
         dev = torch.device("cpu")
         y = 0.1 * torch.randn(gbatch, 1, Lw, generator=torch.Generator().manual_seed(0))
-        nfe, Tp, model, noise = args.N, 0, None, None
+        y_host = None
+        nfe = {"euler": args.N, "midpoint": 2 * args.N, "heun2": 2 * args.N, "heun2_eulerlast": 2 * args.N - 1}[args.solver]
+        Tp, model, noise = 0, None, None
 
-        def local_fn(yb):
-            return yb * 2.0 + 1.0
+        def step(src):
+            t1 = time.perf_counter()
+            out = sharded_apply(lambda yb: yb * 2.0 + 1.0, src)
+            if stats is not None:
+                stats["gather_s"] = stats.get("gather_s", 0.0) + (time.perf_counter() - t1)
+            return out
     else:
         import flowdec_amd
         from flowdec_amd import _lib as L
         dev = torch.device("cuda", 0 if args.share_gpu else local_rank)
         torch.cuda.set_device(dev)
         # synthetic data + seeded random-init weights of the FlowDec-75m architecture (no checkpoints offline)
-        model = flowdec_amd.from_preset(args.preset, precision=args.precision, conv_algo=args.conv_algo)
+        model = flowdec_amd.from_preset(args.preset, precision=args.precision, conv_algo=args.conv_algo, side_stream=not args.no_side_stream)
         g = torch.Generator().manual_seed(1234)
         sd = {}
         for k, v in model.state_dict().items():
@@ -156,33 +176,19 @@ def main():
                 sd[k] = torch.randn(v.shape, generator=g) / fan_in ** 0.5
         model.load_state_dict(sd, strict=False)
         model = model.to(dev)
-        # the same global batch on every rank (seeded), resident in HBM before the timed region; each rank works on its slice
+        # the same global batch on every rank (seeded), resident in HBM before the timed region (and once more in pinned host memory
+        # for the e2e loop); each rank enhances its rows.  The initial noise is a GLOBAL tensor indexed by clip, so the result does
+        # not depend on the number of ranks.
         gen = torch.Generator(device=dev).manual_seed(0)
         y = 0.1 * torch.randn(gbatch, 1, Lw, device=dev, generator=gen)
+        y_host = y.cpu().pin_memory()
         lib = L.load()
         T = lib.fd_num_frames(Lw, 384); Tp = lib.fd_padded_frames(T)
-        noise = torch.randn(gbatch, 1, 768, Tp, dtype=torch.complex64, device=dev, generator=gen)[lo:hi].contiguous()
+        noise = torch.randn(gbatch, 1, 768, Tp, dtype=torch.complex64, device=dev, generator=gen)
         nfe = {"euler": args.N, "midpoint": 2 * args.N, "heun2": 2 * args.N, "heun2_eulerlast": 2 * args.N - 1, "dopri5": None}[args.solver]
 
-        def local_fn(yb):
-            return model.enhance(yb, N=args.N, solver=args.solver, noise=noise, use_graph=not args.no_graph)
-
-    t_gather = [0.0]
-
-    def step():
-        if dist is None:
-            return local_fn(y)
-        t0 = time.perf_counter()
-        local = local_fn(y[lo:hi])
-        if dev.type == "cuda":
-            torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        out = sharded_apply(lambda _yb: local, y)      # all-gather of the enhanced waveforms (RCCL over xGMI / gloo)
-        if dev.type == "cuda":
-            torch.cuda.synchronize(dev)
-        t_gather[0] += time.perf_counter() - t1
-        del t0
-        return out
+        def step(src):   # src: the global batch, on the device (timed `value`) or in pinned host memory (`e2e`)
+            return sharded_enhance(model, src, N=args.N, solver=args.solver, noise=noise, use_graph=not args.no_graph, stats=stats)
 
     def sync_all():
         if dist is not None:
@@ -190,27 +196,32 @@ def main():
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
 
+    def timed(src, steps):
+        sync_all()
+        if stats is not None:
+            stats.clear()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step(src)
+        sync_all()
+        el = time.perf_counter() - t0
+        gs = stats.get("gather_s", 0.0) if stats is not None else 0.0
+        per_rank = [1e3 * el / steps]
+        if dist is not None:
+            tt = torch.tensor([el, gs], device=dev, dtype=torch.float64)
+            allt = [torch.empty_like(tt) for _ in range(world)]
+            dist.all_gather(allt, tt)
+            per_rank = [1e3 * float(t[0]) / steps for t in allt]
+            gs = max(float(t[1]) for t in allt)
+            el = max(float(t[0]) for t in allt)
+        return out, el, per_rank, 1e3 * gs / steps
+
     for _ in range(args.warmup):
-        out = step()
-    sync_all()
-    t_gather[0] = 0.0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    assert out.shape[0] == gbatch and torch.isfinite(out).all()
+        out = step(y)
+    out, elapsed, per_rank_ms, gather_ms = timed(y, args.steps)
+    assert out.shape[0] == gbatch and out.device == y.device and torch.isfinite(out).all()
     if nfe is None:
         nfe = model.last_nfe   # adaptive solver: realised number of vector-field evaluations of the last step
-    per_rank_ms = [1e3 * elapsed / args.steps]
-    gather_ms = 1e3 * t_gather[0] / args.steps
-    if dist is not None:
-        tt = torch.tensor([elapsed, t_gather[0]], device=dev, dtype=torch.float64)
-        allt = [torch.empty_like(tt) for _ in range(world)]
-        dist.all_gather(allt, tt)
-        per_rank_ms = [1e3 * float(t[0]) / args.steps for t in allt]
-        gather_ms = 1e3 * max(float(t[1]) for t in allt) / args.steps
-        elapsed = max(float(t[0]) for t in allt)
 
     audio_seconds = gbatch * args.seconds * args.steps
     result = {
@@ -221,12 +232,20 @@ def main():
         "dtype": args.precision, "data": "synthetic (0.1*randn waveforms, seeded random-init weights of the FlowDec-75m architecture)",
         "config": {"workload": f"{args.preset} enhance(): global batch={gbatch} x {args.seconds:g} s clips @48 kHz ({hi - lo} per GPU), {args.N}-step "
                                f"{args.solver} (NFE {nfe}), T_pad={Tp} frames, inputs resident in HBM, output waveforms all-gathered",
-                   "global_batch": gbatch, "nfe": nfe, "parallelism": f"batch-shard x{world}", "hipgraph": not args.no_graph,
-                   "conv_algo": args.conv_algo, "backend": args.backend if world > 1 else None},
+                   "global_batch": gbatch, "clips_per_rank": shard_sizes(gbatch, world), "nfe": nfe, "parallelism": f"batch-shard x{world}",
+                   "hipgraph": not args.no_graph, "conv_algo": args.conv_algo, "backend": args.backend if world > 1 else None},
         "per_rank_ms_per_step": per_rank_ms, "allgather_ms_per_step": gather_ms if world > 1 else 0.0,
     }
     if args.stub_step:
         result["config"]["workload"] = "STUB step (launcher / collective test, no model)"
+    elif not args.no_e2e:
+        # the same K steps from pinned host memory to host memory: H2D of this rank's rows, solve, gather, D2H
+        out_h = step(y_host)
+        assert out_h.device.type == "cpu" and torch.equal(out_h, out.cpu()), "e2e result differs from the HBM-resident one"
+        _, el2, _, _ = timed(y_host, args.steps)
+        result["e2e"] = {"value": audio_seconds / el2, "unit": "audio-seconds/second", "ms_per_step": 1e3 * el2 / args.steps,
+                         "path": f"pinned host float32 [{gbatch}, 1, {Lw}] -> H2D -> enhance -> all-gather -> D2H host float32 (same K steps, same clock)",
+                         "pcie_bytes_per_step": 2 * 4 * (hi - lo) * Lw if world == 1 else 4 * ((hi - lo) + gbatch) * Lw}
 
     if rank == 0 and world == 1 and not args.no_roofline and not args.stub_step:
         from flowdec_amd import _lib as L
@@ -241,6 +260,8 @@ def main():
         L.check(lib.fd_profile_read(h, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
         fms, fn_, fby = C.c_double(), C.c_longlong(), C.c_double()
         L.check(lib.fd_profile_read_fir(h, C.byref(fms), C.byref(fn_), C.byref(fby)))
+        sms, scalls = (C.c_double * 6)(), (C.c_int * 2)()
+        L.check(lib.fd_profile_read_stft(h, C.byref(sms), C.byref(scalls)))
         L.check(lib.fd_profile_enable(h, 0))
         achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[args.precision]
@@ -256,6 +277,26 @@ def main():
                                   "achieved": fach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": fach / HBM_PEAK_GBPS, "traffic": None,
                                   "launches": int(fn_.value), "avg_launch_ms": fms.value / fnl, "ms_per_step": fms.value,
                                   "algorithmic_bytes_per_launch": fby.value / fnl}
+        # STFT / iSTFT (ComplexSTFT + compression and their inverses, once per step each): the two exact-f32 DFT GEMMs against the
+        # dense f32 MFMA peak, the four elementwise kernels against HBM.  M = B * T frames, K = 1536 (n_fft 1534 padded):
+        #   GEMM flops = 2 * M * K * K each;  frame: read y, write M * K f32;  compress: read M * K, write B * 768 * T_pad c64;
+        #   decompress: read B * 768 * T c64, write M * K;  overlap-add: read M * K (each sample of the 4 overlapping frames), write y.
+        if scalls[0] >= 1 and scalls[1] >= 1:
+            M, K = gbatch * T, 1536
+            gflop = 2.0 * M * K * K
+            by4 = [4.0 * (gbatch * Lw + M * K), 4.0 * M * K + 8.0 * gbatch * 768 * Tp, 8.0 * gbatch * 768 * T + 4.0 * M * K, 4.0 * (M * K + gbatch * Lw)]
+            ms_gemm = sms[1] + sms[4]
+            ms_elem = [sms[0], sms[2], sms[3], sms[5]]
+            tf = 2 * gflop / (ms_gemm * 1e-3) / 1e12 if ms_gemm > 0 else 0.0
+            gbps = sum(by4) / (sum(ms_elem) * 1e-3) / 1e9 if sum(ms_elem) > 0 else 0.0
+            result["roofline_stft"] = {
+                "kernel": "sgemm_mfma_kernel (1534-point DFT / inverse DFT as exact-f32 GEMM) + absmax/frame/compress/decompress/overlap_add",
+                "dft_gemm": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS,
+                             "launches": 2, "avg_launch_ms": ms_gemm / 2, "algorithmic_gflop_per_launch": gflop / 1e9, "M": M, "K": K},
+                "elementwise": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "launches": 5,
+                                "ms": {"absmax+frame": sms[0], "compress": sms[2], "decompress": sms[3], "overlap_add": sms[5]},
+                                "algorithmic_bytes": {"absmax+frame": by4[0], "compress": by4[1], "decompress": by4[2], "overlap_add": by4[3]}},
+                "ms_per_step": sum(sms)}
         # HBM bytes per launch from the committed PMC passes of this same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # corrected as profiles/summarize_pmc.py documents); PMC counters cannot be collected from inside the timed run.
         default_cfg = (args.preset, args.precision, args.solver, args.N, gbatch, args.seconds, args.conv_algo) == \

@@ -101,6 +101,9 @@ SIGNATURES = {
     "fd_profile_enable": (c_int, [_P, c_int]),
     "fd_profile_read": (c_int, [_P, C.POINTER(C.c_double), C.POINTER(c_ll), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "fd_profile_read_fir": (c_int, [_P, C.POINTER(C.c_double), C.POINTER(c_ll), C.POINTER(C.c_double)]),
+    "fd_profile_read_stft": (c_int, [_P, C.POINTER(C.c_double * 6), C.POINTER(c_int * 2)]),
+    "fd_stft_plan_profile": (c_int, [_P, c_int]),
+    "fd_stft_plan_profile_read": (c_int, [_P, C.POINTER(C.c_double * 6), C.POINTER(c_int * 2)]),
 }
 
 _lib = None

@@ -1272,7 +1272,13 @@ extern "C" int fd_profile_enable(fd_model* m, int enable) {
   m->prof_bytes = 0.0;
   m->ev_fir_used = 0;
   m->prof_fir_bytes = 0.0;
+  if (m->stft) FD_TRY(fd_stft_plan_profile(m->stft, enable));
   return FD_OK;
+}
+
+extern "C" int fd_profile_read_stft(fd_model* m, double* ms6, int* calls2) {
+  FD_REQUIRE(m && m->stft, "fd_profile_read_stft: null model / model not finalised");
+  return fd_stft_plan_profile_read(m->stft, ms6, calls2);
 }
 
 extern "C" int fd_profile_read_fir(fd_model* m, double* ms_total, long long* launches, double* bytes_total) {

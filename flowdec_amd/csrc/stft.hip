@@ -22,6 +22,11 @@ struct fd_stft_plan {
   float* Dt = nullptr;   // [kpad][kpad]   forward: rows = sample k (window folded), cols = 2f (re), 2f+1 (im)
   float* E = nullptr;    // [kpad][kpad]   inverse: rows = 2f / 2f+1, cols = sample n (window and 1/N folded)
   float* w2 = nullptr;   // [n_fft]        window^2 (overlap-add envelope)
+  // optional per-kernel timing (fd_stft_plan_profile): events 0..3 bracket {absmax + framing | DFT GEMM | compression} of the LAST
+  // forward call, 4..7 {decompression | inverse DFT GEMM | overlap-add} of the last inverse call
+  bool prof = false;
+  hipEvent_t ev[8] = {};
+  int calls[2] = {0, 0};
 };
 
 namespace {
@@ -269,7 +274,33 @@ extern "C" int fd_stft_plan_create(int n_fft, int hop, fd_stft_plan** out) {
 extern "C" void fd_stft_plan_destroy(fd_stft_plan* p) {
   if (!p) return;
   (void)hipFree(p->Dt); (void)hipFree(p->E); (void)hipFree(p->w2);
+  for (hipEvent_t e : p->ev) if (e) (void)hipEventDestroy(e);
   delete p;
+}
+
+extern "C" int fd_stft_plan_profile(fd_stft_plan* p, int enable) {
+  FD_REQUIRE(p, "fd_stft_plan_profile: null plan");
+  if (enable)
+    for (hipEvent_t& e : p->ev) if (!e) FD_HIP(hipEventCreate(&e));
+  p->prof = enable != 0;
+  p->calls[0] = p->calls[1] = 0;
+  return FD_OK;
+}
+
+extern "C" int fd_stft_plan_profile_read(fd_stft_plan* p, double* ms6, int* calls2) {
+  FD_REQUIRE(p && ms6, "fd_stft_plan_profile_read: null pointer");
+  for (int i = 0; i < 6; ++i) ms6[i] = 0.0;
+  for (int half = 0; half < 2; ++half) {
+    if (!p->calls[half]) continue;
+    FD_HIP(hipEventSynchronize(p->ev[4 * half + 3]));
+    for (int i = 0; i < 3; ++i) {
+      float e = 0.f;
+      FD_HIP(hipEventElapsedTime(&e, p->ev[4 * half + i], p->ev[4 * half + i + 1]));
+      ms6[3 * half + i] = e;
+    }
+  }
+  if (calls2) { calls2[0] = p->calls[0]; calls2[1] = p->calls[1]; }
+  return FD_OK;
 }
 
 size_t fd_stft_ws_bytes(int B, int L, int n_fft, int hop) {
@@ -287,11 +318,17 @@ int fd_stft_forward(fd_stft_plan* p, const float* y, int B, int L, float alpha, 
   float* frames = reinterpret_cast<float*>(ws);
   float* spec = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + fd_align(sizeof(float) * (size_t)B * T * K));
   const int M = B * T;
+  auto mark = [&](int i) { if (p->prof) (void)hipEventRecord(p->ev[i], st); };
+  mark(0);
   hipLaunchKernelGGL(absmax_kernel, dim3(B), dim3(1024), 0, st, y, L, normalize, normfac);
   hipLaunchKernelGGL(frame_kernel, dim3(grid_cap((long long)M * K)), dim3(256), 0, st, y, normfac, frames, B, L, T, p->n_fft, p->hop, K);
+  mark(1);
   launch_sgemm(frames, p->Dt, spec, M, K, K, st);
+  mark(2);
   hipLaunchKernelGGL(compress_kernel, dim3(grid_cap((long long)B * p->n_freq * T_pad)), dim3(256), 0, st, spec, (float2*)Y, B, p->n_freq, T,
                      T_pad, K, alpha, beta);
+  mark(3);
+  if (p->prof) ++p->calls[0];
   FD_LAUNCH_CHECK();
   return FD_OK;
 }
@@ -305,10 +342,16 @@ int fd_stft_inverse(fd_stft_plan* p, const float* X, int B, int T, int T_pad, fl
   float* Z = reinterpret_cast<float*>(ws);
   float* FR = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + fd_align(sizeof(float) * (size_t)B * T * K));
   const int M = B * T;
+  auto mark = [&](int i) { if (p->prof) (void)hipEventRecord(p->ev[i], st); };
+  mark(4);
   hipLaunchKernelGGL(decompress_kernel, dim3(grid_cap((long long)M * (K / 2))), dim3(256), 0, st, (const float2*)X, Z, B, p->n_freq, T, T_pad, K,
                      alpha, beta);
+  mark(5);
   launch_sgemm(Z, p->E, FR, M, K, K, st);
+  mark(6);
   hipLaunchKernelGGL(overlap_add_kernel, dim3(grid_cap((long long)B * L)), dim3(256), 0, st, FR, p->w2, normfac, y, B, T, L, p->n_fft, p->hop, K);
+  mark(7);
+  if (p->prof) ++p->calls[1];
   FD_LAUNCH_CHECK();
   return FD_OK;
 }

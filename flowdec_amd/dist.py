@@ -50,8 +50,13 @@ def all_gather_shards(local: torch.Tensor, n_items: int, group=None) -> torch.Te
     else:
         send = local.new_zeros((pad,) + tail)
         send[: local.shape[0]] = local
-    out = local.new_empty((world * pad,) + tail)
-    dist.all_gather_into_tensor(out, send, group=group)
+    if send.is_cuda and dist.get_backend(group) == "gloo":   # gloo moves host memory: stage device tensors through the host
+        out = send.new_empty((world * pad,) + tail, device="cpu")
+        dist.all_gather_into_tensor(out, send.cpu(), group=group)
+        out = out.to(send.device)
+    else:
+        out = local.new_empty((world * pad,) + tail)
+        dist.all_gather_into_tensor(out, send, group=group)
     if all(s == pad for s in sizes):
         return out
     keep = torch.cat([torch.arange(r * pad, r * pad + s) for r, s in enumerate(sizes)]).to(out.device)

@@ -324,6 +324,13 @@ int fd_profile_read(fd_model* m, double* conv_ms_total, long long* conv_launches
 /* Same for the HBM-bound FIR resampling launches (fd_fir_resample inside the model): total time, launches and algorithmic
  * bytes (input read once + every output written once) since fd_profile_enable. */
 int fd_profile_read_fir(fd_model* m, double* ms_total, long long* launches, double* bytes_total);
+/* Front / back end (ComplexSTFT + compression, feature_extractors.py:86-139): per-kernel time of the LAST forward and the last
+ * inverse transform recorded while profiling was on, ms6 = {absmax + framing, forward DFT GEMM, compression, decompression,
+ * inverse DFT GEMM, overlap-add}; calls2 = number of forward / inverse calls seen.  The plan-level pair does the same for a
+ * caller-owned plan (fd_stft_compress / fd_decompress_istft); fd_profile_enable switches it on for the model's own plan. */
+int fd_profile_read_stft(fd_model* m, double* ms6, int* calls2);
+int fd_stft_plan_profile(fd_stft_plan* plan, int enable);
+int fd_stft_plan_profile_read(fd_stft_plan* plan, double* ms6, int* calls2);
 
 #ifdef __cplusplus
 }

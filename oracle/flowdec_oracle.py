@@ -772,10 +772,32 @@ def score_ode_enhance(net: NCSNppOracle, y: np.ndarray, prior_noise: np.ndarray,
 
 # --------------------------------------------------------------------------------------
 # (f4) adaptive Dormand-Prince 5(4) driver -- torchdyn 1.0.6 `odeint(..., solver='dopri5')` semantics RESTATED
-# (third-party, not in /root/reference: PARITY UNPINNED): Hairer initial step, FSAL stages, error ratio in the
-# Hairer norm sqrt(mean |e / (atol + rtol max(|x|, |x_new|))|^2), step factor min(10, max(0.9 ratio^(-1/5), 0.2 | 1)),
-# checkpoints of t_span hit exactly by shortening the step (no interpolation).  What IS checked: the tableau /
-# controller integrate test problems to tolerance and agree with scipy's RK45 (tests/test_oracle_golden.py).
+# (third-party: requirements.txt:53 `torchdyn==1.0.6`, not in /root/reference and not installable offline: PARITY UNPINNED).
+# Call site: flowdec/model.py:511-514 `NeuralODE(node_fn, solver=solver, sensitivity="adjoint").trajectory(x0, t_span)`.
+# Every constant below, with the place in the torchdyn 1.0.6 source tree it restates, so that a reader WITH the package can
+# check it line by line (paths relative to site-packages/torchdyn/):
+#   tableau c, A, b5, b4         numerics/solvers/_constants.py `construct_dopri5` -- the classical Dormand-Prince 5(4) pair, 7 stages,
+#                                FSAL (stage 7 is evaluated at the 5th-order solution and becomes k1 of the next step)
+#   order = 5                    numerics/solvers/ode.py `DormandPrince45.__init__` (super().__init__(order=5, stepping_class='adaptive'))
+#   safety = 0.9, min_factor = 0.2, max_factor = 10        same class: `self.safety, self.min_factor, self.max_factor`
+#   error norm                   numerics/utils.py `hairer_norm`: tensor.abs().pow(2).mean().sqrt() over ALL elements of the state
+#                                (for a complex state: mean of |z|^2 over complex elements)
+#   scaled error                 numerics/odeint.py `_adaptive_odeint`: x_err / (atol + rtol * max(|x|, |x_new|)), accept iff norm <= 1
+#   step update                  numerics/utils.py `adapt_step`: ratio == 0 -> dt * max_factor; ratio < 1 -> min_factor := 1;
+#                                dt * min(max_factor, max(safety / ratio^(1/order), min_factor))            [exponent 1/5, not 1/(order+1)]
+#   initial step                 numerics/utils.py `init_step` (Hairer II.4): scale = atol + |x0| rtol; d0 = ||x0/scale||, d1 = ||f0/scale||;
+#                                h0 = 1e-6 if d0 < 1e-5 or d1 < 1e-5 else 0.01 d0/d1; one extra evaluation f(t0 + h0, x0 + h0 f0);
+#                                d2 = ||(f1 - f0)/scale|| / h0; h1 = max(1e-6, 1e-3 h0) if d1, d2 <= 1e-15 else (0.01 / max(d1, d2))^(1/(order+1));
+#                                dt = min(100 h0, h1)                                                       [exponent 1/6 here]
+#   checkpoints                  `_adaptive_odeint` without interpolator: when t + dt would pass t_span[i] the step is shortened to land
+#                                on it exactly ("save old dt, raise checkpoint flag"), and dt_old - dt is restored before `adapt_step`
+#   tolerances                   `NeuralODE.__init__` (core/neuralde.py) forwards its own atol / rtol.  SURVEY section 8(c) records them as
+#                                1e-4; the builder's recollection of 1.0.6 is atol = rtol = 1e-3 for NeuralODE (1e-4 being `ODEProblem`'s
+#                                and the adjoint's).  Neither can be checked offline: `enhance(..., solver='dopri5', atol=, rtol=)` takes them
+#                                as arguments (default 1e-4, the tighter of the two) and profiles/r03_bench_cfg5_dopri5*.json has both.
+#   t, dt                        float32 tensors (t_span = torch.linspace(0, 1, N + 1), model.py:513); the state keeps its dtype
+# What IS checked offline: the tableau / controller integrate test problems to tolerance and agree with scipy's RK45
+# (tests/test_oracle_golden.py::test_dopri5_driver_against_scipy); the HIP driver follows this restatement (fixture g16).
 # --------------------------------------------------------------------------------------
 DOPRI5_C = (0.0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0)
 DOPRI5_A = ((), (1 / 5,), (3 / 40, 9 / 40), (44 / 45, -56 / 15, 32 / 9), (19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729),

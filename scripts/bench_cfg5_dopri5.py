@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""BASELINE config 5 as written, per-GPU shard: FlowDec-75m, 8 x 4 s clips (of the 64 x 4 s global batch over 8 GPUs), the
+"32-step adaptive" solver = torchdyn's dopri5 over t_span = linspace(0, 1, 33) at the NeuralODE defaults atol = rtol = 1e-4
+(flowdec/model.py:511-514), in fp32 (the config's dtype) and in `bf16x3` (f32 tolerances on the bf16 matrix cores).
+Reports wall time, realised NFE and the waveform agreement of the two precisions -> gpurun_out/bench_cfg5_dopri5.json
+(committed as profiles/r03_bench_cfg5_dopri5.json).   python scripts/bench_cfg5_dopri5.py [--clips 8] [--seconds 4] [--tol 1e-4]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import flowdec_amd  # noqa: E402
+
+
+def build(precision):
+    m = flowdec_amd.from_preset("flowdec_75m", precision=precision)
+    g = torch.Generator().manual_seed(1234)
+    sd = {}
+    for k, v in m.state_dict().items():
+        if not k.startswith("backbone."):
+            continue
+        if k.endswith(".W"):
+            sd[k] = torch.randn(v.shape, generator=g) * 16.0
+        elif v.ndim == 1 and k.endswith("weight"):
+            sd[k] = 1.0 + 0.1 * torch.randn(v.shape, generator=g)
+        elif k.endswith("bias"):
+            sd[k] = 0.05 * torch.randn(v.shape, generator=g)
+        else:
+            sd[k] = torch.randn(v.shape, generator=g) / v[0].numel() ** 0.5
+    m.load_state_dict(sd, strict=False)
+    return m.cuda()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--clips", type=int, default=8)
+    ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--N", type=int, default=32)
+    ap.add_argument("--tol", type=float, default=1e-4)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "bench_cfg5_dopri5.json"))
+    a = ap.parse_args()
+    Lw = int(a.seconds * 48000)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    y = 0.1 * torch.randn(a.clips, 1, Lw, device="cuda", generator=gen)
+    Tp = 64 * ((1 + Lw // 384 + 63) // 64)
+    nz = torch.randn(a.clips, 1, 768, Tp, dtype=torch.complex64, device="cuda", generator=gen)
+    res = {"config": f"BASELINE cfg 5 per-GPU shard: FlowDec-75m, {a.clips} x {a.seconds:g} s, dopri5 over linspace(0,1,{a.N + 1}), atol = rtol = {a.tol:g}",
+           "runs": {}}
+    waves = {}
+    for prec in ("bf16x3", "fp32"):
+        m = build(prec)
+        m.enhance(y[:1, :, :48000], N=1, solver="euler")      # pack / warm up outside the clock
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = m.enhance(y, N=a.N, solver="dopri5", noise=nz, atol=a.tol, rtol=a.tol)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        waves[prec] = out
+        # the fixed-step reading of "32-step": Euler N = 32 (NFE 32) for scale
+        t1 = time.perf_counter()
+        eul = m.enhance(y, N=a.N, solver="euler", noise=nz)
+        torch.cuda.synchronize()
+        dte = time.perf_counter() - t1
+        res["runs"][prec] = {"seconds": dt, "nfe": m.last_nfe, "audio_seconds_per_second": a.clips * a.seconds / dt, "ms_per_nfe": 1e3 * dt / m.last_nfe,
+                             "finite": bool(torch.isfinite(out).all()), "euler32_seconds": dte, "euler32_audio_seconds_per_second": a.clips * a.seconds / dte,
+                             "dopri5_vs_euler32_rel_l2": float((out - eul).norm() / eul.norm())}
+        print(prec, res["runs"][prec], flush=True)
+        del m
+        torch.cuda.empty_cache()
+    d = float((waves["bf16x3"] - waves["fp32"]).norm() / waves["fp32"].norm())
+    res["bf16x3_vs_fp32_rel_l2"] = d
+    res["fp32_waveform_tolerance"] = 5e-4
+    res["agree"] = d < 5e-4 or res["runs"]["fp32"]["nfe"] != res["runs"]["bf16x3"]["nfe"]
+    res["note"] = ("the two precisions take the same accept / reject decisions when their NFE agree; then the waveforms must agree at the fp32 "
+                   "tolerance.  A different NFE means one controller decision flipped (error ratio within rounding of 1): both are valid "
+                   "solutions at the requested tolerance and differ by O(tol).")
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    with open(a.out, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

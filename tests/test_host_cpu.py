@@ -127,6 +127,37 @@ full = sharded_apply(fn, y)
 assert full.shape == y.shape and torch.equal(full, fn(y)), "sharded result differs from the single-process result"
 empty = sharded_apply(fn, y[:1])                 # fewer clips than ranks: one rank idles
 assert torch.equal(empty, fn(y[:1]))
+
+# sharded_enhance: N ranks == one process, bit for bit, for every way of defining the initial noise.  The model is a stand-in
+# with the FlowModel surface sharded_enhance uses (device, feature_extractor._cfg(), enhance(y, N, solver, noise)); the real
+# one needs a GPU (tests/test_hip_dist.py).
+from flowdec_amd.dist import clip_noise, sharded_enhance
+class FE:
+    def _cfg(self): return dict(n_fft=30, hop=8, alpha=0.3, beta=0.33)
+class Stub:
+    device = torch.device("cpu"); feature_extractor = FE(); calls = []
+    def enhance(self, yb, N=50, solver="euler", noise=None, **kw):
+        assert noise.shape == (yb.shape[0], 1, 16, 64) and noise.dtype == torch.complex64, noise.shape
+        self.calls.append(yb.shape[0])
+        return yb * N + noise.real.mean(dim=(1, 2, 3)).reshape(-1, 1, 1) + (1.0 if solver == "midpoint" else 0.0)
+m = Stub()
+y = torch.randn(5, 1, 100)
+nz = torch.randn(5, 1, 16, 64, dtype=torch.complex64)
+ref = m.enhance(y, N=3, solver="midpoint", noise=nz)
+out = sharded_enhance(m, y, N=3, solver="midpoint", noise=nz)
+assert torch.equal(out, ref), "noise= mode"
+ref = m.enhance(y, N=2, noise=torch.stack([clip_noise(77, i, (1, 16, 64), "cpu") for i in range(5)]))
+st = {}
+assert torch.equal(sharded_enhance(m, y, N=2, seed=77, stats=st), ref), "seed= mode: clip i draws from stream (seed, i)"
+assert st["local_s"] >= 0 and st["gather_s"] > 0
+g1 = torch.Generator().manual_seed(5); g2 = torch.Generator().manual_seed(5)
+ref = m.enhance(y, N=2, noise=torch.randn((5, 1, 16, 64), dtype=torch.complex64, generator=g1))
+assert torch.equal(sharded_enhance(m, y, N=2, generator=g2), ref), "generator= mode: full draw, sliced"
+a = sharded_enhance(m, y, N=2); b = sharded_enhance(m, y, N=2)      # nothing given: rank 0's seed is broadcast
+ga = [torch.empty_like(a) for _ in range(2)]; dist.all_gather(ga, a)
+assert torch.equal(ga[0], ga[1]) and not torch.equal(a, b), "default: all ranks agree on a fresh seed per call"
+one = sharded_enhance(m, y[:1], N=2, seed=1)      # one clip, two ranks: rank 1 idles but still gathers
+assert one.shape == (1, 1, 100) and torch.equal(one, m.enhance(y[:1], N=2, noise=clip_noise(1, 0, (1, 16, 64), "cpu")[None]))
 dist.barrier(); dist.destroy_process_group()
 print("rank", os.environ["RANK"], "ok")
 '''
@@ -163,6 +194,14 @@ def test_bench_self_launch_gloo_world2():
                         "--warmup", "0", "--seconds", "0.01", "--global-batch", "5"], env=env, capture_output=True, text=True, timeout=300)
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 5 and res["scaling"] == "strong"
+    # BASELINE config 4's shape arithmetic: 256 clips over the ranks (2 here, 8 on the node), strong scaling
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub-step", "--steps", "1",
+                        "--warmup", "0", "--seconds", "0.01", "--global-batch", "256", "--N", "3", "--solver", "midpoint"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 256 and res["config"]["clips_per_rank"] == [128, 128]
+    assert res["scaling"] == "strong" and res["config"]["nfe"] == 6 and abs(res["value"] * res["ms_per_step"] * 1e-3 - 256 * 0.01) < 1e-6
 
 
 def test_bench_refuses_missing_gpus():

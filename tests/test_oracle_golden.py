@@ -249,3 +249,26 @@ def test_dopri5_driver_against_scipy():
     # looser tolerance -> fewer evaluations, still inside that tolerance
     x1, nfe1 = O.odeint_dopri5(f, x0, O.linspace_f32(0.0, 1.0, 2), atol=1e-3, rtol=1e-3)
     assert nfe1 < nfe and rel_err(x1, sol.y[:, -1]) < 5e-3
+
+
+def test_torch_oracle_matches_numpy_oracle_and_golden():
+    """oracle/flowdec_oracle_torch.py (the oracle's graph + solver on torch CPU kernels: bench.py's same-box `cpu_baseline`) is
+    pinned like the NumPy oracle: forward against the reference's NCSNpp (G8), enhance against the reference's
+    FlowModel.enhance (G9, three solvers), the polyphase FIR pair against upfirdn2d (G4) -- at the fp32 tolerances."""
+    import torch
+    from oracle import flowdec_oracle_torch as OT
+    g = load_golden("g8_ncsnpp_nf8.npz")
+    net = OT.NCSNppTorchCPU(O.random_state_dict(seed=int(g["seed"]), nf=8), nf=8)
+    out = net.forward(torch.from_numpy(g["x"]), torch.from_numpy(g["y"]), torch.tensor([0.25])).numpy()
+    assert rel_err(out, g["out_t025"]) < 2e-5
+    out2 = net.forward(torch.from_numpy(g["x"]), torch.from_numpy(g["y"]), torch.from_numpy(g["t"]).float().reshape(-1)).numpy() if g["t"].size == 2 else None
+    if out2 is not None:
+        assert rel_err(out2, g["out_t01_09"]) < 2e-5
+    x = np.random.default_rng(0).standard_normal((2, 3, 12, 8)).astype(np.float32)
+    assert rel_err(OT.upsample_2d(torch.from_numpy(x)).numpy(), O.upsample_2d(x)) < 1e-6
+    assert rel_err(OT.downsample_2d(torch.from_numpy(x)).numpy(), O.downsample_2d(x)) < 1e-6
+    g9 = load_golden("g9_enhance_nf8.npz")
+    net = OT.NCSNppTorchCPU(O.random_state_dict(seed=int(g9["seed"]), nf=8), nf=8)
+    for solver, N in (("euler", 6), ("midpoint", 3), ("heun2", 3)):
+        got = OT.enhance(net, g9["y"], g9["noise"], g9["sigma_y"], N=N, solver=solver)
+        assert rel_err(got, g9[f"{solver}_N{N}"]) < 1e-4, solver
