@@ -49,8 +49,17 @@ def cpu_baseline():
     y = (0.1 * rng.standard_normal((1, 1, 48000))).astype(np.float32)
     Tp = O.padded_frames(O.num_frames(48000))
     noise = ((rng.standard_normal((1, 1, 768, Tp)) + 1j * rng.standard_normal((1, 1, 768, Tp))) / np.sqrt(2)).astype(np.complex64)
-    threads = torch.get_num_threads()
-    OT.enhance(net, y, noise, 0.66, N=1, solver="euler")
+    # thread count: torch's default (= physical cores) is not the fastest on a many-core host (measured on the round-3 box, EPYC 9575F:
+    # 128 threads 32.6 s per enhance); one warm 1-NFE probe per candidate, the full run with the fastest
+    probe = {}
+    for nt in sorted({torch.get_num_threads(), 64, 32, 16} & set(range(1, torch.get_num_threads() + 1)), reverse=True):
+        torch.set_num_threads(nt)
+        OT.enhance(net, y, noise, 0.66, N=1, solver="euler")          # warm-up: thread pool, oneDNN primitive cache
+        t0 = time.perf_counter()
+        OT.enhance(net, y, noise, 0.66, N=1, solver="euler")
+        probe[nt] = time.perf_counter() - t0
+    threads = min(probe, key=probe.get)
+    torch.set_num_threads(threads)
     t0 = time.perf_counter()
     out = OT.enhance(net, y, noise, 0.66, N=6, solver="euler")
     dt = time.perf_counter() - t0
@@ -62,7 +71,8 @@ def cpu_baseline():
     except OSError:
         pass
     sample = (f"BASELINE config 1 in full (1 clip x 1 s, 6-step Euler = 6 NFE of the full-width NCSN++ + STFT/iSTFT, fp32), oracle on PyTorch CPU "
-              f"kernels (oracle/flowdec_oracle_torch.py): {dt:.2f} s per enhance on {threads} threads of {os.cpu_count()} logical cores ({cpu})")
+              f"kernels (oracle/flowdec_oracle_torch.py): {dt:.2f} s per enhance on {threads} threads of {os.cpu_count()} logical cores ({cpu}); "
+              f"1-NFE probe per thread count: " + ", ".join(f"{k}: {v:.2f} s" for k, v in sorted(probe.items())))
     ref = os.path.join(ROOT, "profiles", REF_CPU_FILE)
     if os.path.exists(ref):   # the reference implementation itself, measured in the build container (it cannot travel to this box)
         with open(ref) as f:

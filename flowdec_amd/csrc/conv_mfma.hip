@@ -32,6 +32,15 @@
 //   MIXED = 1 / 2     f32 storage around bf16 operands: rounded once at the LDS store (FD_BF16_OPERANDS), or split as hi + lo with three
 //                     MFMAs per product (FD_BF16X3_OPERANDS: the f32-tolerance mode on the bf16 matrix cores);
 //   SH                one halo buffer instead of two: 70 KiB of LDS, two workgroups per CU (FD_TILE_DUO128; measured, not scheduled).
+//   RE                "register epilogue, continuous tiles" (round 3; bf16, Cout == BN, whole tiles, no residual input): ONE workgroup per
+//                     CU walks a contiguous range of pixel tiles as one uninterrupted software pipeline -- the weight stream wraps around
+//                     to slab 0 and the last chunk of tile i prefetches / activates / publishes the first halo of tile i + 1, so a tile
+//                     boundary has no prologue (no exposed memory round trip, no ring refill).  The epilogue never touches LDS staging:
+//                     bias / scale / bf16 rounding happen on the accumulator registers, v_permlane32_swap pairs the two 4-cout halves of
+//                     a pixel so that every lane stores 16 contiguous bytes, the stores are left in flight (the first barrier of the next
+//                     tile waits with a COUNTED vmcnt), and the GroupNorm partial sums are reduced over the 32 pixel lanes with
+//                     v_permlane16_swap + 4 DPP steps.  Same K order per output and the same (acc + bias) * scale arithmetic: the
+//                     convolution result is bit-identical to the staged epilogue; the statistics differ in summation order only.
 #include <string.h>
 
 #include <mutex>
@@ -95,6 +104,16 @@ __device__ __forceinline__ u32x4 transform_slot(u32x4 raw, const char* ad) {
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
+// v + (v of the lane DPP control CTRL selects): one v_add_f32_dpp
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  bf16x2 r = {(bf16)a, (bf16)b};
+  return __builtin_bit_cast(unsigned, r);
+}
+
 // MIXED configurations (f32 storage, bf16 MFMA operands): the 8 channels of one LDS slot are 32 bytes of f32 in memory; they are
 // activated in f32 and rounded to bf16 HERE, at the LDS store -- the only rounding of the residual stream on its way into a conv.
 // low = true: the SECOND term of the two-term bf16 split y = bf16(y) + bf16(y - bf16(y)) (SPLIT configurations, see below).
@@ -121,7 +140,7 @@ __device__ __forceinline__ u32x4 wide_slot(u32x4 lo, u32x4 hi, const char* ad, b
 // CW ("chunk-resident weights", the low-latency configuration): the ring holds the slabs of TWO whole chunks (18 slots), the K loop
 // has ONE barrier per chunk and every slab is requested a full chunk before its first use -- on a small grid the tap-pair ring below
 // makes every barrier group wait for one memory round trip (measured: 31 us for a 256 -> 256 convolution whatever the tile width).
-template <int WM, int WN, int MT, int NT, bool CW = false, bool SH = false>
+template <int WM, int WN, int MT, int NT, bool CW = false, bool SH = false, bool RE = false>
 struct Geo {
   static constexpr int NTH = 64 * WM * WN;
   static constexpr int NP = WM * MT;       // 4x8-pixel patches per tile, arranged (NP/2) x 2
@@ -146,7 +165,13 @@ struct Geo {
   static constexpr int PPASS = NTH / OCT;        // pixels per epilogue pass
   static constexpr int NPASS = EP_PIX / PPASS;
   static constexpr int ST_BYTES = PPASS * OCT * 80;   // statistics staging: 80-byte records (see the end of the kernel)
-  static constexpr int LDS_BYTES = cmax(MAIN_BYTES, cmax(2 * EP_BYTES, ST_BYTES));   // epilogue staging is double-buffered
+  // RE: no epilogue staging; a second affine table (the prefetch runs one image ahead of the MFMAs at an image boundary) and the
+  // cross-wave scratch of the statistics, both in LDS that neither the halo stores nor the weight DMA ever write
+  static constexpr int SCR_BYTES = WM * BN * 8;     // [WM][BN][{sum, sumsq}] f32
+  static constexpr int BIAS_BYTES = 2 * BN * 4;     // [image parity][BN] f32 (the epilogue reads its bias through LDS: a global load
+                                                    // there would order itself behind the output stores still in flight)
+  static constexpr int LDS_BYTES = RE ? MAIN_BYTES + AFF_BYTES + SCR_BYTES + BIAS_BYTES
+                                      : cmax(MAIN_BYTES, cmax(2 * EP_BYTES, ST_BYTES));   // epilogue staging is double-buffered
   static constexpr int DMA_PER_WAVE = (W_LDS / 1024 + NTH / 64 - 1) / (NTH / 64);  // DMA instructions per wave per slab
   static constexpr int PPP = NTH / 4;            // rows covered per loader pass (4 slots per row)
   static constexpr int HITER = (HH * HW + PPP - 1) / PPP;
@@ -168,10 +193,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 // ~1e-5 per product instead of bf16's 4e-3 -- the f32-tolerance mode at 3x the bf16 MFMA work instead of the f32 MFMA's 16x).  A K
 // step is then 16 channels: LDS row = [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15], so the two "k-halves" of the pipeline below are
 // the hi and the lo fragments of the step.
-template <typename T, int WM, int WN, int MT, int NT, bool SKIP, bool CW = false, int MIXED = 0, bool SH = false>
+template <typename T, int WM, int WN, int MT, int NT, bool SKIP, bool CW = false, int MIXED = 0, bool SH = false, bool RE = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) {
-  using G = Geo<WM, WN, MT, NT, CW, SH>;
+  using G = Geo<WM, WN, MT, NT, CW, SH, RE>;
   static_assert(!SH || (!CW && MIXED == 0), "single-halo configuration: plain storage, tap-pair ring");
+  static_assert(!RE || (!SKIP && !CW && !SH && MIXED == 0 && sizeof(T) == 2), "register-epilogue configuration: bf16, tap-pair ring, no residual input");
   using TS = std::conditional_t<MIXED != 0, float, T>;   // storage type of activations / residual / output (T: MFMA operand type)
   constexpr bool SPLIT = MIXED == 2;
   static_assert(!MIXED || sizeof(T) == 2, "MIXED = f32 storage around bf16 MFMA operands");
@@ -193,13 +219,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
     lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   }
-  const int nt_i = lid % p.tiles_n;
-  int pt = lid / p.tiles_n;
-  const int tw_i = pt % p.tiles_w; pt /= p.tiles_w;
-  const int th_i = pt % p.tiles_h;
-  const int b = pt / p.tiles_h;
-  const int h0 = th_i * G::TH, w0 = tw_i * G::TW, n0 = nt_i * G::BN;
   const int H = p.H, W = p.W;
+  // RE: this workgroup owns the contiguous tile range [tile_cur, tile_end) of the (b, tile row, tile column) order (tiles_n == 1)
+  int tile_cur = lid, tile_end = lid + 1;
+  if constexpr (RE) {
+    const long long ntl = (long long)p.B * p.tiles_h * p.tiles_w;
+    tile_cur = (int)(ntl * lid / nblk);
+    tile_end = (int)(ntl * (lid + 1) / nblk);
+  }
+  int b, th_i, tw_i, h0, w0;   // the tile the MFMAs / the epilogue work on
+  const int n0 = RE ? 0 : (lid % p.tiles_n) * G::BN;
+  auto decode_tile = [&](int tl, int& b_, int& th_, int& tw_) {
+    int pt = RE ? tl : tl / p.tiles_n;
+    tw_ = pt % p.tiles_w; pt /= p.tiles_w;
+    th_ = pt % p.tiles_h;
+    b_ = pt / p.tiles_h;
+  };
+  decode_tile(tile_cur, b, th_i, tw_i);
+  h0 = th_i * G::TH; w0 = tw_i * G::TW;
 
   const int t = threadIdx.x;
   const int q = t & 3;        // 16-byte slot inside the 64-byte chunk row
@@ -207,20 +244,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 
   // ---- loader bookkeeping.  Loads are unconditional (clamped addresses); validity is applied when the
   // registers are written to LDS. ----------------------------------------------------------------------------
-  int pixl[G::HITER];   // clamped pixel index inside image b
+  int pixl[G::HITER];   // clamped pixel index inside the loader's image
   int hlds[G::HITER];   // LDS byte offset of the slot
   unsigned pvalid = 0, hexist = 0;
+  int lb = b;           // image the LOADER works on (RE: one chunk ahead of the MFMAs, i.e. possibly already the next tile's)
+  auto set_loader_tile = [&](int lh0, int lw0) {
+    pvalid = 0; hexist = 0;
 #pragma unroll
-  for (int i = 0; i < G::HITER; ++i) {
-    const int hp = prow + i * G::PPP;
-    const int hpc = hp < G::HH * G::HW ? hp : 0;
-    const int hr = hpc / G::HW, hc = hpc - hr * G::HW;
-    const int gh = h0 - 1 + hr, gw = w0 - 1 + hc;
-    const bool ok = gh >= 0 && gh < H && gw >= 0 && gw < W;
-    pixl[i] = ok ? gh * W + gw : 0;
-    hlds[i] = (hr * PITCH + hc) * ROWB + q * 16;
-    if (hp < G::HH * G::HW) { hexist |= 1u << i; if (ok) pvalid |= 1u << i; }
-  }
+    for (int i = 0; i < G::HITER; ++i) {
+      const int hp = prow + i * G::PPP;
+      const int hpc = hp < G::HH * G::HW ? hp : 0;
+      const int hr = hpc / G::HW, hc = hpc - hr * G::HW;
+      const int gh = lh0 - 1 + hr, gw = lw0 - 1 + hc;
+      const bool ok = gh >= 0 && gh < H && gw >= 0 && gw < W;
+      pixl[i] = ok ? gh * W + gw : 0;
+      hlds[i] = (hr * PITCH + hc) * ROWB + q * 16;
+      if (hp < G::HH * G::HW) { hexist |= 1u << i; if (ok) pvalid |= 1u << i; }
+    }
+  };
+  set_loader_tile(h0, w0);
   const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
   const size_t img_elems = (size_t)H * W;
 
@@ -233,13 +275,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   bool nchan_ok = false;
   auto next_chunk = [&](int s, int ch) {
     const Seg sg = p.seg[s];
-    const TS* src = reinterpret_cast<const TS*>(sg.src) + (size_t)b * img_elems * sg.C;
+    const TS* src = reinterpret_cast<const TS*>(sg.src) + (size_t)lb * img_elems * sg.C;
     nsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<TS*>(src), 0, (int)(img_elems * sg.C * sizeof(TS)), 0x00020000);
     nC = sg.C;
     const int c = SPLIT ? ch * CK + (q & 1) * 8 : ch * CK + q * EPS;   // SPLIT: slots 0,1 = hi, 2,3 = lo of the same 16 channels
     nchan_ok = c < sg.C;
     nc = nchan_ok ? c : 0;
-    naff = sg.aff_off >= 0 ? (sg.aff_off + nc) * 8 : -1;  // byte offset of this slot's (a,d) pairs in the LDS table
+    naff = sg.aff_off >= 0 ? (sg.aff_off + nc) * 8 + (RE ? (lb & 1) * AFF_BYTES : 0) : -1;  // byte offset of this slot's (a,d) pairs in the LDS table (RE: one table per image parity)
   };
 #ifndef FD_HALO_AUX
 #define FD_HALO_AUX 0
@@ -329,6 +371,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
+  // RE: the first barrier after a register epilogue.  In flight, oldest first: the last weight DMAs of the previous tile (needed now),
+  // then the epilogue's output stores (RE_NST per wave) and possibly one statistics store -- those may stay in flight.
+  constexpr int RE_NST = MT * NT * 2;
+  int pend_st = 0;   // stores of the last epilogue that the next barrier need not wait for (wave-uniform; 0 = none)
+  auto block_sync_after_epilogue = [&]() {
+    if (pend_st == RE_NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RE_NST) : "memory");
+    else if (pend_st == RE_NST + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RE_NST + 1) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pend_st = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
   // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence as well: it waits for vmcnt(0), i.e. for
   // every global STORE issued so far to be acknowledged, which in the epilogue exposes a full memory round trip per
   // staging round (the output stores of the previous round) for no reason -- nothing read here depends on them.
@@ -407,7 +462,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     for (int nj = 0; nj < (SPLIT ? NT : 0); ++nj) wfA[nj] = wfC[nj];
   };
 
-  int step = 0, hcur = 0;   // step = running (chunk, tap) index = index of the weight slab in K order
+  int step = 0, hcur = 0;   // step = running (chunk, tap) index = index of the weight slab in K order (RE: running over ALL tiles of the
+                            // workgroup -- it only names ring slots; `lstep` counts inside the tile)
+  int lstep = 0;
   int fetch = 0;            // CW: next slab to DMA; slab i lives in ring slot i % NWBUF
   const int last_step = nsteps - 1;
   auto slot_of = [&](int i) { return wbuf + (i % G::NWBUF) * G::W_LDS; };
@@ -417,8 +474,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // walks the slabs in K order and the per-lane part of the address never changes, so a slab costs two scalar adds; the pointer
   // simply runs past the last slab (fd_conv_packed_bytes pads the buffer by NWBUF slabs: what lands is never read).
   constexpr unsigned WOFF = G::NHB * G::HALO_BYTES;   // LDS byte offset of the ring
-  const char* wfetch = reinterpret_cast<const char*>(p.w) + (size_t)n0 * WROWB;
+  const char* const wfetch0 = reinterpret_cast<const char*>(p.w) + (size_t)n0 * WROWB;
+  const char* wfetch = wfetch0;
   const size_t slab_stride = (size_t)p.CoutPad * WROWB;
+  int fleft = nsteps;   // RE: slabs left in this tile's stream; then the pointer wraps to slab 0 = the next tile's first step
   int dma_pce[G::DMA_PER_WAVE];        // the 1-KiB pieces of a slab this wave copies (wave-uniform)
   unsigned dma_voff[G::DMA_PER_WAVE];  // per-lane byte offset inside the slab
   {
@@ -435,6 +494,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wfetch + dma_voff[j]),
                                        (__attribute__((address_space(3))) void*)(smem + dst_off + dma_pce[j] * 1024), 16, 0, 0);
     wfetch += slab_stride;
+    if constexpr (RE) {
+      if (--fleft == 0) { wfetch = wfetch0; fleft = nsteps; }
+    }
     asm volatile("" : "+s"(wfetch));   // keep the walk scalar and sequential (hipcc otherwise pre-computes the vector addresses of a whole chunk)
   };
   auto fetch_slabs = [&](int n) {   // CW only
@@ -452,9 +514,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #pragma unroll
     for (int k = 0; k < G::NWBUF; ++k) fetch_to(WOFF + k * G::W_LDS);
   }
-  if (p.affine) {  // affine table of image b: [affC] x (a, d)
-    const float* ap = p.affine + (size_t)b * p.affC * 2;
-    for (int i = t; i < p.affC / 2; i += G::NTH) *reinterpret_cast<f32x4*>(afftab + i * 16) = *reinterpret_cast<const f32x4*>(ap + i * 4);
+  auto load_afftab = [&](int img) {   // affine table of image `img`: [affC] x (a, d)   (RE: into the table of the image's parity)
+    const float* ap = p.affine + (size_t)img * p.affC * 2;
+    char* dst = afftab + (RE ? (img & 1) * AFF_BYTES : 0);
+    for (int i = t; i < p.affC / 2; i += G::NTH) *reinterpret_cast<f32x4*>(dst + i * 16) = *reinterpret_cast<const f32x4*>(ap + i * 4);
+  };
+  char* const scratch = afftab + 2 * AFF_BYTES;                 // RE only (see Geo::LDS_BYTES)
+  char* const biastab = scratch + G::SCR_BYTES;
+  // (RE) uniform buffer resources of the statistics output and of the bias: see the statistics store in the epilogue
+  const __amdgpu_buffer_rsrc_t stsrd = __builtin_amdgcn_make_buffer_rsrc(p.stats, 0, RE && p.stats ? (int)((size_t)p.B * p.tiles_h * p.tiles_w * p.CoutPad * 8) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t bisrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, RE && p.bias ? (p.bias_rows > 1 ? p.B : 1) * p.Cout * 4 : 0, 0x00020000);
+  auto load_biastab = [&](int img) {   // RE: bias row of image `img` -> LDS table of the image's parity (zeros without a bias: out-of-range reads return 0)
+    for (int i = t; i < G::BN; i += G::NTH)
+      reinterpret_cast<float*>(biastab)[(img & 1) * G::BN + i] =
+          __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bisrd, (n0 + i) * 4, (p.bias_rows > 1 ? img : 0) * p.Cout * 4, 0));
+  };
+  if constexpr (RE) load_biastab(b);
+  if (p.affine) {
+    load_afftab(b);
     __syncthreads();
   }
 #pragma unroll
@@ -476,6 +553,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // site pair: with both tap counts inside one loop the compiler keeps two copies of the 128-register accumulator.
   // The phases are straight-line code: work past the end of the K loop (the DMA / halo prefetch / fragment reads of the
   // last steps) is not branched around but redirected to harmless targets (re-load of the last slab / the current chunk).
+  // RE: the loader moves on to the workgroup's NEXT tile while the MFMAs work on the last chunk of this one
+  auto loader_to_next_tile = [&]() {
+    int nb, nth, ntw;
+    decode_tile(tile_cur + 1, nb, nth, ntw);
+    if (nb != lb && p.affine) load_afftab(nb);   // into the other parity's table; published by the barriers before its first use (tap 3)
+    lb = nb;
+    set_loader_tile(nth * G::TH, ntw * G::TW);
+    cs = 0; cch = 0;
+    next_chunk(0, 0);
+  };
+  for (;;) {   // tile loop: a single pass unless RE
   if constexpr (CW) {
     // Low-latency K loop.  With few MFMAs per phase the two-set pipeline above is a pure latency chain (the MFMAs of phase p + 1
     // wait for reads issued one MFMA pair earlier: ~350 cycles per phase whatever the tile width, measured); here the fragments
@@ -535,8 +623,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   } else
   for (int i = 0; i < n9; ++i) {
     const bool last_chunk = (i == n9 - 1) && n1 == 0;
-    if (!last_chunk) { advance(cs, cch); next_chunk(cs, cch); }   // else: the prefetch of this chunk is unused
-    else npix_on = 0;
+    if (!last_chunk) { advance(cs, cch); next_chunk(cs, cch); }
+    else if (RE && tile_cur + 1 < tile_end) loader_to_next_tile();   // the first halo of the next tile
+    else npix_on = 0;                                                  // the prefetch of this chunk is unused
     const char* hb = hbuf + hcur * G::HALO_BYTES;
     const char* hbn = hbuf + (hcur ^ 1) * G::HALO_BYTES;
     const int first_off_next = (i == n9 - 1) ? CENTER : 0;
@@ -570,7 +659,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       if (barrier_here) {
         // everything issued after the previous barrier has landed and is published; all reads of the finished group's
         // slabs are complete, so their ring slots are refilled with the next slabs in K order
-        block_sync();
+        if (RE && tap == 1) { if (pend_st) block_sync_after_epilogue(); else block_sync(); }
+        else block_sync();
         // the slabs of steps s + 3 (and s + 4): steps 0..3 were fetched by the prologue, every barrier moves on by its group size
         if (tap == 8) fetch_to(wso[0]);
         else { fetch_to(wso[(tap + 3) & 3]); fetch_to(wso[(tap + 4) & 3]); }
@@ -610,12 +700,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     if constexpr (!SH) hcur ^= 1;
   }
   for (int i = 0; i < n1; ++i) {
-    const bool m1 = step + 1 < nsteps;
+    const bool m1 = (RE ? n9 * 9 + i : step) + 1 < nsteps;
     const char* hb = hbuf + hcur * G::HALO_BYTES;
     const char* hbn = hbuf + (hcur ^ 1) * G::HALO_BYTES;
     const char* wb = slot_of(step);
     const char* wbn = slot_of(step + 1);
     if (m1) { advance(cs, cch); next_chunk(cs, cch); }
+    else if (RE && tile_cur + 1 < tile_end) loader_to_next_tile();
     else npix_on = 0;
     // the next 1-tap chunk's halo: loaded and published within this step
 #pragma unroll
@@ -648,6 +739,99 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     }
     ++step; hcur ^= 1;
   }
+  if constexpr (RE) {
+    // ---- register epilogue (see the file header).  Lane (l31, lh) of wave (wm, wn) holds, for M-tile mi and N-tile nj, the
+    // couts 8 qd + 4 lh + e (qd, e = 0..3) of pixel l31 of patch wm * MT + mi.
+    bf16* const outp = reinterpret_cast<bf16*>(p.out);
+    const float* const bt = reinterpret_cast<const float*>(biastab) + (b & 1) * G::BN;
+    float* const scr = reinterpret_cast<float*>(scratch);
+    const int row4 = lane >> 4;   // DPP row: rows 0, 1 = lh 0, rows 2, 3 = lh 1
+    const bool want_stats = p.stats != nullptr;
+#pragma unroll
+    for (int nj = 0; nj < NT; ++nj) {
+      const int cw = (wn * NT + nj) * 32;   // first cout of this MFMA tile inside the workgroup's BN
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {      // couts 16 qp .. 16 qp + 15 of the MFMA tile: qd = 2 qp (x[0..3]) and 2 qp + 1 (x[4..7])
+        float bv[8], ssum[8], ssq[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bt + cw + 16 * qp + 8 * h + 4 * lh);
+          bv[4 * h] = b4[0]; bv[4 * h + 1] = b4[1]; bv[4 * h + 2] = b4[2]; bv[4 * h + 3] = b4[3];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ssum[k] = ssq[k] = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          const int pi = wm * MT + mi;
+          const int gh = h0 + 4 * (pi >> 1) + (l31 >> 3), gw = w0 + 8 * (pi & 1) + (l31 & 7);
+          bf16* const op = outp + (((size_t)b * H + gh) * W + gw) * p.Cout + n0 + cw + 8 * lh;
+          float x[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+#pragma clang fp contract(off)
+            const float v = (acc[mi][nj][8 * qp + k] + bv[k]) * p.scale;   // the staged epilogue's arithmetic: two roundings, then bf16
+            x[k] = v;
+            ssum[k] += v;
+            ssq[k] = __builtin_fmaf(v, v, ssq[k]);
+          }
+          // v_permlane32_swap(X, Y): lanes 0-31 end with {X own, X of lane + 32}, lanes 32-63 with {Y of lane - 32, Y own}: the lh = 0
+          // lane of a pixel gets couts 0..7 of qd = 2 qp, its lh = 1 partner couts 0..7 of qd = 2 qp + 1 -- 16 contiguous bytes each
+          const auto s0 = __builtin_amdgcn_permlane32_swap(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[4], x[5]), false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(pack_bf16x2(x[2], x[3]), pack_bf16x2(x[6], x[7]), false, false);
+          *reinterpret_cast<u32x4*>(op + 16 * qp) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        }
+        if (want_stats) {
+          // sum over the 32 pixel lanes of each half-wave.  v_permlane16_swap(A, B) + add folds rows {0, 1} and {2, 3}: rows 0 / 2 then
+          // carry A (qd = 2 qp), rows 1 / 3 carry B (qd = 2 qp + 1); four DPP steps finish the 16 lanes of a row.
+          float* const sp = scr + (size_t)(wm * G::BN + cw + 16 * qp + 8 * (row4 & 1) + 4 * (row4 >> 1)) * 2;
+#pragma unroll
+          for (int which = 0; which < 2; ++which)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float A = which ? ssq[e] : ssum[e], B = which ? ssq[4 + e] : ssum[4 + e];
+              const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, A), __builtin_bit_cast(unsigned, B), false, false);
+              float r = __builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]);
+              r = dpp_add<0xB1>(r);    // quad_perm [1,0,3,2]
+              r = dpp_add<0x4E>(r);    // quad_perm [2,3,0,1]
+              r = dpp_add<0x141>(r);   // row_half_mirror
+              r = dpp_add<0x140>(r);   // row_mirror
+              if ((lane & 15) == 0) sp[e * 2 + which] = r;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one (nj, qp) group at a time: interleaving them costs more registers than the file has
+      }
+    }
+    pend_st = RE_NST;
+    if (want_stats) {
+      lds_barrier();
+      // (through a buffer resource: uniform base + tile offset in scalar registers, the per-thread part is 4 * o -- a 64-bit per-thread
+      // address would be hoisted out of the tile loop and spilled, and its reload would drain the stores just issued)
+      const int tile = th_i * p.tiles_w + tw_i;
+      const int rec = (b * p.tiles_h * p.tiles_w + tile) * p.CoutPad * 2;   // first float of this tile's record (launcher: fits 31 bits in bytes)
+      for (int o = t; o < 2 * G::BN; o += G::NTH) {   // o = 2 * channel + which
+        float a = 0.f;
+#pragma unroll
+        for (int w_ = 0; w_ < WM; ++w_) a += scr[w_ * 2 * G::BN + o];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, a), stsrd, o * 4, rec * 4, 0);
+      }
+      if (__builtin_amdgcn_readfirstlane(t) < 2 * G::BN) pend_st = RE_NST + 1;
+    }
+    if (++tile_cur >= tile_end) break;
+    {   // on to the next tile: its first halo is published, its first weight slabs are in the ring
+      int nb;
+      decode_tile(tile_cur, nb, th_i, tw_i);
+      if (nb != b) load_biastab(nb);   // (other parity; read by the NEXT epilogue, many barriers from here)
+      b = nb; h0 = th_i * G::TH; w0 = tw_i * G::TW;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < NT; ++nj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
+    read_frags(wfA, pfA, hbuf + hcur * G::HALO_BYTES, smem + WOFF + (step & 3) * G::W_LDS, 0, 0);
+    continue;
+  } else {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // all fragment reads / DMA done before the epilogue reuses the LDS
 
@@ -846,6 +1030,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     d[6] = t2_end - t2_e3;        // final barrier + statistics
   }
 #endif
+  break;
+  }   // !RE
+  }   // tile loop
 }
 
 // ---- weight packing: [Cout][Cin][k][k] f32 -> [step][CoutPad][WROWB bytes] -----------------------------------------
@@ -925,6 +1112,44 @@ int set_attr() {
   return FD_OK;
 }
 
+int g_num_cu[64] = {};   // compute units per device (fd_conv_init_attributes)
+
+template <int WM, int WN, int MT, int NT>
+int set_attr_re() {
+  using G = Geo<WM, WN, MT, NT, false, false, true>;
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<bf16, WM, WN, MT, NT, false, false, 0, false, true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+  return FD_OK;
+}
+
+// RE ("register epilogue, continuous tiles"): one persistent workgroup per compute unit, each walking a contiguous range of tiles.
+template <int WM, int WN, int MT, int NT>
+bool re_applies(const ConvArgs& a) {
+  using G = Geo<WM, WN, MT, NT, false, false, true>;
+#ifdef FD_NO_RE
+  return false;
+#endif
+  if (a.skip || a.Cout != G::BN || a.H % G::TH || a.W % G::TW) return false;
+  if ((long long)a.B * (a.H / G::TH) * (a.W / G::TW) * a.CoutPad * 8 >= (1ll << 31)) return false;   // statistics addressed through one buffer resource
+  bool has9 = false;
+  for (int s = 0; s < a.nseg; ++s) has9 = has9 || a.seg[s].taps == 9;
+  return has9;
+}
+template <int WM, int WN, int MT, int NT>
+int launch_conv_re(ConvArgs a, hipStream_t st) {
+  using G = Geo<WM, WN, MT, NT, false, false, true>;
+  a.tiles_h = a.H / G::TH; a.tiles_w = a.W / G::TW; a.tiles_n = 1;
+  const long long ntl = (long long)a.B * a.tiles_h * a.tiles_w;
+  FD_REQUIRE(ntl > 0 && ntl < (1ll << 31), "conv grid out of range");
+  int dev = 0;
+  FD_HIP(hipGetDevice(&dev));
+  const int ncu = dev >= 0 && dev < 64 && g_num_cu[dev] > 0 ? g_num_cu[dev] : 256;
+  const unsigned grid = (unsigned)(ntl < ncu ? ntl : ncu);
+  hipLaunchKernelGGL((conv_mfma_kernel<bf16, WM, WN, MT, NT, false, false, 0, false, true>), dim3(grid), dim3(G::NTH), G::LDS_BYTES, st, a);
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}
+
 template <typename T, int WM, int WN, int MT, int NT, bool CW = false, int MIXED = 0, bool SH = false>
 int launch_conv(ConvArgs a, hipStream_t st) {
   using G = Geo<WM, WN, MT, NT, CW, SH>;
@@ -955,6 +1180,10 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int bn_hint, bool chunk_rin
   }
   if (bn == 32) return launch_conv<T, 4, 1, 2, 1>(a, st);                                 // 4 waves, BN = 32 (pyramid heads, tiny grids)
   if (bn == 64) return launch_conv<T, 4, 2, 2, 1>(a, st);                                 // 8 waves, BN = 64
+  if constexpr (sizeof(T) == 2) {   // whole tiles, Cout == BN, no residual input: the persistent register-epilogue configuration
+    if (bn_hint == 0 && bn == 128 && re_applies<4, 2, 2, 2>(a)) return launch_conv_re<4, 2, 2, 2>(a, st);
+    if (bn_hint == 0 && bn == 256 && re_applies<2, 4, 4, 2>(a)) return launch_conv_re<2, 4, 4, 2>(a, st);
+  }
   if (bn == 128) return launch_conv<T, 4, 2, 2, 2>(a, st);                                // 8 waves, BN = 128
   return launch_conv<T, 2, 4, 4, 2>(a, st);                                               // 8 waves, BN = 256
 }
@@ -987,6 +1216,8 @@ int fd_conv_init_attributes() {
   FD_TRY((set_attr<float, 4, 1, 2, 1>())); FD_TRY((set_attr<float, 4, 2, 2, 1>())); FD_TRY((set_attr<float, 4, 2, 2, 2>())); FD_TRY((set_attr<float, 2, 4, 4, 2>()));
   FD_TRY((set_attr<bf16, 4, 1, 2, 1, false, 1>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2, false, 1>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2, false, 1>()));
   FD_TRY((set_attr<bf16, 4, 1, 2, 1, false, 2>())); FD_TRY((set_attr<bf16, 4, 2, 2, 2, false, 2>())); FD_TRY((set_attr<bf16, 2, 4, 4, 2, false, 2>()));
+  FD_TRY((set_attr_re<2, 4, 4, 2>())); FD_TRY((set_attr_re<4, 2, 2, 2>()));
+  if (known) FD_HIP(hipDeviceGetAttribute(&g_num_cu[dev], hipDeviceAttributeMultiprocessorCount, dev));
   FD_TRY(fd_wino_init_attributes());
   FD_TRY(fd_head_init_attributes());
   if (known) done_dev[dev] = true;

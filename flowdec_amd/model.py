@@ -146,6 +146,7 @@ class NCSNpp(nn.Module):
         self._stft_cfg = dict(n_fft=1534, hop=384, alpha=0.3, beta=0.33)
         self._normalize = True
         self._native_lock = threading.RLock()
+        self._last_call_done = None   # event at the end of the previous native call (see _NativeCall)
 
     # -- native handle management ----------------------------------------------------------------
     def _config_struct(self):
@@ -179,7 +180,7 @@ class NCSNpp(nn.Module):
     # the copy repacks lazily on first use
     def __getstate__(self):
         st = self.__dict__.copy()
-        st["_handle"], st["_handle_sig"], st["_ws"] = None, None, {}
+        st["_handle"], st["_handle_sig"], st["_ws"], st["_last_call_done"] = None, None, {}, None
         st.pop("_native_lock", None)
         return st
 
@@ -245,7 +246,7 @@ class NCSNpp(nn.Module):
 
     # -- reference API -----------------------------------------------------------------------------
     def forward(self, x, y, t):
-        with self._native_lock:
+        with _NativeCall(self):
             return self._forward(x, y, t)
 
     def _forward(self, x, y, t):
@@ -269,16 +270,47 @@ class NCSNpp(nn.Module):
         return out
 
 
+class _NativeCall:
+    """One native call at a time per model -- on the host AND on the device.  The packed model, its workspace, its I/O staging
+    buffers and its hipGraph cache are shared state: (i) a lock serialises the enqueueing threads (the C ABI answers a concurrent
+    call with FD_EBUSY); (ii) an event recorded at the end of every call makes the NEXT call's stream wait for it, so that two
+    callers on different streams cannot overlap on the GPU inside the shared workspace.  The reference's nn.Module can be called
+    from several threads / streams; this keeps that working -- calls queue up instead of failing or racing."""
+
+    def __init__(self, backbone):
+        self.bb = backbone
+
+    def __enter__(self):
+        bb = self.bb
+        bb._native_lock.acquire()
+        try:
+            p = next(bb.parameters())
+            self.stream = torch.cuda.current_stream(p.device) if p.is_cuda else None
+            if self.stream is not None and bb._last_call_done is not None:
+                self.stream.wait_event(bb._last_call_done)
+        except BaseException:
+            bb._native_lock.release()
+            raise
+        return self
+
+    def __exit__(self, *exc):
+        bb = self.bb
+        try:
+            if self.stream is not None:
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+                bb._last_call_done = ev
+        finally:
+            bb._native_lock.release()
+        return False
+
+
 def _serialized(fn):
-    """One native call at a time per model: the packed model, its workspace, its I/O staging buffers and its hipGraph cache are
-    shared state (the C ABI answers a concurrent call with FD_EBUSY).  The reference's nn.Module can be called from several threads;
-    this lock keeps that working -- calls queue up instead of failing."""
     import functools
 
     @functools.wraps(fn)
     def wrapper(self, *args, **kwargs):
-        bb = self if isinstance(self, NCSNpp) else self.backbone
-        with bb._native_lock:
+        with _NativeCall(self if isinstance(self, NCSNpp) else self.backbone):
             return fn(self, *args, **kwargs)
     return wrapper
 

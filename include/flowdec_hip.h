@@ -19,7 +19,10 @@
  *    fd_model holds scratch that its enqueueing calls share (time-embedding biases, hipGraph cache, side stream, profiling events):
  *    it serves ONE enqueueing call at a time.  A second thread that enters fd_ncsnpp_forward / fd_ode_solve[_adaptive] / fd_enhance /
  *    fd_score_* / fd_regression_enhance while another is inside gets FD_EBUSY (nothing is enqueued, nothing is corrupted); use one
- *    fd_model per thread for concurrent solves.  "Inside" is the host-side enqueue only -- the GPU work itself is asynchronous.
+ *    fd_model per thread for concurrent solves.  "Inside" is the host-side enqueue only -- the GPU work itself is asynchronous:
+ *    consecutive calls of one model on DIFFERENT streams must be ordered by the caller (record an event after one call, make the
+ *    next stream wait for it), because the workspace passed in and the model's own scratch (the per-step time-embedding biases)
+ *    are reused from call to call.  The Python binding does both for its callers (flowdec_amd/model.py: _NativeCall).
  */
 #ifndef FLOWDEC_HIP_H
 #define FLOWDEC_HIP_H
