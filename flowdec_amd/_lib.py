@@ -21,7 +21,7 @@ FD_BF16_OPERANDS = 0x10000  # with FD_F32: f32 storage, bf16 MFMA operands (prec
 FD_NO_SIDE_STREAM = 0x40000  # fd_model_config.act_dtype: side branches stay on the caller's stream
 FD_EBUSY = -5
 FD_BF16X3_OPERANDS = 0x20000  # with FD_F32: operands as hi + lo bf16 pairs, three bf16 MFMAs per product (precision='bf16x3')
-FD_TILE = {0: 0, 32: 0x1000, 64: 0x2000, 128: 0x3000, "64c": 0x4000, "32c": 0x5000, "duo": 0x6000}  # fd_conv2d: output channels per workgroup (0 = default)
+FD_TILE = {0: 0, 32: 0x1000, 64: 0x2000, 128: 0x3000, "64c": 0x4000, "32c": 0x5000, "duo": 0x6000, "persist": 0x7000}  # fd_conv2d: output channels per workgroup (0 = default)
 SOLVERS = {"euler": 0, "midpoint": 1, "heun2": 2, "heun2_eulerlast": 3}
 
 c_void_p, c_int, c_float, c_ll, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -30,6 +30,11 @@ c_void_p, c_int, c_float, c_ll, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_l
 class FdModelConfig(C.Structure):
     _fields_ = [("nf", c_int), ("ch_mult", c_int * 8), ("num_levels", c_int), ("num_res_blocks", c_int),
                 ("n_fft", c_int), ("hop", c_int), ("alpha", c_float), ("beta", c_float), ("act_dtype", c_int)]
+
+
+class FdNdacConfig(C.Structure):
+    _fields_ = [("encoder_dim", c_int), ("encoder_rates", c_int * 8), ("n_encoder_rates", c_int), ("latent_dim", c_int), ("decoder_dim", c_int),
+                ("decoder_rates", c_int * 8), ("n_decoder_rates", c_int), ("n_codebooks", c_int), ("codebook_size", c_int), ("codebook_dim", c_int)]
 
 
 class FdResblockDesc(C.Structure):
@@ -102,6 +107,22 @@ SIGNATURES = {
     "fd_profile_read": (c_int, [_P, C.POINTER(C.c_double), C.POINTER(c_ll), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "fd_profile_read_fir": (c_int, [_P, C.POINTER(C.c_double), C.POINTER(c_ll), C.POINTER(C.c_double)]),
     "fd_profile_read_stft": (c_int, [_P, C.POINTER(C.c_double * 6), C.POINTER(c_int * 2)]),
+    "fd_conv1d": (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 9 + [_P]),
+    "fd_conv_transpose1d": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 7 + [_P]),
+    "fd_ndac_create": (c_int, [C.POINTER(FdNdacConfig), C.POINTER(_P)]),
+    "fd_ndac_destroy": (None, [_P]),
+    "fd_ndac_hop_length": (c_int, [_P]),
+    "fd_ndac_num_params": (c_int, [_P]),
+    "fd_ndac_param_info": (c_int, [_P, c_int, C.POINTER(C.c_char_p), C.POINTER(c_int), C.POINTER(c_int * 3)]),
+    "fd_ndac_set_param": (c_int, [_P, C.c_char_p, _P, c_ll]),
+    "fd_ndac_finalize": (c_int, [_P, _P]),
+    "fd_ndac_latent_frames": (c_int, [_P, c_int]),
+    "fd_ndac_decoded_length": (c_int, [_P, c_int]),
+    "fd_ndac_workspace_bytes": (c_size_t, [_P, c_int, c_int]),
+    "fd_ndac_encode": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "fd_rvq_encode": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "fd_rvq_from_codes": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
+    "fd_ndac_decode": (c_int, [_P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
     "fd_stft_plan_profile": (c_int, [_P, c_int]),
     "fd_stft_plan_profile_read": (c_int, [_P, C.POINTER(C.c_double * 6), C.POINTER(c_int * 2)]),
 }

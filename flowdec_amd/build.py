@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libflowdec_hip.so")
-SOURCES = ["api.hip", "conv_mfma.hip", "conv_wino.hip", "conv_head.hip", "elementwise.hip", "stft.hip", "model.hip"]
+SOURCES = ["api.hip", "conv_mfma.hip", "conv_wino.hip", "conv_head.hip", "elementwise.hip", "stft.hip", "model.hip", "ndac.hip"]
 # -fno-slp-vectorize: hipcc (ROCm 7.2) otherwise packs adjacent f32 FMAs into v_pk_fma_f32; beside MFMAs that is slower
 # (guide: MI355X_MICROARCH "price of one filler beside MFMAs") and one such packing of the fused GroupNorm affine
 # produced wrong lanes (op_sel_hi broadcast) in the f32 conv path.
@@ -26,7 +26,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INC, "flowdec_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INC, "flowdec_hip.h"), os.path.abspath(__file__)]   # (this file: SOURCES / FLAGS)
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -109,6 +109,12 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
+// v_permlane16_swap_b32 a, b: rows 1 / 3 of a <-> rows 0 / 2 of b (a row = 16 lanes), from inline asm: hipcc (ROCm 7.2) miscompiles
+// `r = __builtin_amdgcn_permlane16_swap(a, b); x = f(r[0]) + f(r[1])` into v_add_f32 x, a', a' (scripts/probe_lane_ops.hip shows
+// both the builtin's lane pattern and the wrong sum).  The s_nop covers the VALU-write -> DPP-read hazard the compiler cannot see.
+__device__ __forceinline__ void permlane16_swap(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
   bf16x2 r = {(bf16)a, (bf16)b};
   return __builtin_bit_cast(unsigned, r);
@@ -220,23 +226,35 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   }
   const int H = p.H, W = p.W;
-  // RE: this workgroup owns the contiguous tile range [tile_cur, tile_end) of the (b, tile row, tile column) order (tiles_n == 1)
-  int tile_cur = lid, tile_end = lid + 1;
-  if constexpr (RE) {
-    const long long ntl = (long long)p.B * p.tiles_h * p.tiles_w;
-    tile_cur = (int)(ntl * lid / nblk);
-    tile_end = (int)(ntl * (lid + 1) / nblk);
-  }
+  // RE: this workgroup owns a contiguous range of `tiles_left` tiles of the (b, tile row, tile column) order (tiles_n == 1).  Only a
+  // countdown and the (b, row, column) counters of the compute tile and of the loader's tile stay live in scalar registers across the K
+  // loop; everything a tile boundary needs besides (image size, tile counts, output / statistics pointers) is re-read there from the
+  // kernel-argument segment (`KP()`): kept live, those values pushed the K loop into scalar-register spills (+7 % cycles, measured).
+  int tiles_left = 1;
   int b, th_i, tw_i, h0, w0;   // the tile the MFMAs / the epilogue work on
   const int n0 = RE ? 0 : (lid % p.tiles_n) * G::BN;
-  auto decode_tile = [&](int tl, int& b_, int& th_, int& tw_) {
-    int pt = RE ? tl : tl / p.tiles_n;
-    tw_ = pt % p.tiles_w; pt /= p.tiles_w;
-    th_ = pt % p.tiles_h;
-    b_ = pt / p.tiles_h;
-  };
-  decode_tile(tile_cur, b, th_i, tw_i);
+  {
+    int tile0 = lid;
+    if constexpr (RE) {
+      const long long ntl = (long long)p.B * p.tiles_h * p.tiles_w;
+      tile0 = (int)(ntl * lid / nblk);
+      tiles_left = (int)(ntl * (lid + 1) / nblk) - tile0;
+    }
+    int pt = RE ? tile0 : tile0 / p.tiles_n;
+    tw_i = pt % p.tiles_w; pt /= p.tiles_w;
+    th_i = pt % p.tiles_h;
+    b = pt / p.tiles_h;
+  }
   h0 = th_i * G::TH; w0 = tw_i * G::TW;
+  // the kernel arguments through an opaque pointer: loads through it are issued where they are written, not hoisted to the kernel entry
+  auto KP = [&]() {
+    const __attribute__((address_space(4))) ConvArgs* k = (const __attribute__((address_space(4))) ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return k;
+  };
+  auto next_tile = [&](int& b_, int& th_, int& tw_, int tiles_w, int tiles_h) {   // (b, row, column) of the following tile
+    if (++tw_ == tiles_w) { tw_ = 0; if (++th_ == tiles_h) { th_ = 0; ++b_; } }
+  };
 
   const int t = threadIdx.x;
   const int q = t & 3;        // 16-byte slot inside the 64-byte chunk row
@@ -247,8 +265,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   int pixl[G::HITER];   // clamped pixel index inside the loader's image
   int hlds[G::HITER];   // LDS byte offset of the slot
   unsigned pvalid = 0, hexist = 0;
-  int lb = b;           // image the LOADER works on (RE: one chunk ahead of the MFMAs, i.e. possibly already the next tile's)
-  auto set_loader_tile = [&](int lh0, int lw0) {
+  int lb = b, lth = th_i, ltw = tw_i;   // tile the LOADER works on (RE: one chunk ahead of the MFMAs, i.e. possibly already the next tile)
+  auto set_loader_tile = [&](int lh0, int lw0, int H, int W) {
     pvalid = 0; hexist = 0;
 #pragma unroll
     for (int i = 0; i < G::HITER; ++i) {
@@ -262,7 +280,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       if (hp < G::HH * G::HW) { hexist |= 1u << i; if (ok) pvalid |= 1u << i; }
     }
   };
-  set_loader_tile(h0, w0);
+  set_loader_tile(h0, w0, H, W);
   const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
   const size_t img_elems = (size_t)H * W;
 
@@ -521,13 +539,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   };
   char* const scratch = afftab + 2 * AFF_BYTES;                 // RE only (see Geo::LDS_BYTES)
   char* const biastab = scratch + G::SCR_BYTES;
-  // (RE) uniform buffer resources of the statistics output and of the bias: see the statistics store in the epilogue
-  const __amdgpu_buffer_rsrc_t stsrd = __builtin_amdgcn_make_buffer_rsrc(p.stats, 0, RE && p.stats ? (int)((size_t)p.B * p.tiles_h * p.tiles_w * p.CoutPad * 8) : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t bisrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, RE && p.bias ? (p.bias_rows > 1 ? p.B : 1) * p.Cout * 4 : 0, 0x00020000);
   auto load_biastab = [&](int img) {   // RE: bias row of image `img` -> LDS table of the image's parity (zeros without a bias: out-of-range reads return 0)
+    const auto k = KP();
+    const __amdgpu_buffer_rsrc_t bisrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(k->bias), 0, k->bias ? (k->bias_rows > 1 ? k->B : 1) * k->Cout * 4 : 0, 0x00020000);
     for (int i = t; i < G::BN; i += G::NTH)
       reinterpret_cast<float*>(biastab)[(img & 1) * G::BN + i] =
-          __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bisrd, (n0 + i) * 4, (p.bias_rows > 1 ? img : 0) * p.Cout * 4, 0));
+          __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bisrd, (n0 + i) * 4, (k->bias_rows > 1 ? img : 0) * k->Cout * 4, 0));
   };
   if constexpr (RE) load_biastab(b);
   if (p.affine) {
@@ -555,14 +572,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // last steps) is not branched around but redirected to harmless targets (re-load of the last slab / the current chunk).
   // RE: the loader moves on to the workgroup's NEXT tile while the MFMAs work on the last chunk of this one
   auto loader_to_next_tile = [&]() {
-    int nb, nth, ntw;
-    decode_tile(tile_cur + 1, nb, nth, ntw);
-    if (nb != lb && p.affine) load_afftab(nb);   // into the other parity's table; published by the barriers before its first use (tap 3)
-    lb = nb;
-    set_loader_tile(nth * G::TH, ntw * G::TW);
+    const auto k = KP();
+    const int ob = lb;
+    next_tile(lb, lth, ltw, k->tiles_w, k->tiles_h);
+    if (lb != ob && k->affine) load_afftab(lb);   // into the other parity's table; published by the barriers before its first use (tap 3)
+    set_loader_tile(lth * G::TH, ltw * G::TW, k->H, k->W);
     cs = 0; cch = 0;
     next_chunk(0, 0);
   };
+#ifdef FD_TIMING2
+  unsigned long long re_t0 = RE ? __builtin_amdgcn_s_memtime() : 0ull, re_loop = 0, re_epi = 0, re_stat = 0, re_tiles = 0;
+#endif
   for (;;) {   // tile loop: a single pass unless RE
   if constexpr (CW) {
     // Low-latency K loop.  With few MFMAs per phase the two-set pipeline above is a pure latency chain (the MFMAs of phase p + 1
@@ -624,7 +644,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   for (int i = 0; i < n9; ++i) {
     const bool last_chunk = (i == n9 - 1) && n1 == 0;
     if (!last_chunk) { advance(cs, cch); next_chunk(cs, cch); }
-    else if (RE && tile_cur + 1 < tile_end) loader_to_next_tile();   // the first halo of the next tile
+    else if (RE && tiles_left > 1) loader_to_next_tile();             // the first halo of the next tile
     else npix_on = 0;                                                  // the prefetch of this chunk is unused
     const char* hb = hbuf + hcur * G::HALO_BYTES;
     const char* hbn = hbuf + (hcur ^ 1) * G::HALO_BYTES;
@@ -706,7 +726,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     const char* wb = slot_of(step);
     const char* wbn = slot_of(step + 1);
     if (m1) { advance(cs, cch); next_chunk(cs, cch); }
-    else if (RE && tile_cur + 1 < tile_end) loader_to_next_tile();
+    else if (RE && tiles_left > 1) loader_to_next_tile();
     else npix_on = 0;
     // the next 1-tap chunk's halo: loaded and published within this step
 #pragma unroll
@@ -740,44 +760,54 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     ++step; hcur ^= 1;
   }
   if constexpr (RE) {
+#ifdef FD_TIMING2
+    const unsigned long long re_t1 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- register epilogue (see the file header).  Lane (l31, lh) of wave (wm, wn) holds, for M-tile mi and N-tile nj, the
     // couts 8 qd + 4 lh + e (qd, e = 0..3) of pixel l31 of patch wm * MT + mi.
-    bf16* const outp = reinterpret_cast<bf16*>(p.out);
+    const auto kp = KP();
+    const int H_ = kp->H, W_ = kp->W, Cout_ = kp->Cout;
+    const float scale_ = kp->scale;
+    bf16* const outp = reinterpret_cast<bf16*>(kp->out);
+    float* const stats_ = kp->stats;
     const float* const bt = reinterpret_cast<const float*>(biastab) + (b & 1) * G::BN;
     float* const scr = reinterpret_cast<float*>(scratch);
     const int row4 = lane >> 4;   // DPP row: rows 0, 1 = lh 0, rows 2, 3 = lh 1
-    const bool want_stats = p.stats != nullptr;
+    const bool want_stats = stats_ != nullptr;
+    const f32x2 sc2 = {scale_, scale_};
 #pragma unroll
     for (int nj = 0; nj < NT; ++nj) {
       const int cw = (wn * NT + nj) * 32;   // first cout of this MFMA tile inside the workgroup's BN
 #pragma unroll
       for (int qp = 0; qp < 2; ++qp) {      // couts 16 qp .. 16 qp + 15 of the MFMA tile: qd = 2 qp (x[0..3]) and 2 qp + 1 (x[4..7])
-        float bv[8], ssum[8], ssq[8];
+        // two channels per instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: the same IEEE operations as the staged epilogue's)
+        f32x2 bv[4], ssum[4], ssq[4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const f32x4 b4 = *reinterpret_cast<const f32x4*>(bt + cw + 16 * qp + 8 * h + 4 * lh);
-          bv[4 * h] = b4[0]; bv[4 * h + 1] = b4[1]; bv[4 * h + 2] = b4[2]; bv[4 * h + 3] = b4[3];
+          bv[2 * h] = f32x2{b4[0], b4[1]}; bv[2 * h + 1] = f32x2{b4[2], b4[3]};
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) ssum[k] = ssq[k] = 0.f;
+        for (int k = 0; k < 4; ++k) ssum[k] = ssq[k] = f32x2{0.f, 0.f};
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
           const int pi = wm * MT + mi;
           const int gh = h0 + 4 * (pi >> 1) + (l31 >> 3), gw = w0 + 8 * (pi & 1) + (l31 & 7);
-          bf16* const op = outp + (((size_t)b * H + gh) * W + gw) * p.Cout + n0 + cw + 8 * lh;
-          float x[8];
+          bf16* const op = outp + (((size_t)b * H_ + gh) * W_ + gw) * Cout_ + n0 + cw + 8 * lh;
+          unsigned pk[4];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
+          for (int k = 0; k < 4; ++k) {
 #pragma clang fp contract(off)
-            const float v = (acc[mi][nj][8 * qp + k] + bv[k]) * p.scale;   // the staged epilogue's arithmetic: two roundings, then bf16
-            x[k] = v;
-            ssum[k] += v;
-            ssq[k] = __builtin_fmaf(v, v, ssq[k]);
+            f32x2 x = {acc[mi][nj][8 * qp + 2 * k], acc[mi][nj][8 * qp + 2 * k + 1]};
+            x = (x + bv[k]) * sc2;                                   // two roundings, then bf16: the staged epilogue's arithmetic
+            ssum[k] += x;
+            ssq[k] = __builtin_elementwise_fma(x, x, ssq[k]);
+            pk[k] = pack_bf16x2(x[0], x[1]);
           }
           // v_permlane32_swap(X, Y): lanes 0-31 end with {X own, X of lane + 32}, lanes 32-63 with {Y of lane - 32, Y own}: the lh = 0
           // lane of a pixel gets couts 0..7 of qd = 2 qp, its lh = 1 partner couts 0..7 of qd = 2 qp + 1 -- 16 contiguous bytes each
-          const auto s0 = __builtin_amdgcn_permlane32_swap(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[4], x[5]), false, false);
-          const auto s1 = __builtin_amdgcn_permlane32_swap(pack_bf16x2(x[2], x[3]), pack_bf16x2(x[6], x[7]), false, false);
+          const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
           *reinterpret_cast<u32x4*>(op + 16 * qp) = u32x4{s0[0], s1[0], s0[1], s1[1]};
         }
         if (want_stats) {
@@ -788,9 +818,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
           for (int which = 0; which < 2; ++which)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float A = which ? ssq[e] : ssum[e], B = which ? ssq[4 + e] : ssum[4 + e];
-              const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, A), __builtin_bit_cast(unsigned, B), false, false);
-              float r = __builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]);
+              float A = which ? ssq[e >> 1][e & 1] : ssum[e >> 1][e & 1], B = which ? ssq[2 + (e >> 1)][e & 1] : ssum[2 + (e >> 1)][e & 1];
+              permlane16_swap(A, B);
+              float r = A + B;
               r = dpp_add<0xB1>(r);    // quad_perm [1,0,3,2]
               r = dpp_add<0x4E>(r);    // quad_perm [2,3,0,1]
               r = dpp_add<0x141>(r);   // row_half_mirror
@@ -802,12 +832,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       }
     }
     pend_st = RE_NST;
+#ifdef FD_TIMING2
+    const unsigned long long re_t2 = __builtin_amdgcn_s_memtime();
+#endif
     if (want_stats) {
       lds_barrier();
       // (through a buffer resource: uniform base + tile offset in scalar registers, the per-thread part is 4 * o -- a 64-bit per-thread
       // address would be hoisted out of the tile loop and spilled, and its reload would drain the stores just issued)
-      const int tile = th_i * p.tiles_w + tw_i;
-      const int rec = (b * p.tiles_h * p.tiles_w + tile) * p.CoutPad * 2;   // first float of this tile's record (launcher: fits 31 bits in bytes)
+      const int ntile = kp->tiles_h * kp->tiles_w, cpad = kp->CoutPad;
+      const __amdgpu_buffer_rsrc_t stsrd = __builtin_amdgcn_make_buffer_rsrc(stats_, 0, (int)((size_t)kp->B * ntile * cpad * 8), 0x00020000);
+      const int rec = ((b * ntile + th_i * kp->tiles_w + tw_i) * cpad + n0) * 2;   // first float of this tile's record (launcher: fits 31 bits in bytes)
       for (int o = t; o < 2 * G::BN; o += G::NTH) {   // o = 2 * channel + which
         float a = 0.f;
 #pragma unroll
@@ -816,12 +850,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       }
       if (__builtin_amdgcn_readfirstlane(t) < 2 * G::BN) pend_st = RE_NST + 1;
     }
-    if (++tile_cur >= tile_end) break;
+#ifdef FD_TIMING2
+    {   // per-workgroup sums over its tiles: K loop | register epilogue (math + stores + lane reduction) | statistics barrier + combine
+      const unsigned long long re_t3 = __builtin_amdgcn_s_memtime();
+      re_loop += re_t1 - re_t0; re_epi += re_t2 - re_t1; re_stat += re_t3 - re_t2; ++re_tiles;
+      if (tiles_left <= 1 && p.dbg && t == 0 && bid < 8192) {
+        unsigned long long* d = p.dbg + (size_t)bid * 8;
+        d[0] = t2_first - t2_entry; d[1] = re_loop; d[2] = re_epi; d[3] = re_stat; d[4] = re_tiles; d[5] = re_t3 - t2_entry;
+      }
+    }
+#endif
+    if (--tiles_left <= 0) break;
     {   // on to the next tile: its first halo is published, its first weight slabs are in the ring
-      int nb;
-      decode_tile(tile_cur, nb, th_i, tw_i);
-      if (nb != b) load_biastab(nb);   // (other parity; read by the NEXT epilogue, many barriers from here)
-      b = nb; h0 = th_i * G::TH; w0 = tw_i * G::TW;
+      const int ob = b;
+      next_tile(b, th_i, tw_i, kp->tiles_w, kp->tiles_h);
+      if (b != ob) load_biastab(b);   // (other parity; read by the NEXT epilogue, many barriers from here)
+      h0 = th_i * G::TH; w0 = tw_i * G::TW;
     }
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
@@ -830,6 +874,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
     read_frags(wfA, pfA, hbuf + hcur * G::HALO_BYTES, smem + WOFF + (step & 3) * G::W_LDS, 0, 0);
+#ifdef FD_TIMING2
+    re_t0 = __builtin_amdgcn_s_memtime();   // (transition -- tile decode, accumulator reset -- is counted with the total only)
+#endif
     continue;
   } else {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1126,9 +1173,6 @@ int set_attr_re() {
 template <int WM, int WN, int MT, int NT>
 bool re_applies(const ConvArgs& a) {
   using G = Geo<WM, WN, MT, NT, false, false, true>;
-#ifdef FD_NO_RE
-  return false;
-#endif
   if (a.skip || a.Cout != G::BN || a.H % G::TH || a.W % G::TW) return false;
   if ((long long)a.B * (a.H / G::TH) * (a.W / G::TW) * a.CoutPad * 8 >= (1ll << 31)) return false;   // statistics addressed through one buffer resource
   bool has9 = false;
@@ -1167,7 +1211,7 @@ int launch_conv(ConvArgs a, hipStream_t st) {
 // bn_hint: output channels per workgroup (32 / 64 / 128 / 256) or 0 = by Cout.  All configurations run the same K order per
 // output, so the convolution result does not depend on the choice (the per-tile statistics differ in summation order only).
 template <typename T>
-int dispatch_conv(const ConvArgs& a, hipStream_t st, int bn_hint, bool chunk_ring) {
+int dispatch_conv(const ConvArgs& a, hipStream_t st, int bn_hint, bool chunk_ring, bool persist = false) {
   int bn = a.Cout <= 32 ? 32 : (a.Cout <= 128 ? 128 : 256);
   if (bn_hint > 0 && bn_hint < bn) bn = bn_hint;   // (bn_hint < 0: FD_TILE_DUO128, below)
   if constexpr (sizeof(T) == 2) {
@@ -1180,9 +1224,9 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int bn_hint, bool chunk_rin
   }
   if (bn == 32) return launch_conv<T, 4, 1, 2, 1>(a, st);                                 // 4 waves, BN = 32 (pyramid heads, tiny grids)
   if (bn == 64) return launch_conv<T, 4, 2, 2, 1>(a, st);                                 // 8 waves, BN = 64
-  if constexpr (sizeof(T) == 2) {   // whole tiles, Cout == BN, no residual input: the persistent register-epilogue configuration
-    if (bn_hint == 0 && bn == 128 && re_applies<4, 2, 2, 2>(a)) return launch_conv_re<4, 2, 2, 2>(a, st);
-    if (bn_hint == 0 && bn == 256 && re_applies<2, 4, 4, 2>(a)) return launch_conv_re<2, 4, 4, 2>(a, st);
+  if constexpr (sizeof(T) == 2) {   // FD_TILE_PERSIST: whole tiles, Cout == BN, no residual input -> the persistent register-epilogue configuration
+    if (persist && bn == 128 && re_applies<4, 2, 2, 2>(a)) return launch_conv_re<4, 2, 2, 2>(a, st);
+    if (persist && bn == 256 && re_applies<2, 4, 4, 2>(a)) return launch_conv_re<2, 4, 4, 2>(a, st);
   }
   if (bn == 128) return launch_conv<T, 4, 2, 2, 2>(a, st);                                // 8 waves, BN = 128
   return launch_conv<T, 2, 4, 4, 2>(a, st);                                               // 8 waves, BN = 256
@@ -1283,7 +1327,7 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
              "fd_conv2d: FD_BF16_OPERANDS / FD_BF16X3_OPERANDS go with FD_F32 storage and the default direct configuration only");
   const int tile = dtype & FD_TILE_MASK;
   const int bn_hint = tile == FD_TILE_DUO128 ? -128 : (tile == FD_TILE_BN32 || tile == FD_TILE_BN32_CHUNK) ? 32 : (tile == FD_TILE_BN64 || tile == FD_TILE_BN64_CHUNK) ? 64 : tile == FD_TILE_BN128 ? 128 : 0;
-  FD_REQUIRE(tile == 0 || bn_hint != 0, "fd_conv2d: bad FD_TILE_* flag");
+  FD_REQUIRE(tile == 0 || bn_hint != 0 || tile == FD_TILE_PERSIST, "fd_conv2d: bad FD_TILE_* flag");
   dtype &= 0xff;
   FD_REQUIRE(!wino || (dtype == FD_BF16 && fd_wino_supported(Cout, C0, C1, S0, S1, ksize)),
              "fd_conv2d: FD_WINOGRAD needs bf16 storage, ksize 3, Cout %% 128 == 0 and channel counts %% 32 == 0");
@@ -1323,6 +1367,6 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
 #ifndef FD_NO_HEAD_KERNEL
   if (bn_hint == 0 && fd_head_supported(a, ksize, dtype)) return fd_head_launch(a, fd_stream(stream));
 #endif
-  if (dtype == FD_BF16) return dispatch_conv<bf16>(a, fd_stream(stream), bn_hint, tile == FD_TILE_BN64_CHUNK || tile == FD_TILE_BN32_CHUNK);
+  if (dtype == FD_BF16) return dispatch_conv<bf16>(a, fd_stream(stream), bn_hint, tile == FD_TILE_BN64_CHUNK || tile == FD_TILE_BN32_CHUNK, tile == FD_TILE_PERSIST);
   return dispatch_conv<float>(a, fd_stream(stream), bn_hint, false);
 }

@@ -74,6 +74,11 @@ extern "C" {
                                      round trip per chunk instead of per tap pair (bf16; falls back to FD_TILE_BN64 otherwise) */
 #define FD_TILE_BN32_CHUNK 0x5000 /* same with 32-channel workgroups (4 waves) */
 #define FD_TILE_DUO128 0x6000 /* 4 waves x (128 px x 64 cout) with ONE halo buffer: 70 KiB of LDS, two workgroups per CU (bf16, Cout % 128 == 0) */
+#define FD_TILE_PERSIST 0x7000 /* "register epilogue, continuous tiles" (bf16, Cout == 128 or 256, H % 16 == W % 16 == 0, no residual input; the
+                                  default configuration otherwise): one persistent workgroup per compute unit walks a contiguous range of tiles
+                                  as ONE software pipeline, epilogue on the accumulator registers, stores left in flight.  Bit-identical
+                                  convolution result.  Measured (profiles/r03_register_epilogue.txt): no prologue, 12 % fewer instructions
+                                  around the MFMAs -- and 0.97-1.06x of the default: the K loop loses what the tile boundary gains.  Opt-in. */
 #define FD_TILE_MASK 0xf000
 /* fd_model_config.act_dtype only: low-latency schedule for ONE short clip -- both packings are kept (as with FD_WINOGRAD_AUTO) and
  * every convolution picks kernel and workgroup width by its IMAGE size (never by the batch size): FD_TILE_BN32_CHUNK for images of
@@ -334,6 +339,55 @@ int fd_profile_read_fir(fd_model* m, double* ms_total, long long* launches, doub
 int fd_profile_read_stft(fd_model* m, double* ms6, int* calls2);
 int fd_stft_plan_profile(fd_stft_plan* plan, int enable);
 int fd_stft_plan_profile_read(fd_stft_plan* plan, double* ms6, int* calls2);
+
+/* ------------------------------------------------------------------------------------------------
+ * NDAC codec: the Descript-Audio-Codec architecture whose output FlowDec post-filters.  Reference call
+ * sites: demo.ipynb cell 2 (`DAC.load(.../weights.pth)`), cell 3 (`preprocess`, `encode(x, n_quantizers=nq)`,
+ * `quantizer.from_codes(codes)`, `decode(zq)`); arithmetic = descript-audio-codec==1.0.0 (requirements.txt:4), a third-party
+ * package that is not under /root/reference: restated from the published algorithm, PARITY UNPINNED (oracle/ndac_oracle.py).
+ * Layout [B][C][T] float32 like nn.Conv1d.  Weights are passed EFFECTIVE (weight norm g * v / ||v|| folded by the caller:
+ * flowdec_amd/ndac.py), under their state_dict names with `.weight` in place of `.weight_g` / `.weight_v`.
+ * ---------------------------------------------------------------------------------------------- */
+/* Operator level (stateless, re-entrant): nn.Conv1d / nn.ConvTranspose1d with the DAC surroundings fused in.
+ *   alpha_in [Ci] or NULL : Snake activation x + sin^2(alpha x) / (alpha + 1e-9) applied to the INPUT (zero padding after it)
+ *   residual [B][Co][To] or NULL : added to the result (ResidualUnit: x + block(x));  tanh_out != 0 : tanh of the result
+ * w: [Co][Ci][K] (conv) / [Ci][Co][K] (transposed); To = (T + 2 p - d (K - 1) - 1) / s + 1  resp.  (T - 1) s - 2 p + K. */
+int fd_conv1d(const float* x, const float* w, const float* bias, const float* alpha_in, const float* residual, float* out, int B, int Ci,
+              int T, int Co, int K, int stride, int padding, int dilation, int tanh_out, void* stream);
+int fd_conv_transpose1d(const float* x, const float* w, const float* bias, const float* alpha_in, float* out, int B, int Ci, int T, int Co,
+                        int K, int stride, int padding, void* stream);
+
+typedef struct fd_ndac fd_ndac;
+typedef struct fd_ndac_config {   /* dac.DAC.__init__ keyword arguments (the `metadata["kwargs"]` of a weights.pth) */
+  int encoder_dim;                /* 64 */
+  int encoder_rates[8];           /* e.g. {2,4,8,8}; hop length = their product */
+  int n_encoder_rates;
+  int latent_dim;                 /* encoder_dim * 2^n_encoder_rates unless the checkpoint says otherwise */
+  int decoder_dim;                /* 1536 */
+  int decoder_rates[8];           /* e.g. {8,8,4,2} */
+  int n_decoder_rates;
+  int n_codebooks, codebook_size, codebook_dim;   /* 9, 1024, 8 (codebook_dim <= 8) */
+} fd_ndac_config;
+int fd_ndac_create(const fd_ndac_config* cfg, fd_ndac** out);
+void fd_ndac_destroy(fd_ndac* m);
+int fd_ndac_hop_length(const fd_ndac* m);
+int fd_ndac_num_params(const fd_ndac* m);
+int fd_ndac_param_info(const fd_ndac* m, int i, const char** name, int* ndim, int shape[3]);
+int fd_ndac_set_param(fd_ndac* m, const char* name, const float* host_data, long long numel);   /* float32 HOST pointer */
+int fd_ndac_finalize(fd_ndac* m, void* stream);   /* uploads; normalises the codebooks (synchronous, init time) */
+int fd_ndac_latent_frames(const fd_ndac* m, int L);    /* frames for L samples (L % hop == 0: L / hop) */
+int fd_ndac_decoded_length(const fd_ndac* m, int T);   /* samples the decoder produces for T frames */
+size_t fd_ndac_workspace_bytes(const fd_ndac* m, int B, int L);   /* covers encode of [B][L] and decode of its frames */
+/* dac.DAC.encode (eval): x [B][L] (L % hop == 0: DAC.preprocess pads) -> z_q [B][latent][T] f32, codes [B][nq][T] int32,
+ * latents [B][nq * codebook_dim][T] or NULL.  n_quantizers <= 0 or > n_codebooks: all of them. */
+int fd_ndac_encode(fd_ndac* m, const float* x, int B, int L, int n_quantizers, float* z_q, int* codes, float* latents, void* ws,
+                   size_t ws_bytes, void* stream);
+/* ResidualVectorQuantize.forward on a given latent z [B][latent][T] (ws: B * latent * T floats) / .from_codes */
+int fd_rvq_encode(fd_ndac* m, const float* z, int B, int T, int n_quantizers, float* z_q, int* codes, float* latents, void* ws,
+                  size_t ws_bytes, void* stream);
+int fd_rvq_from_codes(fd_ndac* m, const int* codes, int B, int n_quantizers, int T, float* z_q, void* stream);
+/* dac.DAC.decode: z [B][latent][T] -> audio [B][fd_ndac_decoded_length(T)] in (-1, 1) */
+int fd_ndac_decode(fd_ndac* m, const float* z, int B, int T, float* audio, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

