@@ -52,7 +52,7 @@ def cpu_baseline():
     # thread count: torch's default (= physical cores) is not the fastest on a many-core host (measured on the round-3 box, EPYC 9575F:
     # 128 threads 32.6 s per enhance); one warm 1-NFE probe per candidate, the full run with the fastest
     probe = {}
-    for nt in sorted({torch.get_num_threads(), 64, 32, 16} & set(range(1, torch.get_num_threads() + 1)), reverse=True):
+    for nt in sorted({torch.get_num_threads(), 64, 32, 16, 8} & set(range(1, torch.get_num_threads() + 1)), reverse=True):
         torch.set_num_threads(nt)
         OT.enhance(net, y, noise, 0.66, N=1, solver="euler")          # warm-up: thread pool, oneDNN primitive cache
         t0 = time.perf_counter()
