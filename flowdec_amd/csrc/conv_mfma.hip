@@ -495,7 +495,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   const char* const wfetch0 = reinterpret_cast<const char*>(p.w) + (size_t)n0 * WROWB;
   const char* wfetch = wfetch0;
   const size_t slab_stride = (size_t)p.CoutPad * WROWB;
-  int fleft = nsteps;   // RE: slabs left in this tile's stream; then the pointer wraps to slab 0 = the next tile's first step
   int dma_pce[G::DMA_PER_WAVE];        // the 1-KiB pieces of a slab this wave copies (wave-uniform)
   unsigned dma_voff[G::DMA_PER_WAVE];  // per-lane byte offset inside the slab
   {
@@ -512,9 +511,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wfetch + dma_voff[j]),
                                        (__attribute__((address_space(3))) void*)(smem + dst_off + dma_pce[j] * 1024), 16, 0, 0);
     wfetch += slab_stride;
-    if constexpr (RE) {
-      if (--fleft == 0) { wfetch = wfetch0; fleft = nsteps; }
-    }
     asm volatile("" : "+s"(wfetch));   // keep the walk scalar and sequential (hipcc otherwise pre-computes the vector addresses of a whole chunk)
   };
   auto fetch_slabs = [&](int n) {   // CW only
@@ -873,6 +869,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       for (int nj = 0; nj < NT; ++nj)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mi][nj][e] = 0.f;
+    // the weight stream has run 4 slabs past this tile's last step, into the copies of slabs 0..3 that the packing keeps there:
+    // it continues with slab 4 of the next tile (no per-slab wrap-around test in the K loop)
+    wfetch = wfetch0 + 4 * slab_stride;
+    asm volatile("" : "+s"(wfetch));
     read_frags(wfA, pfA, hbuf + hcur * G::HALO_BYTES, smem + WOFF + (step & 3) * G::W_LDS, 0, 0);
 #ifdef FD_TIMING2
     re_t0 = __builtin_amdgcn_s_memtime();   // (transition -- tile decode, accumulator reset -- is counted with the total only)
@@ -1313,6 +1313,12 @@ extern "C" int fd_conv_pack_weights(const float* w, const float* w_sc, void* pac
   run(w, C0, C1, taps, 0);
   if (w_sc) run(w_sc, S0, S1, 1, n_steps(C0, C1, taps, CK));
   FD_LAUNCH_CHECK();
+  {   // the 4 slabs of padding behind the last step hold copies of slabs 0..3: the weight stream of a persistent workgroup
+      // (FD_TILE_PERSIST) runs over the end of a tile's K loop straight into the first steps of the next tile, no wrap-around test
+    const long long ns = n_steps(C0, C1, taps, CK) + n_steps(S0, S1, 1, CK);
+    const size_t slab = (size_t)CoutPad * WROWB;
+    if (ns >= 4) FD_HIP(hipMemcpyAsync((char*)packed + ns * slab, packed, 4 * slab, hipMemcpyDeviceToDevice, st));
+  }
   return FD_OK;
 }
 

@@ -21,7 +21,7 @@ for name, C0, C1, aff, S in [("plain 256", 256, 0, 0, 0), ("cat aff 512", 256, 2
         wsc = torch.randn(Cout, S, 1, 1, device="cuda", generator=g) / S ** 0.5
     pw = ops.pack_conv_weight(w, C0=C0, dtype=dt, w_sc=wsc, S0=256 if S else None)
     A = torch.stack([1 + 0.1 * torch.randn(B, C0 + C1, device="cuda", generator=g), 0.1 * torch.randn(B, C0 + C1, device="cuda", generator=g)], -1).contiguous() if aff else None
-    f = lambda: ops.conv2d(x0, pw, Cout, 3, x1=x1, affine=A, scale=0.7, sc0=sc0, sc1=sc1, want_stats=True)
+    f = lambda: ops.conv2d(x0, pw, Cout, 3, x1=x1, affine=A, scale=0.7, sc0=sc0, sc1=sc1, want_stats=True, tile_bn='persist')
     for _ in range(3):
         f()
     torch.cuda.synchronize(); dbg.zero_()
