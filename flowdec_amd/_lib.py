@@ -23,6 +23,7 @@ FD_EBUSY = -5
 FD_BF16X3_OPERANDS = 0x20000  # with FD_F32: operands as hi + lo bf16 pairs, three bf16 MFMAs per product (precision='bf16x3')
 FD_TILE = {0: 0, 32: 0x1000, 64: 0x2000, 128: 0x3000, "64c": 0x4000, "32c": 0x5000, "duo": 0x6000, "persist": 0x7000}  # fd_conv2d: output channels per workgroup (0 = default)
 SOLVERS = {"euler": 0, "midpoint": 1, "heun2": 2, "heun2_eulerlast": 3}
+ADAPTIVE_SOLVERS = {"dopri5": 0, "tsit5": 1}   # FD_ADAPTIVE_*
 
 c_void_p, c_int, c_float, c_ll, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
 
@@ -95,6 +96,7 @@ SIGNATURES = {
     "fd_ode_solve": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "fd_ode_adaptive_workspace_bytes": (c_size_t, [_P, c_int, c_int]),
     "fd_ode_solve_adaptive": (c_int, [_P, _P, _P, c_float, c_int, c_float, c_float, _P, _P, C.POINTER(c_int), c_int, c_int, _P, c_size_t, _P]),
+    "fd_ode_solve_adaptive_method": (c_int, [_P, _P, _P, c_float, c_int, c_int, c_float, c_float, _P, _P, C.POINTER(c_int), c_int, c_int, _P, c_size_t, _P]),
     "fd_enhance_workspace_bytes": (c_size_t, [_P, c_int, c_int]),
     "fd_enhance_normfac_offset": (c_size_t, [_P, c_int, c_int]),
     "fd_model_set_normalize": (c_int, [_P, c_int]),

@@ -976,6 +976,15 @@ const double DP_A[7][6] = {{0}, {1.0 / 5}, {3.0 / 40, 9.0 / 40}, {44.0 / 45, -56
 // error weights b5 - b4 (the 5th-order weights b5 are the last row of DP_A; its 7th entry is 0)
 const double DP_E[7] = {35.0 / 384 - 5179.0 / 57600, 0.0, 500.0 / 1113 - 7571.0 / 16695, 125.0 / 192 - 393.0 / 640,
                         -2187.0 / 6784 + 92097.0 / 339200, 11.0 / 84 - 187.0 / 2100, -1.0 / 40};
+// Tsitouras 5(4) (torchdyn's `Tsitouras45` / `construct_tsit5`; coefficients as published, verified against the order conditions in
+// tests/test_oracle_golden.py): the same 7-stage FSAL shape, E = the published error weights
+const double TS_C[7] = {0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0};
+const double TS_A[7][6] = {{0}, {0.161}, {-0.008480655492356989, 0.335480655492357}, {2.8971530571054935, -6.359448489975075, 4.3622954328695815},
+                           {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525},
+                           {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383},
+                           {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774}};
+const double TS_E[7] = {-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995, -0.1447110071732629, 0.5823571654525552,
+                        -0.45808210592918697, 0.015151515151515152};
 size_t adaptive_ws_bytes(const fd_model* m, int B, int T) {
   const size_t state = fd_align(sizeof(float) * 2 * (size_t)B * m->n_freq * T);
   return 10 * state + fd_align(sizeof(double) * DP_NORM_BLOCKS) + forward_ws_bytes(m, B, T);
@@ -987,9 +996,20 @@ extern "C" size_t fd_ode_adaptive_workspace_bytes(const fd_model* m, int B, int 
   return adaptive_ws_bytes(m, B, T_pad);
 }
 
+extern "C" int fd_ode_solve_adaptive_method(fd_model* m, const float* Y, const float* noise, float sigma_fac, int N, int method, float atol, float rtol,
+                                            float* X_out, float* traj, int* nfe_out, int B, int T_pad, void* ws, size_t ws_bytes, void* stream);
 extern "C" int fd_ode_solve_adaptive(fd_model* m, const float* Y, const float* noise, float sigma_fac, int N, float atol, float rtol, float* X_out,
                                      float* traj, int* nfe_out, int B, int T_pad, void* ws, size_t ws_bytes, void* stream) {
+  return fd_ode_solve_adaptive_method(m, Y, noise, sigma_fac, N, FD_ADAPTIVE_DOPRI5, atol, rtol, X_out, traj, nfe_out, B, T_pad, ws, ws_bytes, stream);
+}
+
+extern "C" int fd_ode_solve_adaptive_method(fd_model* m, const float* Y, const float* noise, float sigma_fac, int N, int method, float atol, float rtol,
+                                            float* X_out, float* traj, int* nfe_out, int B, int T_pad, void* ws, size_t ws_bytes, void* stream) {
   FD_MODEL_ENTER(m, "fd_ode_solve_adaptive");
+  FD_REQUIRE(method == FD_ADAPTIVE_DOPRI5 || method == FD_ADAPTIVE_TSIT5, "fd_ode_solve_adaptive: unknown method id %d", method);
+  const double* const TB_C = method == FD_ADAPTIVE_TSIT5 ? TS_C : DP_C;
+  const double (*const TB_A)[6] = method == FD_ADAPTIVE_TSIT5 ? TS_A : DP_A;
+  const double* const TB_E = method == FD_ADAPTIVE_TSIT5 ? TS_E : DP_E;
   FD_TRY(check_ready(m));
   FD_REQUIRE(Y && noise && X_out && ws, "fd_ode_solve_adaptive: null pointer");
   FD_REQUIRE(N >= 1 && atol > 0.f && rtol >= 0.f, "fd_ode_solve_adaptive: need N >= 1, atol > 0, rtol >= 0");
@@ -1052,14 +1072,14 @@ extern "C" int fd_ode_solve_adaptive(fd_model* m, const float* Y, const float* n
     if (ckpt < N && t + dt > ts[ckpt + 1]) { dt_old = dt; flag = true; dt = ts[ckpt + 1] - t; }
     for (int s = 1; s < 7; ++s) {                                    // stages 2..7; stage 7 is evaluated at the 5th-order solution (FSAL)
       const float* kk[6]; float cc[6];
-      for (int j = 0; j < s; ++j) { kk[j] = k[j]; cc[j] = (float)DP_A[s][j]; }
+      for (int j = 0; j < s; ++j) { kk[j] = k[j]; cc[j] = (float)TB_A[s][j]; }
       float* xs = s == 6 ? x_new : err;                              // `err` doubles as the stage input buffer
       FD_TRY(fd_ode_lincomb(x, 1.f, dt, kk, cc, s, xs, (long long)nstate, st));
-      FD_TRY(eval(xs, t + (float)DP_C[s] * dt, k[s]));
+      FD_TRY(eval(xs, t + (float)TB_C[s] * dt, k[s]));
     }
     {
       const float* kk[7]; float cc[7];
-      for (int j = 0; j < 7; ++j) { kk[j] = k[j]; cc[j] = (float)DP_E[j]; }
+      for (int j = 0; j < 7; ++j) { kk[j] = k[j]; cc[j] = (float)TB_E[j]; }
       FD_TRY(fd_ode_lincomb(x, 0.f, dt, kk, cc, 7, err, (long long)nstate, st));
     }
     double ratio;

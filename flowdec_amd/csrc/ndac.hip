@@ -30,9 +30,11 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int TT = 128;   // output positions per workgroup
 constexpr int CT = 32;    // output channels per workgroup
 constexpr int CIC = 8;    // input channels per LDS chunk
+constexpr int CTP = CT + 4;   // padded weight row of the transposed convolution
 
 __device__ __forceinline__ float snake_f(float x, float alpha) {
   // x + (alpha + 1e-9)^-1 sin^2(alpha x)   (dac/nn/layers.py `snake`); IEEE division, sinf at full precision
@@ -43,6 +45,7 @@ __device__ __forceinline__ float snake_f(float x, float alpha) {
 struct Conv1dArgs {
   const float* x; const float* w; const float* bias; const float* alpha; const float* res; float* out;
   int B, Ci, T, Co, K, To, stride, pad, dil, tanh_out;
+  int wt;   // weight layout: 0 = [Co][Ci][K] (nn.Conv1d, the operator-level ABI), 1 = [Ci][K][Co] (the codec's own copy: coalesced staging)
 };
 
 // weights are read as [Co][Ci][K] (PyTorch layout) and staged as [ci][k][co] so that a thread's 4 output channels are one b128 read
@@ -53,11 +56,9 @@ __global__ __launch_bounds__(256) void conv1d_kernel(Conv1dArgs a) {
   float* ws = sm + CIC * span;            // [CIC][K][CT]
   const int b = blockIdx.z, co0 = blockIdx.y * CT, t0 = blockIdx.x * TT;
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;   // thread: outputs t0 + tx + 32 j (j < 4) x channels co0 + 4 ty .. + 3
-  float acc[4][4];
+  f32x2 acc[4][2];   // [output j][channel pair]: v_pk_fma_f32, two channels per instruction (the same IEEE fma per element)
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[j][c] = 0.f;
+  for (int j = 0; j < 4; ++j) acc[j][0] = acc[j][1] = f32x2{0.f, 0.f};
   const long long in0 = (long long)t0 * a.stride - a.pad;   // input position of xs[.][0]
   for (int c0 = 0; c0 < a.Ci; c0 += CIC) {
     __syncthreads();
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(Conv1dArgs a) {
     }
     for (int i = tid; i < CIC * a.K * CT; i += 256) {
       const int co = i % CT, r = i / CT, k = r % a.K, ci = r / a.K;
-      ws[i] = (c0 + ci < a.Ci && co0 + co < a.Co) ? a.w[((size_t)(co0 + co) * a.Ci + c0 + ci) * a.K + k] : 0.f;
+      ws[i] = (c0 + ci < a.Ci && co0 + co < a.Co) ? a.w[a.wt ? ((size_t)(c0 + ci) * a.K + k) * a.Co + co0 + co : ((size_t)(co0 + co) * a.Ci + c0 + ci) * a.K + k] : 0.f;
     }
     __syncthreads();
 #pragma unroll 1
@@ -82,11 +83,13 @@ __global__ __launch_bounds__(256) void conv1d_kernel(Conv1dArgs a) {
       const float* wr = ws + ci * a.K * CT + ty * 4;
       for (int k = 0; k < a.K; ++k) {
         const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k * CT);
+        const f32x2 w01 = {wv[0], wv[1]}, w23 = {wv[2], wv[3]};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float xv = xr[32 * j * a.stride + k * a.dil];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) acc[j][c] = fmaf(xv, wv[c], acc[j][c]);
+          const f32x2 x2 = {xv, xv};
+          acc[j][0] = __builtin_elementwise_fma(x2, w01, acc[j][0]);
+          acc[j][1] = __builtin_elementwise_fma(x2, w23, acc[j][1]);
         }
       }
     }
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(Conv1dArgs a) {
       const int t = t0 + tx + 32 * j;
       if (t >= a.To) continue;
       const size_t o = ((size_t)b * a.Co + co) * a.To + t;
-      float v = acc[j][c] + bv;
+      float v = acc[j][c >> 1][c & 1] + bv;
       if (a.res) v += a.res[o];
       if (a.tanh_out) v = tanhf(v);
       a.out[o] = v;
@@ -112,6 +115,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(Conv1dArgs a) {
 struct ConvTr1dArgs {
   const float* x; const float* w; const float* bias; const float* alpha; float* out;
   int B, Ci, T, Co, K, To, stride, pad;
+  int wt;   // 0 = [Ci][Co][K] (nn.ConvTranspose1d), 1 = [Ci][K][Co]
 };
 
 // out[b][co][n] = bias[co] + sum_ci sum_{k = (n + p) mod s, += s, < K} act(x)[b][ci][(n + p - k) / s] * w[ci][co][k]   (w: [Ci][Co][K])
@@ -120,7 +124,8 @@ __global__ __launch_bounds__(256) void convtr1d_kernel(ConvTr1dArgs a) {
   const int ntap = (a.K + a.stride - 1) / a.stride;
   const int tspan = TT / a.stride + ntap + 1;
   float* xs = sm;                         // [CIC][tspan]
-  float* ws = sm + CIC * tspan;           // [CIC][K][CT]
+  float* ws = sm + CIC * tspan;           // [CIC][K][CTP]: rows padded by 16 B -- the tap index k varies per LANE here (k = (n + p) mod s),
+                                          // and rows 128 B apart would put the lanes of a b128 group on 2 of its 16 slots
   const int b = blockIdx.z, co0 = blockIdx.y * CT, n0 = blockIdx.x * TT;
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
   const int tbase = (n0 + a.pad) / a.stride - (ntap - 1);   // input position of xs[.][0] (may be negative)
@@ -149,18 +154,18 @@ __global__ __launch_bounds__(256) void convtr1d_kernel(ConvTr1dArgs a) {
     }
     for (int i = tid; i < CIC * a.K * CT; i += 256) {
       const int co = i % CT, r = i / CT, k = r % a.K, ci = r / a.K;
-      ws[i] = (c0 + ci < a.Ci && co0 + co < a.Co) ? a.w[((size_t)(c0 + ci) * a.Co + co0 + co) * a.K + k] : 0.f;
+      ws[r * CTP + co] = (c0 + ci < a.Ci && co0 + co < a.Co) ? a.w[a.wt ? ((size_t)(c0 + ci) * a.K + k) * a.Co + co0 + co : ((size_t)(c0 + ci) * a.Co + co0 + co) * a.K + k] : 0.f;
     }
     __syncthreads();
 #pragma unroll 1
     for (int ci = 0; ci < CIC; ++ci) {
       const float* xr = xs + ci * tspan;
-      const float* wr = ws + ci * a.K * CT + ty * 4;
+      const float* wr = ws + ci * a.K * CTP + ty * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         for (int m = 0, k = kk0[j]; k < a.K; ++m, k += a.stride) {
           const float xv = xr[tt0[j] - m];
-          const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k * CT);
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k * CTP);
 #pragma unroll
           for (int c = 0; c < 4; ++c) acc[j][c] = fmaf(xv, wv[c], acc[j][c]);
         }
@@ -305,29 +310,29 @@ __global__ __launch_bounds__(256) void rvq_from_codes_kernel(FromCodesArgs a) {
 }
 
 size_t conv1d_lds(int K, int stride, int dil) { return sizeof(float) * (size_t)(CIC * ((TT - 1) * stride + (K - 1) * dil + 1) + CIC * K * CT); }
-size_t convtr_lds(int K, int stride) { return sizeof(float) * (size_t)(CIC * (TT / stride + (K + stride - 1) / stride + 1) + CIC * K * CT); }
+size_t convtr_lds(int K, int stride) { return sizeof(float) * (size_t)(CIC * (TT / stride + (K + stride - 1) / stride + 1) + CIC * K * CTP); }
 
 int launch_conv1d(const float* x, const float* w, const float* bias, const float* alpha, const float* res, float* out, int B, int Ci, int T, int Co,
-                  int K, int stride, int pad, int dil, int tanh_out, hipStream_t st) {
+                  int K, int stride, int pad, int dil, int tanh_out, hipStream_t st, int wt = 0) {
   FD_REQUIRE(B > 0 && Ci > 0 && T > 0 && Co > 0 && K > 0 && stride > 0 && dil > 0 && pad >= 0, "fd_conv1d: bad shape");
   const long long To = ((long long)T + 2 * pad - (long long)dil * (K - 1) - 1) / stride + 1;
   FD_REQUIRE(To > 0 && To < (1ll << 31), "fd_conv1d: empty output");
   const size_t lds = conv1d_lds(K, stride, dil);
   FD_REQUIRE(lds <= 64 * 1024, "fd_conv1d: kernel %d / stride %d / dilation %d needs %zu bytes of LDS (limit 64 KiB)", K, stride, dil, lds);
-  Conv1dArgs a{x, w, bias, alpha, res, out, B, Ci, T, Co, K, (int)To, stride, pad, dil, tanh_out};
+  Conv1dArgs a{x, w, bias, alpha, res, out, B, Ci, T, Co, K, (int)To, stride, pad, dil, tanh_out, wt};
   hipLaunchKernelGGL(conv1d_kernel, dim3(fd_cdiv(To, TT), fd_cdiv(Co, CT), B), dim3(256), lds, st, a);
   FD_LAUNCH_CHECK();
   return FD_OK;
 }
 
 int launch_convtr1d(const float* x, const float* w, const float* bias, const float* alpha, float* out, int B, int Ci, int T, int Co, int K, int stride,
-                    int pad, hipStream_t st) {
+                    int pad, hipStream_t st, int wt = 0) {
   FD_REQUIRE(B > 0 && Ci > 0 && T > 0 && Co > 0 && K > 0 && stride > 0 && pad >= 0, "fd_conv_transpose1d: bad shape");
   const long long To = ((long long)T - 1) * stride - 2 * pad + K;
   FD_REQUIRE(To > 0 && To < (1ll << 31), "fd_conv_transpose1d: empty output");
   const size_t lds = convtr_lds(K, stride);
   FD_REQUIRE(lds <= 64 * 1024, "fd_conv_transpose1d: kernel %d needs %zu bytes of LDS (limit 64 KiB)", K, lds);
-  ConvTr1dArgs a{x, w, bias, alpha, out, B, Ci, T, Co, K, (int)To, stride, pad};
+  ConvTr1dArgs a{x, w, bias, alpha, out, B, Ci, T, Co, K, (int)To, stride, pad, wt};
   hipLaunchKernelGGL(convtr1d_kernel, dim3(fd_cdiv(To, TT), fd_cdiv(Co, CT), B), dim3(256), lds, st, a);
   FD_LAUNCH_CHECK();
   return FD_OK;
@@ -395,7 +400,7 @@ struct Run {
   const float* P(const std::string& n) const { return m->dev.at(n); }
   int conv(const float* x, const std::string& n, const float* alpha, const float* res, float* out, int Ci, int T, int Co, int K, int stride, int pad, int dil,
            int tanh_out = 0) const {
-    return launch_conv1d(x, P(n + ".weight"), P(n + ".bias"), alpha, res, out, B, Ci, T, Co, K, stride, pad, dil, tanh_out, st);
+    return launch_conv1d(x, P(n + ".weight"), P(n + ".bias"), alpha, res, out, B, Ci, T, Co, K, stride, pad, dil, tanh_out, st, /*wt*/ 1);
   }
   // ResidualUnit: out = x + conv1(snake(conv7_dil(snake(x))))   (tmp: [B][dim][T])
   int res_unit(const float* x, const std::string& n, int dim, int T, int dil, float* tmp, float* out) const {
@@ -534,6 +539,23 @@ extern "C" int fd_ndac_finalize(fd_ndac* m, void* stream) {
   for (const Param& p : m->params) {
     auto it = m->host.find(p.name);
     if (it == m->host.end()) return fd_set_error(FD_ESTATE, "fd_ndac_finalize: parameter '%s' missing", p.name.c_str());
+    const bool enc_dec = p.name.rfind("encoder.", 0) == 0 || p.name.rfind("decoder.", 0) == 0;
+    if (enc_dec && p.shape.size() == 3 && p.name.size() > 7 && p.name.compare(p.name.size() - 7, 7, ".weight") == 0) {
+      // the conv stacks keep their weights as [Ci][K][Co] (output channel fastest: the kernels stage 32 consecutive channels per row);
+      // state_dict layout is [Co][Ci][K] for Conv1d and [Ci][Co][K] for ConvTranspose1d (the only transposed ones: `.block.1` of a decoder block)
+      size_t nblk = 0;
+      for (size_t pos = p.name.find(".block."); pos != std::string::npos; pos = p.name.find(".block.", pos + 1)) ++nblk;
+      const bool tr = p.name.rfind("decoder.model.", 0) == 0 && nblk == 1 && p.name.size() > 15 &&
+                      p.name.compare(p.name.size() - 15, 15, ".block.1.weight") == 0;   // decoder.model.<i>.block.1 = WNConvTranspose1d
+      const int d0 = p.shape[0], d1 = p.shape[1], K = p.shape[2];
+      const int Ci = tr ? d0 : d1, Co = tr ? d1 : d0;
+      std::vector<float> t((size_t)Ci * K * Co);
+      for (int ci = 0; ci < Ci; ++ci)
+        for (int k = 0; k < K; ++k)
+          for (int co = 0; co < Co; ++co)
+            t[((size_t)ci * K + k) * Co + co] = tr ? it->second[((size_t)ci * Co + co) * K + k] : it->second[((size_t)co * Ci + ci) * K + k];
+      it->second.swap(t);
+    }
     float* d = nullptr;
     FD_TRY(upload(it->second, &d));
     m->dev[p.name] = d;
@@ -672,7 +694,7 @@ extern "C" int fd_ndac_decode(fd_ndac* m, const float* z, int B, int T, float* a
     const std::string p = "decoder.model." + std::to_string(i + 1);
     int nxt = (cur + 1) % 3;
     FD_TRY(launch_convtr1d(buf[cur], r.P(p + ".block.1.weight"), r.P(p + ".block.1.bias"), r.P(p + ".block.0.alpha"), buf[nxt], B, idim, T, od, 2 * s, s,
-                           ceil_half(s), st));
+                           ceil_half(s), st, /*wt*/ 1));
     T = (T - 1) * s - 2 * ceil_half(s) + 2 * s;
     cur = nxt;
     const int dil[3] = {1, 3, 9};

@@ -554,9 +554,9 @@ class FlowModel(nn.Module):
         """Enhances a coded/noisy waveform y (model.py:476-528).  y: [L], [1, L] or [B, 1, L]."""
         if with_grad:
             raise NotImplementedError("flowdec_amd.FlowModel.enhance: with_grad=True (backprop through the solver) is out of scope")
-        adaptive = solver == "dopri5"
+        adaptive = solver in L.ADAPTIVE_SOLVERS
         if not adaptive and solver not in L.SOLVERS:
-            raise ValueError(f"unknown solver {solver!r}; supported: {sorted(L.SOLVERS) + ['dopri5']}")
+            raise ValueError(f"unknown solver {solver!r}; supported: {sorted(L.SOLVERS) + sorted(L.ADAPTIVE_SOLVERS)}")
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("flowdec_amd: move the model to the GPU first (`model.cuda()`)")
@@ -587,7 +587,7 @@ class FlowModel(nn.Module):
             with torch.cuda.stream(side):
                 if adaptive:
                     res = self._enhance_adaptive(lib, h, cfg, io, B, Lw, F, T, Tp, N, sigma_fac, return_traj, squeeze_dims, dev,
-                                                 float(kwargs.get("atol", 1e-4)), float(kwargs.get("rtol", 1e-4)))
+                                                 float(kwargs.get("atol", 1e-4)), float(kwargs.get("rtol", 1e-4)), L.ADAPTIVE_SOLVERS[solver])
                 else:
                     res = self._enhance_native(lib, h, cfg, io, B, Lw, F, T, Tp, N, solver, sigma_fac, return_traj,
                                                return_preprocess_info, squeeze_dims, use_graph, dev)
@@ -604,8 +604,8 @@ class FlowModel(nn.Module):
         x_hat = x_hat.to(orig_device)
         return (x_hat, info) if return_preprocess_info else x_hat
 
-    def _enhance_adaptive(self, lib, h, cfg, io, B, Lw, F, T, Tp, N, sigma_fac, return_traj, squeeze_dims, dev, atol, rtol):
-        """solver='dopri5': adaptive Dormand-Prince over t_span = linspace(0, 1, N+1) (torchdyn semantics restated, unpinned);
+    def _enhance_adaptive(self, lib, h, cfg, io, B, Lw, F, T, Tp, N, sigma_fac, return_traj, squeeze_dims, dev, atol, rtol, method=0):
+        """solver='dopri5' / 'tsit5': adaptive 5(4) pair over t_span = linspace(0, 1, N+1) (torchdyn semantics restated, unpinned);
         host-driven (one read-back per attempted step), so no hipGraph.  The realised NFE is left in `self.last_nfe`."""
         from . import ops
         Y, normfac, _ = ops.stft_compress(io["y"], normalize=self.normalize_mode == "noisy", **cfg)
@@ -614,7 +614,7 @@ class FlowModel(nn.Module):
         need = lib.fd_ode_adaptive_workspace_bytes(h, B, Tp)
         ws = self.backbone.workspace(("ode", B, Tp), need, dev)
         nfe = C.c_int(0)
-        L.check(lib.fd_ode_solve_adaptive(h, L.ptr(torch.view_as_real(Y)), L.ptr(torch.view_as_real(io["noise"])), float(sigma_fac), int(N),
+        L.check(lib.fd_ode_solve_adaptive_method(h, L.ptr(torch.view_as_real(Y)), L.ptr(torch.view_as_real(io["noise"])), float(sigma_fac), int(N), int(method),
                                           atol, rtol, L.ptr(torch.view_as_real(X)), L.ptr(torch.view_as_real(traj)) if return_traj else None,
                                           C.byref(nfe), B, Tp, L.ptr(ws), ws.numel(), L.stream()))
         self.last_nfe = int(nfe.value)

@@ -277,6 +277,12 @@ int fd_ode_solve(fd_model* m, const float* Y, const float* noise, float sigma_fa
 size_t fd_ode_adaptive_workspace_bytes(const fd_model* m, int B, int T_pad);
 int fd_ode_solve_adaptive(fd_model* m, const float* Y, const float* noise, float sigma_fac, int N, float atol, float rtol,
                           float* X_out, float* traj, int* nfe_out, int B, int T_pad, void* ws, size_t ws_bytes, void* stream);
+/* Same driver with the embedded pair chosen by id: Dormand-Prince 5(4) ('dopri5') or Tsitouras 5(4) ('tsit5', the default solver of
+ * torchdyn's NeuralODE); both 7 stages with FSAL, the same controller. */
+#define FD_ADAPTIVE_DOPRI5 0
+#define FD_ADAPTIVE_TSIT5 1
+int fd_ode_solve_adaptive_method(fd_model* m, const float* Y, const float* noise, float sigma_fac, int N, int method, float atol, float rtol,
+                                 float* X_out, float* traj, int* nfe_out, int B, int T_pad, void* ws, size_t ws_bytes, void* stream);
 size_t fd_enhance_workspace_bytes(const fd_model* m, int B, int L);
 /* Byte offset, inside the workspace of fd_enhance / fd_score_enhance / fd_regression_enhance, of the B float32 normalisation
  * factors the front end computed (EnhancementModel._preprocess' `normfac`, model.py:156-162); valid after the call. */

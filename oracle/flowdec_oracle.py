@@ -776,7 +776,7 @@ def score_ode_enhance(net: NCSNppOracle, y: np.ndarray, prior_noise: np.ndarray,
 # Call site: flowdec/model.py:511-514 `NeuralODE(node_fn, solver=solver, sensitivity="adjoint").trajectory(x0, t_span)`.
 # Every constant below, with the place in the torchdyn 1.0.6 source tree it restates, so that a reader WITH the package can
 # check it line by line (paths relative to site-packages/torchdyn/):
-#   tableau c, A, b5, b4         numerics/solvers/_constants.py `construct_dopri5` -- the classical Dormand-Prince 5(4) pair, 7 stages,
+#   tableau c, A, b5, b4         numerics/solvers/_constants.py `construct_dopri5` (and `construct_tsit5` for solver='tsit5', below) -- the classical Dormand-Prince 5(4) pair, 7 stages,
 #                                FSAL (stage 7 is evaluated at the 5th-order solution and becomes k1 of the next step)
 #   order = 5                    numerics/solvers/ode.py `DormandPrince45.__init__` (super().__init__(order=5, stepping_class='adaptive'))
 #   safety = 0.9, min_factor = 0.2, max_factor = 10        same class: `self.safety, self.min_factor, self.max_factor`
@@ -819,9 +819,25 @@ def dopri5_adapt_step(dt, ratio, safety=0.9, min_factor=0.2, max_factor=10.0, or
     return np.float32(dt * min(max_factor, max(safety / ratio ** (1.0 / order), min_factor)))
 
 
-def odeint_dopri5(f: Callable[[np.float32, np.ndarray], np.ndarray], x: np.ndarray, t_span: np.ndarray, atol=1e-4, rtol=1e-4,
-                  return_traj: bool = False, max_steps: int = 100000):
-    """-> (x(T) or [x(t_span[i])], nfe).  State dtype is kept (complex64 / float32 / float64); t, dt are float32."""
+# Tsitouras 5(4) ('tsit5', torchdyn's NeuralODE DEFAULT solver; numerics/solvers/_constants.py `construct_tsit5`, numerics/solvers/ode.py
+# `Tsitouras45`: order 5, the same safety / min_factor / max_factor, FSAL).  Coefficients as published (Ch. Tsitouras, "Runge-Kutta pairs of
+# order 5(4) satisfying only the first column simplifying assumption", 2011) -- typed from memory and VERIFIED: every order condition up
+# to order 5 holds to 1e-16 and the pair converges with order 5.4 / its estimator with order 5 (tests/test_oracle_golden.py).
+TSIT5_C = (0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0)
+TSIT5_A = ((), (0.161,), (-0.008480655492356989, 0.335480655492357), (2.8971530571054935, -6.359448489975075, 4.3622954328695815),
+           (5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525),
+           (5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383),
+           (0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774))
+TSIT5_E = (-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995, -0.1447110071732629, 0.5823571654525552, -0.45808210592918697,
+           0.015151515151515152)
+ADAPTIVE_TABLEAUS = {"dopri5": (DOPRI5_C, DOPRI5_A, DOPRI5_E), "tsit5": (TSIT5_C, TSIT5_A, TSIT5_E)}
+
+
+def odeint_adaptive(f: Callable[[np.float32, np.ndarray], np.ndarray], x: np.ndarray, t_span: np.ndarray, method: str = "dopri5", atol=1e-4,
+                    rtol=1e-4, return_traj: bool = False, max_steps: int = 100000):
+    """-> (x(T) or [x(t_span[i])], nfe).  State dtype is kept (complex64 / float32 / float64); t, dt are float32.  7-stage FSAL pairs of
+    order 5(4): 'dopri5' | 'tsit5' (the last row of A are the 5th-order weights; E the error weights)."""
+    C_, A_, E_ = ADAPTIVE_TABLEAUS[method]
     dt_ = x.dtype
     t, T = np.float32(t_span[0]), np.float32(t_span[-1])
     t_eval = [np.float32(v) for v in t_span[1:]]
@@ -839,7 +855,7 @@ def odeint_dopri5(f: Callable[[np.float32, np.ndarray], np.ndarray], x: np.ndarr
     while t < T:
         steps += 1
         if steps > max_steps:
-            raise RuntimeError("odeint_dopri5: step limit")
+            raise RuntimeError("odeint_adaptive: step limit")
         if np.float32(t + dt) > T:
             dt = np.float32(T - t)
         flag = False
@@ -850,15 +866,15 @@ def odeint_dopri5(f: Callable[[np.float32, np.ndarray], np.ndarray], x: np.ndarr
         for s in range(1, 7):
             xs = x
             acc = np.zeros_like(x)
-            for j, a in enumerate(DOPRI5_A[s]):
+            for j, a in enumerate(A_[s]):
                 if a != 0.0:
                     acc = acc + np.float32(a) * ks[j]
             xs = (x + dt * acc).astype(dt_)
             if s == 6:
                 x_new = xs
-            ks.append(f(np.float32(t + np.float32(DOPRI5_C[s]) * dt), xs).astype(dt_)); nfe += 1
+            ks.append(f(np.float32(t + np.float32(C_[s]) * dt), xs).astype(dt_)); nfe += 1
         err = np.zeros_like(x)
-        for j, e in enumerate(DOPRI5_E):
+        for j, e in enumerate(E_):
             if e != 0.0:
                 err = err + np.float32(e) * ks[j]
         err = (dt * err).astype(dt_)
@@ -873,3 +889,7 @@ def odeint_dopri5(f: Callable[[np.float32, np.ndarray], np.ndarray], x: np.ndarr
             dt = np.float32(dt_old - dt)
         dt = dopri5_adapt_step(dt, ratio)
     return (traj if return_traj else x), nfe
+
+
+def odeint_dopri5(f, x, t_span, atol=1e-4, rtol=1e-4, return_traj: bool = False, max_steps: int = 100000):
+    return odeint_adaptive(f, x, t_span, "dopri5", atol, rtol, return_traj, max_steps)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Fixture for solver='dopri5' (adaptive Dormand-Prince).  NOT a reference output: torchdyn is not installed, so this is
+"""Fixture for solver='dopri5' / 'tsit5' (adaptive 5(4) pairs).  NOT a reference output: torchdyn is not installed, so this is
 produced by the ORACLE's restatement of torchdyn's controller (oracle.odeint_dopri5, parity unpinned) on the inputs of
 g9_enhance_nf8.npz; it lets the GPU test check the HIP driver without running ~60 oracle forward passes on the GPU box.
 
@@ -29,6 +29,11 @@ def main():
         out["mid_feat_norm"] = np.float64(np.linalg.norm(traj[1].ravel()))
         out["nfe_tol1e-3"] = np.int64(nfe)
         print("tol", tol, "nfe", nfe)
+        traj, nfe = O.odeint_adaptive(f, x0, O.t_span_linspace(2), "tsit5", atol=tol, rtol=tol, return_traj=True)
+        out["tsit5_wave_tol1e-3"] = O.postprocess(traj[-1], info)
+        out["tsit5_mid_feat_norm"] = np.float64(np.linalg.norm(traj[1].ravel()))
+        out["tsit5_nfe_tol1e-3"] = np.int64(nfe)
+        print("tsit5 tol", tol, "nfe", nfe)
     np.savez_compressed(os.path.join(HERE, "g16_dopri5_oracle_nf8.npz"), **out)
 
 

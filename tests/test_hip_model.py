@@ -250,3 +250,12 @@ def test_enhance_dopri5_adaptive_vs_oracle():
     # a tighter tolerance costs more evaluations (the random-weight field is too stiff for the two answers to be compared)
     tight = m.enhance(y, N=2, solver="dopri5", noise=nz, atol=1e-5, rtol=1e-5)
     assert m.last_nfe > nfe and torch.isfinite(tight).all()
+    # solver='tsit5' (Tsitouras 5(4), torchdyn's NeuralODE default): the same driver with the other tableau
+    out5 = m.enhance(y, N=2, solver="tsit5", noise=nz, atol=1e-3, rtol=1e-3)
+    n5, n5_ref = m.last_nfe, int(ref["tsit5_nfe_tol1e-3"])
+    assert (n5 - 2) % 6 == 0 and abs(n5 - n5_ref) <= 12, (n5, n5_ref)
+    check("enhance_tsit5[fp32]", out5.numpy(), ref["tsit5_wave_tol1e-3"], 5e-3)
+    traj5, _ = m.enhance(y, N=2, solver="tsit5", noise=nz, atol=1e-3, rtol=1e-3, return_traj=True)
+    assert abs(float(torch.view_as_real(traj5[1]).double().pow(2).sum().sqrt()) / float(ref["tsit5_mid_feat_norm"]) - 1) < 1e-3
+    with pytest.raises(ValueError):
+        m.enhance(y, N=2, solver="rk4")

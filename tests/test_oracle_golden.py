@@ -272,3 +272,52 @@ def test_torch_oracle_matches_numpy_oracle_and_golden():
     for solver, N in (("euler", 6), ("midpoint", 3), ("heun2", 3)):
         got = OT.enhance(net, g9["y"], g9["noise"], g9["sigma_y"], N=N, solver=solver)
         assert rel_err(got, g9[f"{solver}_N{N}"]) < 1e-4, solver
+
+
+def test_adaptive_tableaus_order_conditions_and_tsit5_against_scipy():
+    """Both embedded pairs of the adaptive driver ('dopri5', and 'tsit5' = torchdyn's NeuralODE default) satisfy every order condition
+    up to order 5 (the Tsitouras coefficients are typed from the publication: this is their check), their error weights those up to
+    order 4 with weight sum 0, the solution converges with order >= 5; 'tsit5' integrates the nonlinear complex test system to
+    tolerance, agrees with scipy's RK45, hits the checkpoints exactly and reuses its last stage (6 evaluations per step + 2)."""
+    from scipy import integrate
+    for name, (C_, A_, E_) in O.ADAPTIVE_TABLEAUS.items():
+        c = np.array(C_, np.float64)
+        A = np.zeros((7, 7))
+        for i in range(7):
+            A[i, :len(A_[i])] = A_[i]
+        b, e = A[6].copy(), np.array(E_, np.float64)
+        assert np.abs(A.sum(1) - c).max() < 1e-15, name                                     # row sums
+        one = np.ones(7)
+        conds = [(b @ one, 1), (b @ c, 1 / 2), (b @ c ** 2, 1 / 3), (b @ A @ c, 1 / 6), (b @ c ** 3, 1 / 4), ((b * c) @ A @ c, 1 / 8), (b @ A @ c ** 2, 1 / 12),
+                 (b @ A @ A @ c, 1 / 24), (b @ c ** 4, 1 / 5), ((b * c ** 2) @ A @ c, 1 / 10), ((b * c) @ A @ c ** 2, 1 / 15), ((b * c) @ A @ A @ c, 1 / 30),
+                 (b @ (A @ c) ** 2, 1 / 20), (b @ A @ c ** 3, 1 / 20), (b @ A @ (c * (A @ c)), 1 / 40), (b @ A @ A @ c ** 2, 1 / 60), (b @ A @ A @ A @ c, 1 / 120)]
+        assert max(abs(v - w) for v, w in conds) < 1e-15, (name, [abs(v - w) for v, w in conds])
+        econds = [e @ one, e @ c, e @ c ** 2, e @ A @ c, e @ c ** 3, (e * c) @ A @ c, e @ A @ c ** 2, e @ A @ A @ c]
+        assert max(abs(v) for v in econds) < 1e-15, (name, econds)                        # the embedded 4th-order solution
+        assert A[6, 6] == 0 and c[6] == 1.0                                                 # FSAL: stage 7 is f at the 5th-order solution
+
+        def solve(n):
+            x, h = np.array([1.0, 0.0]), 2.0 / n
+            f = lambda t, x_: np.array([x_[1], -x_[0]]) * (1 + 0.3 * np.sin(t))
+            for i in range(n):
+                k = [f(i * h, x)]
+                for s in range(1, 7):
+                    k.append(f(i * h + c[s] * h, x + h * sum(A[s, j] * k[j] for j in range(s))))
+                x = x + h * sum(b[j] * k[j] for j in range(7))
+            return x
+        ref = solve(2048)
+        errs = [np.abs(solve(n) - ref).max() for n in (8, 16, 32)]
+        assert all(np.log2(a / b_) > 4.7 for a, b_ in zip(errs, errs[1:])), (name, errs)
+    rng = np.random.default_rng(5)
+    A = (rng.standard_normal((6, 6)) + 1j * rng.standard_normal((6, 6))).astype(np.complex64) - 3 * np.eye(6, dtype=np.complex64)
+    x0 = (rng.standard_normal(6) + 1j * rng.standard_normal(6)).astype(np.complex64)
+    f = lambda t, x: (A @ x + np.float32(np.sin(3 * t)) * x * np.abs(x)).astype(np.complex64)
+    ts = O.linspace_f32(0.0, 1.0, 9)
+    traj, nfe = O.odeint_adaptive(f, x0, ts, "tsit5", atol=1e-6, rtol=1e-6, return_traj=True)
+    assert len(traj) == 9 and (nfe - 2) % 6 == 0
+    sol = integrate.solve_ivp(lambda t, x: A.astype(np.complex128) @ x + np.sin(3 * t) * x * np.abs(x), (0.0, 1.0), x0.astype(np.complex128),
+                              method="RK45", rtol=1e-10, atol=1e-12, t_eval=[float(v) for v in ts])
+    for i in range(9):
+        assert rel_err(traj[i], sol.y[:, i]) < 2e-5
+    xd, nd = O.odeint_adaptive(f, x0, ts, "dopri5", atol=1e-6, rtol=1e-6)
+    assert rel_err(traj[-1], xd) < 2e-5
