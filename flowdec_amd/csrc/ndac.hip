@@ -44,6 +44,8 @@ __device__ __forceinline__ float snake_f(float x, float alpha) {
 
 struct Conv1dArgs {
   const float* x; const float* w; const float* bias; const float* alpha; const float* res; float* out;
+  float* out_act; const float* alpha_out;   // optional second output: snake(result, alpha_out[co]) -- the NEXT layer's activated input,
+                                            // computed once by the producer instead of once per consuming workgroup (24x at 768 channels)
   int B, Ci, T, Co, K, To, stride, pad, dil, tanh_out;
   int wt;   // weight layout: 0 = [Co][Ci][K] (nn.Conv1d, the operator-level ABI), 1 = [Ci][K][Co] (the codec's own copy: coalesced staging)
 };
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(Conv1dArgs a) {
     const int co = co0 + ty * 4 + c;
     if (co >= a.Co) continue;
     const float bv = a.bias ? a.bias[co] : 0.f;
+    const float ao = a.out_act ? a.alpha_out[co] : 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int t = t0 + tx + 32 * j;
@@ -107,13 +110,105 @@ __global__ __launch_bounds__(256) void conv1d_kernel(Conv1dArgs a) {
       float v = acc[j][c >> 1][c & 1] + bv;
       if (a.res) v += a.res[o];
       if (a.tanh_out) v = tanhf(v);
-      a.out[o] = v;
+      if (a.out) a.out[o] = v;
+      if (a.out_act) a.out_act[o] = snake_f(v, ao);
     }
+  }
+}
+
+// Stride-1 convolutions with a compile-time tap count and dilation (every ResidualUnit conv: K = 7 with dilation 1 / 3, K = 1; the
+// K = 3 latent conv): a thread owns two groups of 4 CONSECUTIVE outputs (t0 + 4 tx + {0..3} and 128 further) x 4 channels.  Per input
+// channel the 4 + (K - 1) DIL inputs a group needs are read ONCE as aligned ds_read_b128 (lane stride 16 B: conflict-free) into a
+// register window and all K taps run out of registers -- 13 wide LDS reads per 224 packed-FMA pairs (K = 7, DIL = 1) where the generic
+// kernel above issues one ds_read_b32 per 4 FMAs and is bound by the LDS pipe.  256 outputs x 32 channels per workgroup.
+constexpr int TT1 = 256;
+template <int K, int DIL>
+__global__ __launch_bounds__(256) void conv1d_s1_kernel(Conv1dArgs a) {
+  extern __shared__ float sm[];
+  constexpr int HALO = (K - 1) * DIL;
+  constexpr int SPAN = (TT1 + HALO + 3) / 4 * 4;     // floats per staged input row (multiple of 4: aligned b128 rows)
+  constexpr int NW = (4 + HALO + 3) / 4;             // b128 reads per group window
+  float* xs = sm;                                    // [CIC][SPAN]
+  float* ws = sm + CIC * SPAN;                       // [CIC][K][CT]
+  const int b = blockIdx.z, co0 = blockIdx.y * CT, t0 = blockIdx.x * TT1;
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  f32x2 acc[2][4][2];   // [group][output][channel pair]
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[g][i][0] = acc[g][i][1] = f32x2{0.f, 0.f};
+  const long long in0 = (long long)t0 - a.pad;
+  for (int c0 = 0; c0 < a.Ci; c0 += CIC) {
+    __syncthreads();
+    for (int i = tid; i < CIC * SPAN; i += 256) {
+      const int ci = i / SPAN, p = i - ci * SPAN;
+      const long long tin = in0 + p;
+      float v = 0.f;
+      if (c0 + ci < a.Ci && tin >= 0 && tin < a.T) {
+        v = a.x[((size_t)b * a.Ci + c0 + ci) * a.T + tin];
+        if (a.alpha) v = snake_f(v, a.alpha[c0 + ci]);
+      }
+      xs[i] = v;
+    }
+    for (int i = tid; i < CIC * K * CT; i += 256) {
+      const int co = i % CT, r = i / CT, k = r % K, ci = r / K;
+      ws[i] = (c0 + ci < a.Ci && co0 + co < a.Co) ? a.w[a.wt ? ((size_t)(c0 + ci) * K + k) * a.Co + co0 + co : ((size_t)(co0 + co) * a.Ci + c0 + ci) * K + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int ci = 0; ci < CIC; ++ci) {
+      const float* wr = ws + ci * K * CT + ty * 4;
+      f32x2 w01[K], w23[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k * CT);
+        w01[k] = f32x2{wv[0], wv[1]}; w23[k] = f32x2{wv[2], wv[3]};
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const float* xr = xs + ci * SPAN + 4 * tx + 128 * g;
+        float xw[4 * NW];
+#pragma unroll
+        for (int m = 0; m < NW; ++m) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * m);
+          xw[4 * m] = v[0]; xw[4 * m + 1] = v[1]; xw[4 * m + 2] = v[2]; xw[4 * m + 3] = v[3];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const f32x2 x2 = {xw[i + k * DIL], xw[i + k * DIL]};
+            acc[g][i][0] = __builtin_elementwise_fma(x2, w01[k], acc[g][i][0]);
+            acc[g][i][1] = __builtin_elementwise_fma(x2, w23[k], acc[g][i][1]);
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int co = co0 + ty * 4 + c;
+    if (co >= a.Co) continue;
+    const float bv = a.bias ? a.bias[co] : 0.f;
+    const float ao = a.out_act ? a.alpha_out[co] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int t = t0 + 4 * tx + 128 * g + i;
+        if (t >= a.To) continue;
+        const size_t o = ((size_t)b * a.Co + co) * a.To + t;
+        float v = acc[g][i][c >> 1][c & 1] + bv;
+        if (a.res) v += a.res[o];
+        if (a.tanh_out) v = tanhf(v);
+        if (a.out) a.out[o] = v;
+        if (a.out_act) a.out_act[o] = snake_f(v, ao);
+      }
   }
 }
 
 struct ConvTr1dArgs {
   const float* x; const float* w; const float* bias; const float* alpha; float* out;
+  float* out_act; const float* alpha_out;
   int B, Ci, T, Co, K, To, stride, pad;
   int wt;   // 0 = [Ci][Co][K] (nn.ConvTranspose1d), 1 = [Ci][K][Co]
 };
@@ -180,7 +275,12 @@ __global__ __launch_bounds__(256) void convtr1d_kernel(ConvTr1dArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + tx + 32 * j;
-      if (n < a.To) a.out[((size_t)b * a.Co + co) * a.To + n] = acc[j][c] + bv;
+      if (n < a.To) {
+        const size_t o = ((size_t)b * a.Co + co) * a.To + n;
+        const float v = acc[j][c] + bv;
+        if (a.out) a.out[o] = v;
+        if (a.out_act) a.out_act[o] = snake_f(v, a.alpha_out[co]);
+      }
     }
   }
 }
@@ -313,26 +413,36 @@ size_t conv1d_lds(int K, int stride, int dil) { return sizeof(float) * (size_t)(
 size_t convtr_lds(int K, int stride) { return sizeof(float) * (size_t)(CIC * (TT / stride + (K + stride - 1) / stride + 1) + CIC * K * CTP); }
 
 int launch_conv1d(const float* x, const float* w, const float* bias, const float* alpha, const float* res, float* out, int B, int Ci, int T, int Co,
-                  int K, int stride, int pad, int dil, int tanh_out, hipStream_t st, int wt = 0) {
+                  int K, int stride, int pad, int dil, int tanh_out, hipStream_t st, int wt = 0, float* out_act = nullptr, const float* alpha_out = nullptr) {
   FD_REQUIRE(B > 0 && Ci > 0 && T > 0 && Co > 0 && K > 0 && stride > 0 && dil > 0 && pad >= 0, "fd_conv1d: bad shape");
   const long long To = ((long long)T + 2 * pad - (long long)dil * (K - 1) - 1) / stride + 1;
   FD_REQUIRE(To > 0 && To < (1ll << 31), "fd_conv1d: empty output");
   const size_t lds = conv1d_lds(K, stride, dil);
   FD_REQUIRE(lds <= 64 * 1024, "fd_conv1d: kernel %d / stride %d / dilation %d needs %zu bytes of LDS (limit 64 KiB)", K, stride, dil, lds);
-  Conv1dArgs a{x, w, bias, alpha, res, out, B, Ci, T, Co, K, (int)To, stride, pad, dil, tanh_out, wt};
+  Conv1dArgs a{x, w, bias, alpha, res, out, out_act, alpha_out, B, Ci, T, Co, K, (int)To, stride, pad, dil, tanh_out, wt};
+  // the accumulation order per output is the same in both kernels (input channels ascending, taps ascending, one fma each): identical bits
+#define FD_CONV1D_S1(K_, D_)                                                                                                                      \
+  if (stride == 1 && K == K_ && dil == D_ && Co >= 4) {                                                                                           \
+    constexpr size_t lds1 = sizeof(float) * (size_t)(CIC * ((TT1 + (K_ - 1) * D_ + 3) / 4 * 4) + CIC * K_ * CT);                                    \
+    hipLaunchKernelGGL((conv1d_s1_kernel<K_, D_>), dim3(fd_cdiv(To, TT1), fd_cdiv(Co, CT), B), dim3(256), lds1, st, a);                            \
+    FD_LAUNCH_CHECK();                                                                                                                            \
+    return FD_OK;                                                                                                                                 \
+  }
+  FD_CONV1D_S1(7, 1) FD_CONV1D_S1(7, 3) FD_CONV1D_S1(1, 1) FD_CONV1D_S1(3, 1)
+#undef FD_CONV1D_S1
   hipLaunchKernelGGL(conv1d_kernel, dim3(fd_cdiv(To, TT), fd_cdiv(Co, CT), B), dim3(256), lds, st, a);
   FD_LAUNCH_CHECK();
   return FD_OK;
 }
 
 int launch_convtr1d(const float* x, const float* w, const float* bias, const float* alpha, float* out, int B, int Ci, int T, int Co, int K, int stride,
-                    int pad, hipStream_t st, int wt = 0) {
+                    int pad, hipStream_t st, int wt = 0, float* out_act = nullptr, const float* alpha_out = nullptr) {
   FD_REQUIRE(B > 0 && Ci > 0 && T > 0 && Co > 0 && K > 0 && stride > 0 && pad >= 0, "fd_conv_transpose1d: bad shape");
   const long long To = ((long long)T - 1) * stride - 2 * pad + K;
   FD_REQUIRE(To > 0 && To < (1ll << 31), "fd_conv_transpose1d: empty output");
   const size_t lds = convtr_lds(K, stride);
   FD_REQUIRE(lds <= 64 * 1024, "fd_conv_transpose1d: kernel %d needs %zu bytes of LDS (limit 64 KiB)", K, lds);
-  ConvTr1dArgs a{x, w, bias, alpha, out, B, Ci, T, Co, K, (int)To, stride, pad, wt};
+  ConvTr1dArgs a{x, w, bias, alpha, out, out_act, alpha_out, B, Ci, T, Co, K, (int)To, stride, pad, wt};
   hipLaunchKernelGGL(convtr1d_kernel, dim3(fd_cdiv(To, TT), fd_cdiv(Co, CT), B), dim3(256), lds, st, a);
   FD_LAUNCH_CHECK();
   return FD_OK;
@@ -395,17 +505,23 @@ void build_params(fd_ndac* m) {
   conv("decoder.model." + std::to_string(c.n_decoder_rates + 2), 1, od, 7);
 }
 
+// Inside the codec every Snake is applied ONCE, by the layer that produces the tensor (second output of its epilogue), never by the
+// consumers: the activated input of a 768-channel convolution would otherwise be recomputed by each of its 24 channel-tile workgroups
+// (sinf + a division per element).  Same function on the same float32 values: bit-identical to activating at the consumer.
 struct Run {
   fd_ndac* m; hipStream_t st; int B;
   const float* P(const std::string& n) const { return m->dev.at(n); }
-  int conv(const float* x, const std::string& n, const float* alpha, const float* res, float* out, int Ci, int T, int Co, int K, int stride, int pad, int dil,
-           int tanh_out = 0) const {
-    return launch_conv1d(x, P(n + ".weight"), P(n + ".bias"), alpha, res, out, B, Ci, T, Co, K, stride, pad, dil, tanh_out, st, /*wt*/ 1);
+  // conv over an ALREADY ACTIVATED (or raw, for the first layer of a stack) input; raw result -> out (may be null), snake(result,
+  // alpha_next) -> out_act (may be null)
+  int conv(const float* x, const std::string& n, const float* res, float* out, float* out_act, const float* alpha_next, int Ci, int T, int Co, int K,
+           int stride, int pad, int dil, int tanh_out = 0) const {
+    return launch_conv1d(x, P(n + ".weight"), P(n + ".bias"), nullptr, res, out, B, Ci, T, Co, K, stride, pad, dil, tanh_out, st, /*wt*/ 1, out_act, alpha_next);
   }
-  // ResidualUnit: out = x + conv1(snake(conv7_dil(snake(x))))   (tmp: [B][dim][T])
-  int res_unit(const float* x, const std::string& n, int dim, int T, int dil, float* tmp, float* out) const {
-    FD_TRY(conv(x, n + ".block.1", P(n + ".block.0.alpha"), nullptr, tmp, dim, T, dim, 7, 1, 3 * dil, dil));
-    return conv(tmp, n + ".block.3", P(n + ".block.2.alpha"), x, out, dim, T, dim, 1, 1, 0, 1);
+  // ResidualUnit on (x_raw, x_act = snake(x, block.0.alpha)): y = x + conv1(snake(conv7_dil(x_act))); -> y_raw (may be null), snake(y, alpha_next)
+  int res_unit(const float* x_raw, const float* x_act, const std::string& n, int dim, int T, int dil, float* tmp_act, float* y_raw, float* y_act,
+               const float* alpha_next) const {
+    FD_TRY(conv(x_act, n + ".block.1", nullptr, nullptr, tmp_act, P(n + ".block.2.alpha"), dim, T, dim, 7, 1, 3 * dil, dil));
+    return conv(tmp_act, n + ".block.3", x_raw, y_raw, y_act, alpha_next, dim, T, dim, 1, 1, 0, 1);
   }
 };
 
@@ -617,7 +733,7 @@ extern "C" size_t fd_ndac_workspace_bytes(const fd_ndac* m, int B, int L) {
   if (d > e) e = d;
   const long long lat = (long long)m->cfg.latent_dim * (T > 0 ? T : 1);
   if (lat > e) e = lat;
-  return 3 * fd_align(sizeof(float) * (size_t)B * e) + 256;
+  return 5 * fd_align(sizeof(float) * (size_t)B * e) + 256;   // {raw, activated} of the current tensor, {raw, activated} of the next, one mid-unit tensor
 }
 
 extern "C" int fd_rvq_encode(fd_ndac* m, const float* z, int B, int T, int n_quantizers, float* z_q, int* codes, float* latents, void* ws, size_t ws_bytes,
@@ -651,30 +767,37 @@ extern "C" int fd_ndac_encode(fd_ndac* m, const float* x, int B, int L, int n_qu
   if (ws_bytes < need) return fd_set_error(FD_ENOMEM, "fd_ndac_encode: workspace %zu < required %zu bytes", ws_bytes, need);
   const fd_ndac_config& c = m->cfg;
   hipStream_t st = fd_stream(stream);
-  const size_t slot = (need - 256) / 3;
-  float* buf[3] = {(float*)ws, (float*)((char*)ws + slot), (float*)((char*)ws + 2 * slot)};
+  const size_t slot = (need - 256) / 5;
+  float* buf[5];
+  for (int i = 0; i < 5; ++i) buf[i] = (float*)((char*)ws + i * slot);
   Run r{m, st, B};
   int T = L, d = c.encoder_dim;
-  FD_TRY(r.conv(x, "encoder.block.0", nullptr, nullptr, buf[0], 1, T, d, 7, 1, 3, 1));
-  int cur = 0;
+  float *cur_raw = buf[0], *cur_act = buf[1], *nxt_raw = buf[2], *nxt_act = buf[3], *tmp = buf[4];
+  auto alpha_of = [&](const std::string& n) { return r.P(n + ".alpha"); };
+  // block.0: WNConv1d(1, d, 7) on the raw audio; its output enters EncoderBlock 1 = ResidualUnit 0 (needs raw + snake(block.0.alpha))
+  FD_TRY(r.conv(x, "encoder.block.0", nullptr, cur_raw, cur_act, alpha_of("encoder.block.1.block.0.block.0"), 1, T, d, 7, 1, 3, 1));
   for (int i = 0; i < c.n_encoder_rates; ++i) {
     const std::string p = "encoder.block." + std::to_string(i + 1);
     const int dil[3] = {1, 3, 9};
-    for (int j = 0; j < 3; ++j) {
-      const int tmp = (cur + 1) % 3, nxt = (cur + 2) % 3;
-      FD_TRY(r.res_unit(buf[cur], p + ".block." + std::to_string(j), d, T, dil[j], buf[tmp], buf[nxt]));
-      cur = nxt;
+    for (int j = 0; j < 3; ++j) {   // unit j -> (raw, activated for unit j + 1 / for the block's Snake in front of the strided conv)
+      const float* an = j < 2 ? alpha_of(p + ".block." + std::to_string(j + 1) + ".block.0") : alpha_of(p + ".block.3");
+      FD_TRY(r.res_unit(cur_raw, cur_act, p + ".block." + std::to_string(j), d, T, dil[j], tmp, j < 2 ? nxt_raw : nullptr, nxt_act, an));
+      std::swap(cur_raw, nxt_raw); std::swap(cur_act, nxt_act);
     }
-    const int s = c.encoder_rates[i], nxt = (cur + 1) % 3;
-    FD_TRY(r.conv(buf[cur], p + ".block.4", r.P(p + ".block.3.alpha"), nullptr, buf[nxt], d, T, 2 * d, 2 * s, s, ceil_half(s), 1));
+    const int s = c.encoder_rates[i];
+    const bool last = i + 1 == c.n_encoder_rates;
+    const float* an = last ? alpha_of("encoder.block." + std::to_string(c.n_encoder_rates + 1))
+                           : alpha_of("encoder.block." + std::to_string(i + 2) + ".block.0.block.0");
+    FD_TRY(r.conv(cur_act, p + ".block.4", nullptr, last ? nullptr : nxt_raw, nxt_act, an, d, T, 2 * d, 2 * s, s, ceil_half(s), 1));
+    std::swap(cur_raw, nxt_raw); std::swap(cur_act, nxt_act);
     T = (T + 2 * ceil_half(s) - 2 * s) / s + 1;
-    d *= 2; cur = nxt;
+    d *= 2;
   }
-  const int nxt = (cur + 1) % 3;
   const std::string last = "encoder.block." + std::to_string(c.n_encoder_rates + 2);
-  FD_TRY(r.conv(buf[cur], last, r.P("encoder.block." + std::to_string(c.n_encoder_rates + 1) + ".alpha"), nullptr, buf[nxt], d, T, c.latent_dim, 3, 1, 1, 1));
+  FD_TRY(r.conv(cur_act, last, nullptr, nxt_raw, nullptr, nullptr, d, T, c.latent_dim, 3, 1, 1, 1));
+  float* const zbuf = nxt_raw;
   const int nq = n_quantizers <= 0 || n_quantizers > c.n_codebooks ? c.n_codebooks : n_quantizers;
-  return rvq_run(m, buf[nxt], B, T, nq, z_q, codes, latents, st);
+  return rvq_run(m, zbuf, B, T, nq, z_q, codes, latents, st);
 }
 
 extern "C" int fd_ndac_decode(fd_ndac* m, const float* z, int B, int T, float* audio, void* ws, size_t ws_bytes, void* stream) {
@@ -682,28 +805,34 @@ extern "C" int fd_ndac_decode(fd_ndac* m, const float* z, int B, int T, float* a
   FD_REQUIRE(z && audio && ws && B > 0 && T > 0, "fd_ndac_decode: bad arguments");
   const fd_ndac_config& c = m->cfg;
   const size_t slot = fd_align(sizeof(float) * (size_t)B * dec_max_elems(c, T));
-  if (ws_bytes < 3 * slot) return fd_set_error(FD_ENOMEM, "fd_ndac_decode: workspace %zu < required %zu bytes", ws_bytes, 3 * slot);
+  if (ws_bytes < 5 * slot) return fd_set_error(FD_ENOMEM, "fd_ndac_decode: workspace %zu < required %zu bytes", ws_bytes, 5 * slot);
   hipStream_t st = fd_stream(stream);
-  float* buf[3] = {(float*)ws, (float*)((char*)ws + slot), (float*)((char*)ws + 2 * slot)};
+  float* buf[5];
+  for (int i = 0; i < 5; ++i) buf[i] = (float*)((char*)ws + i * slot);
   Run r{m, st, B};
-  FD_TRY(r.conv(z, "decoder.model.0", nullptr, nullptr, buf[0], c.latent_dim, T, c.decoder_dim, 7, 1, 3, 1));
-  int cur = 0, od = c.decoder_dim;
+  float *cur_raw = buf[0], *cur_act = buf[1], *nxt_raw = buf[2], *nxt_act = buf[3], *tmp = buf[4];
+  auto alpha_of = [&](const std::string& n) { return r.P(n + ".alpha"); };
+  // model.0: WNConv1d(latent, D, 7); DecoderBlock 1 starts with a Snake: only the activated output is needed
+  FD_TRY(r.conv(z, "decoder.model.0", nullptr, nullptr, cur_act, alpha_of("decoder.model.1.block.0"), c.latent_dim, T, c.decoder_dim, 7, 1, 3, 1));
+  int od = c.decoder_dim;
   for (int i = 0; i < c.n_decoder_rates; ++i) {
     const int idim = c.decoder_dim >> i, s = c.decoder_rates[i];
     od = c.decoder_dim >> (i + 1);
     const std::string p = "decoder.model." + std::to_string(i + 1);
-    int nxt = (cur + 1) % 3;
-    FD_TRY(launch_convtr1d(buf[cur], r.P(p + ".block.1.weight"), r.P(p + ".block.1.bias"), r.P(p + ".block.0.alpha"), buf[nxt], B, idim, T, od, 2 * s, s,
-                           ceil_half(s), st, /*wt*/ 1));
+    FD_TRY(launch_convtr1d(cur_act, r.P(p + ".block.1.weight"), r.P(p + ".block.1.bias"), nullptr, nxt_raw, B, idim, T, od, 2 * s, s, ceil_half(s), st, /*wt*/ 1,
+                           nxt_act, alpha_of(p + ".block.2.block.0")));
+    std::swap(cur_raw, nxt_raw); std::swap(cur_act, nxt_act);
     T = (T - 1) * s - 2 * ceil_half(s) + 2 * s;
-    cur = nxt;
     const int dil[3] = {1, 3, 9};
     for (int j = 0; j < 3; ++j) {
-      const int tmp = (cur + 1) % 3; nxt = (cur + 2) % 3;
-      FD_TRY(r.res_unit(buf[cur], p + ".block." + std::to_string(j + 2), od, T, dil[j], buf[tmp], buf[nxt]));
-      cur = nxt;
+      const bool last_unit = j == 2;
+      const float* an = !last_unit ? alpha_of(p + ".block." + std::to_string(j + 3) + ".block.0")
+                                   : (i + 1 < c.n_decoder_rates ? alpha_of("decoder.model." + std::to_string(i + 2) + ".block.0")
+                                                                : alpha_of("decoder.model." + std::to_string(c.n_decoder_rates + 1)));
+      FD_TRY(r.res_unit(cur_raw, cur_act, p + ".block." + std::to_string(j + 2), od, T, dil[j], tmp, last_unit ? nullptr : nxt_raw, nxt_act, an));
+      std::swap(cur_raw, nxt_raw); std::swap(cur_act, nxt_act);
     }
   }
   const std::string last = "decoder.model." + std::to_string(c.n_decoder_rates + 2);
-  return r.conv(buf[cur], last, r.P("decoder.model." + std::to_string(c.n_decoder_rates + 1) + ".alpha"), nullptr, audio, od, T, 1, 7, 1, 3, 1, /*tanh*/ 1);
+  return r.conv(cur_act, last, nullptr, audio, nullptr, nullptr, od, T, 1, 7, 1, 3, 1, /*tanh*/ 1);
 }
