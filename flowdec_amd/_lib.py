@@ -118,6 +118,8 @@ SIGNATURES = {
     "fd_ndac_param_info": (c_int, [_P, c_int, C.POINTER(C.c_char_p), C.POINTER(c_int), C.POINTER(c_int * 3)]),
     "fd_ndac_set_param": (c_int, [_P, C.c_char_p, _P, c_ll]),
     "fd_ndac_finalize": (c_int, [_P, _P]),
+    "fd_ndac_set_precision": (c_int, [_P, c_int]),
+    "fd_ndac_get_precision": (c_int, [_P]),
     "fd_ndac_latent_frames": (c_int, [_P, c_int]),
     "fd_ndac_decoded_length": (c_int, [_P, c_int]),
     "fd_ndac_workspace_bytes": (c_size_t, [_P, c_int, c_int]),

@@ -23,7 +23,7 @@
 #include <string>
 #include <vector>
 
-#include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -465,6 +465,8 @@ struct fd_ndac {
   // per-codebook device pointer tables for rvq_from_codes_kernel
   const float** d_wout = nullptr; const float** d_bout = nullptr; const float** d_cb = nullptr;
   std::vector<float*> cbn, c2;
+  std::map<std::string, void*> packed;   // "<layer>.weight" -> split-bf16 A-operand copy for ndac_mfma.hip (decoder layers it supports)
+  int precision = FD_NDAC_MFMA_DECODER;
   bool finalized = false;
 };
 
@@ -509,12 +511,19 @@ void build_params(fd_ndac* m) {
 // consumers: the activated input of a 768-channel convolution would otherwise be recomputed by each of its 24 channel-tile workgroups
 // (sinf + a division per element).  Same function on the same float32 values: bit-identical to activating at the consumer.
 struct Run {
-  fd_ndac* m; hipStream_t st; int B;
+  fd_ndac* m; hipStream_t st; int B; bool mfma;
   const float* P(const std::string& n) const { return m->dev.at(n); }
+  const void* packed(const std::string& n) const {
+    if (!mfma) return nullptr;
+    auto it = m->packed.find(n + ".weight");
+    return it == m->packed.end() ? nullptr : it->second;
+  }
   // conv over an ALREADY ACTIVATED (or raw, for the first layer of a stack) input; raw result -> out (may be null), snake(result,
   // alpha_next) -> out_act (may be null)
   int conv(const float* x, const std::string& n, const float* res, float* out, float* out_act, const float* alpha_next, int Ci, int T, int Co, int K,
            int stride, int pad, int dil, int tanh_out = 0) const {
+    if (const void* wp = packed(n); wp && !tanh_out)
+      return fd_ndac_mfma_conv(x, wp, P(n + ".bias"), res, out, out_act, alpha_next, B, Ci, T, Co, K, stride, pad, dil, 0, st);
     return launch_conv1d(x, P(n + ".weight"), P(n + ".bias"), nullptr, res, out, B, Ci, T, Co, K, stride, pad, dil, tanh_out, st, /*wt*/ 1, out_act, alpha_next);
   }
   // ResidualUnit on (x_raw, x_act = snake(x, block.0.alpha)): y = x + conv1(snake(conv7_dil(x_act))); -> y_raw (may be null), snake(y, alpha_next)
@@ -671,6 +680,17 @@ extern "C" int fd_ndac_finalize(fd_ndac* m, void* stream) {
           for (int co = 0; co < Co; ++co)
             t[((size_t)ci * K + k) * Co + co] = tr ? it->second[((size_t)ci * Co + co) * K + k] : it->second[((size_t)co * Ci + ci) * K + k];
       it->second.swap(t);
+      const int stride = tr ? K / 2 : 1;
+      if (p.name.rfind("decoder.", 0) == 0 && fd_ndac_mfma_supported(Ci, Co, K, stride, tr || K == 1 ? 1 : 9, tr)) {
+        const size_t nb = fd_ndac_mfma_packed_bytes(Ci, Co, K);
+        std::vector<unsigned char> hp(nb);
+        fd_ndac_mfma_pack(it->second.data(), Ci, Co, K, stride, tr, hp.data());
+        void* dp = nullptr;
+        FD_HIP(hipMalloc(&dp, nb));
+        m->allocs.push_back(dp);
+        FD_HIP(hipMemcpy(dp, hp.data(), nb, hipMemcpyHostToDevice));
+        m->packed[p.name] = dp;
+      }
     }
     float* d = nullptr;
     FD_TRY(upload(it->second, &d));
@@ -717,6 +737,14 @@ extern "C" int fd_ndac_finalize(fd_ndac* m, void* stream) {
   m->finalized = true;
   return FD_OK;
 }
+
+extern "C" int fd_ndac_set_precision(fd_ndac* m, int flags) {
+  FD_REQUIRE(m, "fd_ndac_set_precision: null codec");
+  FD_REQUIRE((flags & ~FD_NDAC_MFMA_DECODER) == 0, "fd_ndac_set_precision: unknown flags 0x%x", flags);
+  m->precision = flags;
+  return FD_OK;
+}
+extern "C" int fd_ndac_get_precision(const fd_ndac* m) { return m ? m->precision : -1; }
 
 extern "C" int fd_ndac_latent_frames(const fd_ndac* m, int L) {   // frames the encoder produces for L samples (L % hop == 0 -> L / hop)
   if (!m || L <= 0) return 0;
@@ -770,7 +798,7 @@ extern "C" int fd_ndac_encode(fd_ndac* m, const float* x, int B, int L, int n_qu
   const size_t slot = (need - 256) / 5;
   float* buf[5];
   for (int i = 0; i < 5; ++i) buf[i] = (float*)((char*)ws + i * slot);
-  Run r{m, st, B};
+  Run r{m, st, B, false};
   int T = L, d = c.encoder_dim;
   float *cur_raw = buf[0], *cur_act = buf[1], *nxt_raw = buf[2], *nxt_act = buf[3], *tmp = buf[4];
   auto alpha_of = [&](const std::string& n) { return r.P(n + ".alpha"); };
@@ -809,7 +837,7 @@ extern "C" int fd_ndac_decode(fd_ndac* m, const float* z, int B, int T, float* a
   hipStream_t st = fd_stream(stream);
   float* buf[5];
   for (int i = 0; i < 5; ++i) buf[i] = (float*)((char*)ws + i * slot);
-  Run r{m, st, B};
+  Run r{m, st, B, (m->precision & FD_NDAC_MFMA_DECODER) != 0};
   float *cur_raw = buf[0], *cur_act = buf[1], *nxt_raw = buf[2], *nxt_act = buf[3], *tmp = buf[4];
   auto alpha_of = [&](const std::string& n) { return r.P(n + ".alpha"); };
   // model.0: WNConv1d(latent, D, 7); DecoderBlock 1 starts with a Snake: only the activated output is needed
@@ -819,8 +847,12 @@ extern "C" int fd_ndac_decode(fd_ndac* m, const float* z, int B, int T, float* a
     const int idim = c.decoder_dim >> i, s = c.decoder_rates[i];
     od = c.decoder_dim >> (i + 1);
     const std::string p = "decoder.model." + std::to_string(i + 1);
-    FD_TRY(launch_convtr1d(cur_act, r.P(p + ".block.1.weight"), r.P(p + ".block.1.bias"), nullptr, nxt_raw, B, idim, T, od, 2 * s, s, ceil_half(s), st, /*wt*/ 1,
-                           nxt_act, alpha_of(p + ".block.2.block.0")));
+    if (const void* wp = r.packed(p + ".block.1"))
+      FD_TRY(fd_ndac_mfma_conv(cur_act, wp, r.P(p + ".block.1.bias"), nullptr, nxt_raw, nxt_act, alpha_of(p + ".block.2.block.0"), B, idim, T, od, 2 * s, s,
+                               ceil_half(s), 1, 1, st));
+    else
+      FD_TRY(launch_convtr1d(cur_act, r.P(p + ".block.1.weight"), r.P(p + ".block.1.bias"), nullptr, nxt_raw, B, idim, T, od, 2 * s, s, ceil_half(s), st, /*wt*/ 1,
+                             nxt_act, alpha_of(p + ".block.2.block.0")));
     std::swap(cur_raw, nxt_raw); std::swap(cur_act, nxt_act);
     T = (T - 1) * s - 2 * ceil_half(s) + 2 * s;
     const int dil[3] = {1, 3, 9};

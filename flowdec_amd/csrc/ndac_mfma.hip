@@ -1,0 +1,235 @@
+// ndac_mfma.hip -- the NDAC codec's wide 1-D convolutions on the gfx950 matrix cores (v_mfma_f32_32x32x16_bf16), at float32
+// tolerance: both operands are split into two bf16 terms (x = xh + xl, w = wh + wl) and three products are accumulated in f32
+// (wl xh + wh xl + wh xh; the dropped wl xl term is 2^-16 relative), the same scheme as the post-filter's `bf16x3` mode.
+// The vector-ALU kernels of ndac.hip stay the EXACT path (bit-defined operation order: the encoder's code indices); this file is
+// the decoder's default path (dac.DAC.decode is a tolerance comparison in any implementation: cuDNN does not define an order).
+//
+// One kernel, implicit GEMM  out[co][n] = sum_tap sum_ci W_tap[co][ci] x[ci][pos(n, tap)]:
+//   Conv1d (stride 1, dilation d)        taps k = 0..K-1, pos = n - pad + k d, one phase
+//   ConvTranspose1d (stride s, K = m s)  output t = s q + r - pad takes taps k = r + j s of inputs q - j: s PHASES r, each a
+//                                        m-tap convolution over q with its own weight slice, written with stride s
+//   M = 96 (or 64) output channels per workgroup, N = 256 positions (4 waves x 64), K-loop = input channels in chunks of 32.
+//   x is read as float32 [B][Ci][T] (the codec's layout, already Snake-activated by its producer), split and TRANSPOSED into LDS
+//   rows [position][32 channels] (80-byte pitch: 16 lanes x 16 B cover all 64 banks), so a lane's B operand (8 consecutive input
+//   channels of one position) is one ds_read_b128.  Weights are pre-split and pre-swizzled at load time into the exact A-operand
+//   lane order, one contiguous 1 KiB wave load per (tap, 16 channels, 32 outputs, hi|lo), read straight from L2 one step ahead.
+//   Epilogue: bias, residual add, raw output and/or the NEXT layer's Snake activation (hardware sine), as in ndac.hip.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "internal.h"
+
+namespace {
+
+constexpr int TN = 256;    // output positions per workgroup
+constexpr int CK = 32;     // input channels per LDS chunk
+constexpr int ROWB = 80;   // LDS row pitch in bytes (32 bf16 + 16 B pad)
+
+struct MArgs {
+  const float* x; const uint4* wp; const float* bias; const float* res; float* out; float* out_act; const float* alpha_out;
+  int Ci, T, Co, To, N;      // N: GEMM columns per (batch item, phase)
+  int ntaps, nphase;
+  int xlo;                   // input position of LDS row 0 = n0 + xlo
+  int rbase, rstep;          // LDS row of (local column c, tap j) = c + rbase + j * rstep
+  int rows;                  // staged rows = TN + span
+  int ostride, ooff;         // output position of column n, phase r = n * ostride + r + ooff
+};
+
+__device__ __forceinline__ float snake_fast(float v, float alpha, float inv) {
+  const float s = __sinf(alpha * v);
+  return v + inv * (s * s);
+}
+
+template <int MT>
+__global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(MArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned char* const xh = smem;
+  unsigned char* const xl = smem + a.rows * ROWB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, n0 = blockIdx.x * TN;
+  const int ncob = a.Co / (32 * MT);
+  const int vcb = blockIdx.y, phase = vcb / ncob, co0 = (vcb - phase * ncob) * 32 * MT;
+  const int nchunk = a.Ci / CK;
+  constexpr int STEP = MT * 2 * 64;   // uint4 per (chunk, tap, 16-channel block)
+  const uint4* wq = a.wp + (size_t)vcb * nchunk * a.ntaps * 2 * STEP + lane;
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+
+  uint4 ah[MT], al[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) { ah[mt] = wq[(mt * 2) * 64]; al[mt] = wq[(mt * 2 + 1) * 64]; }
+
+  const float* const xb = a.x + (size_t)b * a.Ci * a.T;
+  const long long pos0 = (long long)n0 + a.xlo;
+  const int col = wave * 64 + (lane & 31);
+  const int koff = (lane >> 5) * 16;
+
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    __syncthreads();
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {
+      const float* const src = xb + (size_t)(chunk * CK + 8 * g) * a.T;
+      for (int p = tid; p < a.rows; p += 256) {
+        const long long tp = pos0 + p;
+        float v[8];
+        if (tp >= 0 && tp < a.T) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * a.T + tp];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        }
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { hi[j] = (bf16)v[j]; lo[j] = (bf16)(v[j] - (float)hi[j]); }
+        *reinterpret_cast<bf16x8*>(xh + p * ROWB + g * 16) = hi;
+        *reinterpret_cast<bf16x8*>(xl + p * ROWB + g * 16) = lo;
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int tap = 0; tap < a.ntaps; ++tap) {
+      const int r0 = (col + a.rbase + tap * a.rstep) * ROWB + koff;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        wq += STEP;   // the packed buffer carries one step of padding: the last prefetch stays in bounds
+        uint4 nh[MT], nl[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { nh[mt] = wq[(mt * 2) * 64]; nl[mt] = wq[(mt * 2 + 1) * 64]; }
+        bf16x8 bh[2], bl[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          bh[nt] = *reinterpret_cast<const bf16x8*>(xh + r0 + nt * 32 * ROWB + kb * 32);
+          bl[nt] = *reinterpret_cast<const bf16x8*>(xl + r0 + nt * 32 * ROWB + kb * 32);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[mt]), bh[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[mt]), bl[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[mt]), bh[nt], acc[mt][nt], 0, 0, 0);
+          }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { ah[mt] = nh[mt]; al[mt] = nl[mt]; }
+      }
+    }
+  }
+
+  // epilogue: lane = column (lane & 31) of each 32-wide tile, rows 8 (e / 4) + 4 (lane / 32) + e % 4
+  long long tpos[2];
+  bool ok[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const long long n = (long long)n0 + col + 32 * nt;
+    tpos[nt] = n * a.ostride + phase + a.ooff;
+    ok[nt] = n < a.N && tpos[nt] >= 0 && tpos[nt] < a.To;
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = co0 + 32 * mt + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+      const float bv = a.bias ? a.bias[co] : 0.f;
+      float ao = 0.f, inv = 0.f;
+      if (a.out_act) { ao = a.alpha_out[co]; inv = __builtin_amdgcn_rcpf(ao + 1e-9f); }
+      const size_t rowo = ((size_t)b * a.Co + co) * a.To;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        if (!ok[nt]) continue;
+        const size_t o = rowo + tpos[nt];
+        float v = acc[mt][nt][e] + bv;
+        if (a.res) v += a.res[o];
+        if (a.out) a.out[o] = v;
+        if (a.out_act) a.out_act[o] = snake_fast(v, ao, inv);
+      }
+    }
+}
+
+unsigned short bf16_rne(float f) {
+  unsigned u; memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+float bf16_f32(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+int block_mt(int Co) { return Co % 96 == 0 ? 3 : (Co % 64 == 0 ? 2 : 0); }
+
+}  // namespace
+
+bool fd_ndac_mfma_supported(int Ci, int Co, int K, int stride, int dil, int transposed) {
+  if (Ci <= 0 || Ci % CK || !block_mt(Co) || K <= 0 || stride <= 0 || dil <= 0) return false;
+  if (transposed ? (K % stride != 0 || dil != 1) : stride != 1) return false;
+  const int span = transposed ? K / stride - 1 : (K - 1) * dil;
+  return (size_t)(TN + span) * ROWB * 2 <= 64 * 1024;
+}
+
+size_t fd_ndac_mfma_packed_bytes(int Ci, int Co, int K) {   // (phases x taps = K in both cases) + one step of prefetch padding
+  return ((size_t)Ci * K * Co * 2 + 3 * 2 * 64 * 8) * sizeof(unsigned short);
+}
+
+// w: [Ci][K][Co] float32 (the codec's own layout for both kinds) -> A-operand order
+//   [phase * Co / CB + co block][chunk of 32 ci][tap][16-ci block][32-co tile][hi | lo][lane][8]
+void fd_ndac_mfma_pack(const float* w, int Ci, int Co, int K, int stride, int transposed, void* dst) {
+  const int mt_n = block_mt(Co), CB = 32 * mt_n, ncob = Co / CB;
+  const int nphase = transposed ? stride : 1, ntaps = transposed ? K / stride : K;
+  unsigned short* o = static_cast<unsigned short*>(dst);
+  memset(o, 0, fd_ndac_mfma_packed_bytes(Ci, Co, K));
+  for (int ph = 0; ph < nphase; ++ph)
+    for (int cob = 0; cob < ncob; ++cob)
+      for (int chunk = 0; chunk < Ci / CK; ++chunk)
+        for (int tap = 0; tap < ntaps; ++tap)
+          for (int kb = 0; kb < 2; ++kb)
+            for (int mt = 0; mt < mt_n; ++mt)
+              for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                  const int co = cob * CB + 32 * mt + (lane & 31), ci = chunk * CK + kb * 16 + (lane >> 5) * 8 + j;
+                  const int k = transposed ? ph + tap * stride : tap;
+                  const float v = w[((size_t)ci * K + k) * Co + co];
+                  const unsigned short h = bf16_rne(v), l = bf16_rne(v - bf16_f32(h));
+                  const size_t step = (((size_t)(ph * ncob + cob) * (Ci / CK) + chunk) * ntaps + tap) * 2 + kb;
+                  const size_t base = ((step * mt_n + mt) * 2) * 64 * 8 + (size_t)lane * 8 + j;
+                  o[base] = h;
+                  o[base + 64 * 8] = l;
+                }
+}
+
+int fd_ndac_mfma_conv(const float* x, const void* wp, const float* bias, const float* res, float* out, float* out_act, const float* alpha_out, int B,
+                      int Ci, int T, int Co, int K, int stride, int pad, int dil, int transposed, hipStream_t st) {
+  FD_REQUIRE(fd_ndac_mfma_supported(Ci, Co, K, stride, dil, transposed), "ndac mfma conv: unsupported shape Ci %d Co %d K %d stride %d dilation %d", Ci, Co, K,
+             stride, dil);
+  MArgs a{};
+  a.x = x; a.wp = static_cast<const uint4*>(wp); a.bias = bias; a.res = res; a.out = out; a.out_act = out_act; a.alpha_out = alpha_out;
+  a.Ci = Ci; a.T = T; a.Co = Co;
+  long long To;
+  if (transposed) {
+    a.ntaps = K / stride; a.nphase = stride;
+    To = ((long long)T - 1) * stride - 2 * pad + K;
+    a.N = T + a.ntaps - 1;
+    a.xlo = -(a.ntaps - 1); a.rbase = a.ntaps - 1; a.rstep = -1; a.rows = TN + a.ntaps - 1;
+    a.ostride = stride; a.ooff = -pad;
+  } else {
+    a.ntaps = K; a.nphase = 1;
+    To = (long long)T + 2 * pad - (long long)dil * (K - 1);
+    a.N = (int)To;
+    a.xlo = -pad; a.rbase = 0; a.rstep = dil; a.rows = TN + (K - 1) * dil;
+    a.ostride = 1; a.ooff = 0;
+  }
+  FD_REQUIRE(To > 0 && To < (1ll << 31), "ndac mfma conv: empty output");
+  a.To = (int)To;
+  const int mt = block_mt(Co);
+  const dim3 grid(fd_cdiv(a.N, TN), Co / (32 * mt) * a.nphase, B);
+  const size_t lds = (size_t)a.rows * ROWB * 2;
+  if (mt == 3) hipLaunchKernelGGL((conv1d_mfma_kernel<3>), grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((conv1d_mfma_kernel<2>), grid, dim3(256), lds, st, a);
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}

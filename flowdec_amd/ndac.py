@@ -118,8 +118,9 @@ class DAC(nn.Module):
 
     def __init__(self, encoder_dim: int = 64, encoder_rates: Sequence[int] = (2, 4, 8, 8), latent_dim: Optional[int] = None, decoder_dim: int = 1536,
                  decoder_rates: Sequence[int] = (8, 8, 4, 2), n_codebooks: int = 9, codebook_size: int = 1024, codebook_dim=8, quantizer_dropout: bool = False,
-                 sample_rate: int = 44100, **ignored):
+                 sample_rate: int = 44100, precision: str = "mfma_decoder", **ignored):
         super().__init__()
+        self.precision = precision   # "mfma_decoder" (default: decoder on the matrix cores, split-bf16 operands, f32 tolerance) | "exact"
         if not isinstance(codebook_dim, int):
             raise NotImplementedError("flowdec_amd.ndac.DAC: per-codebook dimensions (a list) are not supported")
         self.encoder_dim, self.encoder_rates, self.decoder_dim, self.decoder_rates = encoder_dim, tuple(encoder_rates), decoder_dim, tuple(decoder_rates)
@@ -249,6 +250,13 @@ class DAC(nn.Module):
         self._handle, self._handle_sig = h, sig
         return h
 
+    PRECISIONS = {"exact": 0, "mfma_decoder": 1}   # include/flowdec_hip.h FD_NDAC_EXACT / FD_NDAC_MFMA_DECODER
+
+    def _apply_precision(self, h):
+        if self.precision not in self.PRECISIONS:
+            raise ValueError(f"DAC.precision must be one of {sorted(self.PRECISIONS)} (got {self.precision!r})")
+        L.check(L.load().fd_ndac_set_precision(h, self.PRECISIONS[self.precision]))
+
     # ---- dac.DAC API ------------------------------------------------------------------------------------------------------
     def preprocess(self, audio_data, sample_rate=None):
         """dac.DAC.preprocess: right-pad to a multiple of the hop length."""
@@ -292,6 +300,7 @@ class DAC(nn.Module):
         lib = L.load()
         with self._lock, torch.cuda.device(z.device):
             h = self.handle()
+            self._apply_precision(h)
             Lo = lib.fd_ndac_decoded_length(h, T)
             out = torch.empty(B, 1, Lo, dtype=torch.float32, device=z.device)
             ws = torch.empty(lib.fd_ndac_workspace_bytes(h, B, max(Lo, T * self.hop_length)), dtype=torch.uint8, device=z.device)

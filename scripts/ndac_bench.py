@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Throughput of the NDAC codec kernels (csrc/ndac.hip) at DAC's published full-width architecture with the ndac-75 frame rate
 (encoder_dim 64, rates 2-4-8-10 = hop 640 at 48 kHz, decoder_dim 1536, 10 x 1024 x 8 codebooks; random weights):
-encode (encoder + RVQ), from_codes, decode for B clips of S seconds; audio-seconds per second and algorithmic TFLOP/s (f32 FMA).
+encode (encoder + RVQ), from_codes, decode (matrix-core default and the exact vector path) for B clips of S seconds; audio-seconds per second and algorithmic TFLOP/s (f32 FMA).
     python scripts/ndac_bench.py [--batch 8] [--seconds 2] [--iters 5]"""
 import argparse
 import json
@@ -61,8 +61,20 @@ def main():
     assert torch.isfinite(y).all() and y.shape[-1] == x.shape[-1], (y.shape, x.shape)
     fe, fd = conv_flops(m, x.shape[-1])
     res = {"config": f"DAC 64/(2,4,8,10)/1536/(10,8,4,2), {a.nq} x 1024 x 8 codebooks, B = {a.batch} x {a.seconds:g} s @ 48 kHz, f32", "audio_seconds": a.batch * a.seconds}
+    y_exact = None
+    if m.precision != "exact":
+        m.precision = "exact"; y_exact = m.decode(zq); m.precision = "mfma_decoder"
+        res["decode_vs_exact_rel_to_peak"] = float((y - y_exact).abs().max() / y_exact.abs().max())
+
+    def decode_exact():
+        m.precision = "exact"
+        try:
+            return m.decode(zq)
+        finally:
+            m.precision = "mfma_decoder"
+
     for name, fn, fl in (("encode", lambda: m.encode(x, n_quantizers=a.nq), fe), ("from_codes", lambda: m.quantizer.from_codes(codes), 0),
-                         ("decode", lambda: m.decode(zq), fd)):
+                         ("decode", lambda: m.decode(zq), fd), ("decode_exact", decode_exact, fd)):
         fn(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.iters):

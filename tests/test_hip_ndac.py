@@ -17,6 +17,9 @@ from test_ndac_cpu import NDAC75_LIKE, SMALL, scaled_sd
 pytestmark = pytest.mark.gpu
 
 
+TOL_MFMA_DECODE = 1e-4   # of the waveform peak: split-bf16 operands (3 products, f32 accumulation) + hardware sine in Snake
+
+
 def lib_call(fn, *a):
     from flowdec_amd import _lib as L
     L.check(getattr(L.load(), fn)(*a))
@@ -112,7 +115,10 @@ def test_codec_encode_from_codes_decode(cfg, gain, nq):
     y = m.decode(zq)
     y_o = o.decode(zq_o)
     assert tuple(y.shape) == y_o.shape and float(y.abs().max()) <= 1.0
-    check(f"ndac_decode[{nqq}]", y.cpu().numpy(), y_o, 2e-5)
+    check(f"ndac_decode[{nqq}]", y.cpu().numpy(), y_o, TOL_MFMA_DECODE)   # default: the layers ndac_mfma.hip supports run on the matrix cores
+    m.precision = "exact"
+    check(f"ndac_decode_exact[{nqq}]", m.decode(zq).cpu().numpy(), y_o, 2e-5)
+    m.precision = "mfma_decoder"
     out = m(torch.from_numpy(x).cuda(), cfg["sample_rate"], n_quantizers=nq)         # dac.DAC.forward: trimmed to the input length
     assert out["audio"].shape == (2, 1, x.shape[-1]) and torch.equal(out["codes"], codes)
 
@@ -157,3 +163,34 @@ def test_demo_chain_ndac_into_flowdec():
     assert xhat_ndac.shape == (1, 1, x.shape[-1]) and torch.isfinite(xhat_ndac).all()
     xhat = fm.enhance(xhat_ndac, N=3, solver="midpoint", generator=g)
     assert xhat.shape == xhat_ndac.shape and torch.isfinite(xhat).all() and xhat.is_cuda
+
+
+# decoder wide enough for csrc/ndac_mfma.hip: 768 -> 384 (x10) -> 192 (x8) -> 96 (x4) on the matrix cores (96-channel tiles, transposed
+# convolutions as stride phases), 96 -> 48 (x2) and the final 48 -> 1 convolution on the exact vector path (mixed walk)
+WIDE_DECODER = dict(NDAC75_LIKE, decoder_dim=768, n_codebooks=4)
+
+
+@pytest.mark.parametrize("cfg,frames,batch", [(WIDE_DECODER, 7, 2), (WIDE_DECODER, 1, 1), (dict(SMALL, decoder_dim=256), 53, 3)],
+                         ids=["wide_7f", "wide_1f", "small256_53f"])
+def test_decoder_on_matrix_cores(cfg, frames, batch):
+    """dac.DAC.decode with the decoder's convolutions on MFMA (the default) against the oracle and against the exact vector path."""
+    from flowdec_amd import _lib as L
+    m, o = build(cfg, 5, 0.6)   # (gain: output peak ~0.5, tanh unsaturated)
+    rng = np.random.default_rng(frames)
+    codes = rng.integers(0, cfg["codebook_size"], size=(batch, cfg["n_codebooks"], frames))
+    zq_o, _, _ = o.from_codes(codes)
+    zq = m.quantizer.from_codes(torch.from_numpy(codes).cuda())[0]
+    assert m.precision == "mfma_decoder"
+    y = m.decode(zq)
+    assert L.load().fd_ndac_get_precision(m.handle()) == 1
+    y_o = o.decode(zq_o)
+    assert tuple(y.shape) == y_o.shape
+    check(f"ndac_decode_mfma[{frames}x{batch}]", y.cpu().numpy(), y_o, TOL_MFMA_DECODE)
+    m.precision = "exact"
+    y_e = m.decode(zq)
+    assert L.load().fd_ndac_get_precision(m.handle()) == 0
+    check(f"ndac_decode_exact[{frames}x{batch}]", y_e.cpu().numpy(), y_o, 2e-5)
+    assert not torch.equal(y, y_e), "the two precisions returned identical bits: the matrix-core path did not run"
+    m.precision = "bf16"
+    with pytest.raises(ValueError):
+        m.decode(zq)
