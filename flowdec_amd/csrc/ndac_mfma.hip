@@ -42,6 +42,44 @@ __device__ __forceinline__ float snake_fast(float v, float alpha, float inv) {
   return v + inv * (s * s);
 }
 
+struct Epi { int b, co0, tpos[2]; bool ok[2]; };
+
+// 16 rows of a tile at a time: their 16 residual values are requested together (one latency per batch, not per element)
+template <int MT, bool RES, bool OUT, bool ACT>
+__device__ __forceinline__ void epilogue(const MArgs& a, const Epi& ep, f32x16 (&acc)[MT][2]) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int eh = 0; eh < 16; eh += 8) {
+      float rv[8][2];
+      if (RES) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const size_t rowo = ((size_t)ep.b * a.Co + ep.co0 + 32 * mt + 8 * ((eh + e) >> 2) + (e & 3)) * a.To;
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) rv[e][nt] = a.res[rowo + ep.tpos[nt]];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int co = ep.co0 + 32 * mt + 8 * ((eh + e) >> 2) + (e & 3);
+        const float bv = a.bias[co];
+        float ao = 0.f, inv = 0.f;
+        if (ACT) { ao = a.alpha_out[co]; inv = __builtin_amdgcn_rcpf(ao + 1e-9f); }
+        const size_t rowo = ((size_t)ep.b * a.Co + co) * a.To;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          float v = acc[mt][nt][eh + e] + bv;
+          if (RES) v += rv[e][nt];
+          if (ep.ok[nt]) {
+            if (OUT) a.out[rowo + ep.tpos[nt]] = v;
+            if (ACT) a.out_act[rowo + ep.tpos[nt]] = snake_fast(v, ao, inv);
+          }
+        }
+      }
+    }
+}
+
 template <int MT>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(MArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -75,23 +113,27 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(MArgs a) {
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     __syncthreads();
 #pragma unroll 1
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < 4; g += 2) {   // two 8-channel groups per pass: 16 loads in flight per thread
       const float* const src = xb + (size_t)(chunk * CK + 8 * g) * a.T;
       for (int p = tid; p < a.rows; p += 256) {
         const long long tp = pos0 + p;
-        float v[8];
+        float v[16];
         if (tp >= 0 && tp < a.T) {
+          const float* q = src + tp;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * a.T + tp];
+          for (int j = 0; j < 16; ++j) { v[j] = *q; q += a.T; }
         } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = 0.f;
+          for (int j = 0; j < 16; ++j) v[j] = 0.f;
         }
-        bf16x8 hi, lo;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { hi[j] = (bf16)v[j]; lo[j] = (bf16)(v[j] - (float)hi[j]); }
-        *reinterpret_cast<bf16x8*>(xh + p * ROWB + g * 16) = hi;
-        *reinterpret_cast<bf16x8*>(xl + p * ROWB + g * 16) = lo;
+        for (int h = 0; h < 2; ++h) {
+          bf16x8 hi, lo;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { hi[j] = (bf16)v[8 * h + j]; lo[j] = (bf16)(v[8 * h + j] - (float)hi[j]); }
+          *reinterpret_cast<bf16x8*>(xh + p * ROWB + (g + h) * 16) = hi;
+          *reinterpret_cast<bf16x8*>(xl + p * ROWB + (g + h) * 16) = lo;
+        }
       }
     }
     __syncthreads();
@@ -125,33 +167,24 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(MArgs a) {
   }
 
   // epilogue: lane = column (lane & 31) of each 32-wide tile, rows 8 (e / 4) + 4 (lane / 32) + e % 4
-  long long tpos[2];
-  bool ok[2];
+  Epi ep;
+  ep.b = b; ep.co0 = co0 + 4 * (lane >> 5);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const long long n = (long long)n0 + col + 32 * nt;
-    tpos[nt] = n * a.ostride + phase + a.ooff;
-    ok[nt] = n < a.N && tpos[nt] >= 0 && tpos[nt] < a.To;
+    const long long t = n * a.ostride + phase + a.ooff;
+    ep.ok[nt] = n < a.N && t >= 0 && t < a.To;
+    ep.tpos[nt] = ep.ok[nt] ? (int)t : 0;   // (clamped: the residual loads are unconditional, the stores predicated)
   }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int co = co0 + 32 * mt + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
-      const float bv = a.bias ? a.bias[co] : 0.f;
-      float ao = 0.f, inv = 0.f;
-      if (a.out_act) { ao = a.alpha_out[co]; inv = __builtin_amdgcn_rcpf(ao + 1e-9f); }
-      const size_t rowo = ((size_t)b * a.Co + co) * a.To;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        if (!ok[nt]) continue;
-        const size_t o = rowo + tpos[nt];
-        float v = acc[mt][nt][e] + bv;
-        if (a.res) v += a.res[o];
-        if (a.out) a.out[o] = v;
-        if (a.out_act) a.out_act[o] = snake_fast(v, ao, inv);
-      }
-    }
+  if (a.res) {
+    if (a.out) epilogue<MT, true, true, true>(a, ep, acc);
+    else epilogue<MT, true, false, true>(a, ep, acc);
+  } else if (a.out) {
+    if (a.out_act) epilogue<MT, false, true, true>(a, ep, acc);
+    else epilogue<MT, false, true, false>(a, ep, acc);
+  } else {
+    epilogue<MT, false, false, true>(a, ep, acc);
+  }
 }
 
 unsigned short bf16_rne(float f) {
@@ -206,6 +239,7 @@ int fd_ndac_mfma_conv(const float* x, const void* wp, const float* bias, const f
                       int Ci, int T, int Co, int K, int stride, int pad, int dil, int transposed, hipStream_t st) {
   FD_REQUIRE(fd_ndac_mfma_supported(Ci, Co, K, stride, dil, transposed), "ndac mfma conv: unsupported shape Ci %d Co %d K %d stride %d dilation %d", Ci, Co, K,
              stride, dil);
+  FD_REQUIRE(x && wp && bias && (out || out_act) && (!out_act || alpha_out), "ndac mfma conv: null argument");
   MArgs a{};
   a.x = x; a.wp = static_cast<const uint4*>(wp); a.bias = bias; a.res = res; a.out = out; a.out_act = out_act; a.alpha_out = alpha_out;
   a.Ci = Ci; a.T = T; a.Co = Co;
