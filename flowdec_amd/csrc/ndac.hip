@@ -206,6 +206,69 @@ __global__ __launch_bounds__(256) void conv1d_s1_kernel(Conv1dArgs a) {
   }
 }
 
+// The two ends of the codec, where the 32-channel tiles above are 97 % padding: ONE input channel (the encoder's first layer:
+// audio -> d channels) and ONE output channel (the decoder's last layer: d channels -> audio, tanh).  Same fma sequence per output
+// as conv1d_kernel (input channels ascending, taps ascending, then + bias): identical bits.
+__global__ __launch_bounds__(256) void conv1d_ci1_kernel(Conv1dArgs a) {   // Ci == 1, stride 1, K <= 8, no input activation
+  const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.To) return;
+  float xv[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const long long tin = (long long)t - a.pad + (long long)k * a.dil;
+    xv[k] = k < a.K && tin >= 0 && tin < a.T ? a.x[(size_t)b * a.T + tin] : 0.f;
+  }
+  for (int co = 0; co < a.Co; ++co) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < a.K) acc = __builtin_fmaf(xv[k], a.w[a.wt ? k * a.Co + co : co * a.K + k], acc);
+    const size_t o = ((size_t)b * a.Co + co) * a.To + t;
+    float v = acc + (a.bias ? a.bias[co] : 0.f);
+    if (a.res) v += a.res[o];
+    if (a.tanh_out) v = tanhf(v);
+    if (a.out) a.out[o] = v;
+    if (a.out_act) a.out_act[o] = snake_f(v, a.alpha_out[co]);
+  }
+}
+
+constexpr int C1C = 16;   // input channels per LDS chunk of the one-output-channel kernel
+__global__ __launch_bounds__(256) void conv1d_co1_kernel(Conv1dArgs a) {   // Co == 1, stride 1
+  extern __shared__ float sm[];
+  const int span = 256 + (a.K - 1) * a.dil;
+  const int b = blockIdx.y, t0 = blockIdx.x * 256, tid = threadIdx.x;
+  const long long in0 = (long long)t0 - a.pad;
+  float acc = 0.f;
+  for (int c0 = 0; c0 < a.Ci; c0 += C1C) {
+    __syncthreads();
+    for (int i = tid; i < C1C * span; i += 256) {
+      const int ci = i / span, p = i - ci * span;
+      const long long tin = in0 + p;
+      float v = 0.f;
+      if (c0 + ci < a.Ci && tin >= 0 && tin < a.T) {
+        v = a.x[((size_t)b * a.Ci + c0 + ci) * a.T + tin];
+        if (a.alpha) v = snake_f(v, a.alpha[c0 + ci]);
+      }
+      sm[i] = v;
+    }
+    __syncthreads();
+    const int cn = a.Ci - c0 < C1C ? a.Ci - c0 : C1C;
+    for (int ci = 0; ci < cn; ++ci) {
+      const float* xr = sm + ci * span + tid;
+      const float* wr = a.w + (size_t)(c0 + ci) * a.K;   // [Co = 1][Ci][K] and [Ci][K][Co = 1] are the same array
+      for (int k = 0; k < a.K; ++k) acc = __builtin_fmaf(xr[k * a.dil], wr[k], acc);
+    }
+  }
+  const int t = t0 + tid;
+  if (t >= a.To) return;
+  const size_t o = (size_t)b * a.To + t;
+  float v = acc + (a.bias ? a.bias[0] : 0.f);
+  if (a.res) v += a.res[o];
+  if (a.tanh_out) v = tanhf(v);
+  if (a.out) a.out[o] = v;
+  if (a.out_act) a.out_act[o] = snake_f(v, a.alpha_out[0]);
+}
+
 struct ConvTr1dArgs {
   const float* x; const float* w; const float* bias; const float* alpha; float* out;
   float* out_act; const float* alpha_out;
@@ -286,7 +349,7 @@ __global__ __launch_bounds__(256) void convtr1d_kernel(ConvTr1dArgs a) {
 }
 
 // ---- residual vector quantiser -------------------------------------------------------------------------------------------
-constexpr int RT = 32;   // time steps per workgroup
+constexpr int RT = 8;    // time steps per workgroup
 
 struct RvqArgs {
   float* residual;        // [B][D][T] in / out
@@ -302,28 +365,41 @@ struct RvqArgs {
 };
 
 // The float32 operation order of oracle/ndac_oracle.py `vq_nearest` / `l2_normalize_rows_f32` (no fused multiply-add anywhere).
+// 8 time steps per workgroup (a 2 s clip has 150 frames: small tiles are what fills the chip); the 256 threads are
+//   (1) 8 steps x 8 codebook dims x 4 quarters of the latent channels (f64 partial sums, combined in a fixed order),
+//   (3) 8 steps x 32 slices of the codebook, each scanned in ascending order with a strict '<', slices merged in ascending order
+//       (ties -> lowest index), (4) 8 steps x 32 output-channel lanes.
 __global__ __launch_bounds__(256) void rvq_step_kernel(RvqArgs a) {
 #pragma clang fp contract(off)
-  __shared__ float ze[RT][9];        // in_proj output per time step (cd <= 8... see the launcher), +1 pad
+  constexpr int NP = 256 / RT;       // codebook slices / output-channel lanes per time step
+  static_assert(NP == 32, "the in_proj split below is 8 dims x 4 channel quarters");
+  __shared__ double pz[4][RT][8];
+  __shared__ float ze[RT][9];        // in_proj output per time step (cd <= 8: fd_ndac_create), +1 pad
   __shared__ float en[RT][9];
   __shared__ float e2s[RT];
-  __shared__ float bestd[8][RT];
-  __shared__ int besti[8][RT];
+  __shared__ float bestd[NP][RT];
+  __shared__ int besti[NP][RT];
   __shared__ float stv[RT][9];       // straight-through value z_e + (c - z_e)
   const int b = blockIdx.y, t0 = blockIdx.x * RT, tid = threadIdx.x;
-  const int tt = tid & 31, part = tid >> 5;   // 32 time steps x 8 parts
+  const int tt = tid % RT, part = tid / RT;
   const int t = t0 + tt;
   const bool tv = t < a.T;
-  // (1) z_e[d] = sum_c win[d][c] * residual[c] + bin[d], d = part (cd <= 8): exact f32 products accumulated in f64, rounded once
-  if (part < a.cd) {
+  // (1) z_e[d] = sum_c win[d][c] * residual[c] + bin[d]: exact f32 products accumulated in f64, rounded to f32 once
+  {
+    const int d = part & 7, qd = part >> 3;   // NP = 32: 8 dims x 4 channel quarters
     double acc = 0.0;
-    if (tv) {
+    if (tv && d < a.cd) {
+      const int c0 = (int)((long long)a.D * qd / 4), c1 = (int)((long long)a.D * (qd + 1) / 4);
       const float* rp = a.residual + (size_t)b * a.D * a.T + t;
-      const float* wp = a.win + (size_t)part * a.D;
-      for (int c = 0; c < a.D; ++c) acc += (double)wp[c] * (double)rp[(size_t)c * a.T];
-      acc += (double)a.bin[part];
+      const float* wp = a.win + (size_t)d * a.D;
+      for (int c = c0; c < c1; ++c) acc += (double)wp[c] * (double)rp[(size_t)c * a.T];
     }
-    ze[tt][part] = (float)acc;
+    pz[qd][tt][d] = acc;
+  }
+  __syncthreads();
+  if (part < 8) {
+    const int d = part;
+    ze[tt][d] = d < a.cd && tv ? (float)((((pz[0][tt][d] + pz[1][tt][d]) + pz[2][tt][d]) + pz[3][tt][d]) + (double)a.bin[d]) : 0.f;
   }
   __syncthreads();
   // (2) normalise: s = sum x^2 (sequential), n = sqrt(s), x / max(n, 1e-12); e2 = sum en^2
@@ -340,12 +416,12 @@ __global__ __launch_bounds__(256) void rvq_step_kernel(RvqArgs a) {
     e2s[tt] = e2;
   }
   __syncthreads();
-  // (3) nearest neighbour: part p scans codes [p J/8, (p+1) J/8) in ascending order with a strict '<' (ties -> lowest index)
+  // (3) nearest neighbour
   {
     float e[8];
     for (int d = 0; d < 8; ++d) e[d] = d < a.cd ? en[tt][d] : 0.f;
     const float e2 = e2s[tt];
-    const int j0 = (int)((long long)a.J * part / 8), j1 = (int)((long long)a.J * (part + 1) / 8);
+    const int j0 = (int)((long long)a.J * part / NP), j1 = (int)((long long)a.J * (part + 1) / NP);
     float bd = INFINITY; int bi = j0;
     for (int j = j0; j < j1; ++j) {
       const float* c = a.cbn + (size_t)j * a.cd;
@@ -359,7 +435,7 @@ __global__ __launch_bounds__(256) void rvq_step_kernel(RvqArgs a) {
   __syncthreads();
   if (part == 0) {
     float bd = bestd[0][tt]; int bi = besti[0][tt];
-    for (int p = 1; p < 8; ++p)
+    for (int p = 1; p < NP; ++p)
       if (bestd[p][tt] < bd) { bd = bestd[p][tt]; bi = besti[p][tt]; }
     if (tv) a.codes[((size_t)b * a.nq + a.q) * a.T + t] = bi;
     for (int d = 0; d < a.cd; ++d) {
@@ -371,7 +447,7 @@ __global__ __launch_bounds__(256) void rvq_step_kernel(RvqArgs a) {
   __syncthreads();
   // (4) z_q_i[c] = sum_d wout[c][d] * st[d] + bout[c] (f64, rounded once);  zq += z_q_i;  residual -= z_q_i
   if (tv) {
-    for (int c = part; c < a.D; c += 8) {
+    for (int c = part; c < a.D; c += NP) {
       double acc = 0.0;
       const float* wp = a.wout + (size_t)c * a.cd;
       for (int d = 0; d < a.cd; ++d) acc += (double)wp[d] * (double)stv[tt][d];
@@ -421,6 +497,16 @@ int launch_conv1d(const float* x, const float* w, const float* bias, const float
   FD_REQUIRE(lds <= 64 * 1024, "fd_conv1d: kernel %d / stride %d / dilation %d needs %zu bytes of LDS (limit 64 KiB)", K, stride, dil, lds);
   Conv1dArgs a{x, w, bias, alpha, res, out, out_act, alpha_out, B, Ci, T, Co, K, (int)To, stride, pad, dil, tanh_out, wt};
   // the accumulation order per output is the same in both kernels (input channels ascending, taps ascending, one fma each): identical bits
+  if (stride == 1 && Ci == 1 && K <= 8 && !alpha) {
+    hipLaunchKernelGGL(conv1d_ci1_kernel, dim3(fd_cdiv(To, 256), B), dim3(256), 0, st, a);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+  }
+  if (stride == 1 && Co == 1 && sizeof(float) * C1C * (256 + (size_t)(K - 1) * dil) <= 64 * 1024) {
+    hipLaunchKernelGGL(conv1d_co1_kernel, dim3(fd_cdiv(To, 256), B), dim3(256), sizeof(float) * C1C * (256 + (size_t)(K - 1) * dil), st, a);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+  }
 #define FD_CONV1D_S1(K_, D_)                                                                                                                      \
   if (stride == 1 && K == K_ && dil == D_ && Co >= 4) {                                                                                           \
     constexpr size_t lds1 = sizeof(float) * (size_t)(CIC * ((TT1 + (K_ - 1) * D_ + 3) / 4 * 4) + CIC * K_ * CT);                                    \
@@ -428,7 +514,7 @@ int launch_conv1d(const float* x, const float* w, const float* bias, const float
     FD_LAUNCH_CHECK();                                                                                                                            \
     return FD_OK;                                                                                                                                 \
   }
-  FD_CONV1D_S1(7, 1) FD_CONV1D_S1(7, 3) FD_CONV1D_S1(1, 1) FD_CONV1D_S1(3, 1)
+  FD_CONV1D_S1(7, 1) FD_CONV1D_S1(7, 3) FD_CONV1D_S1(7, 9) FD_CONV1D_S1(1, 1) FD_CONV1D_S1(3, 1)
 #undef FD_CONV1D_S1
   hipLaunchKernelGGL(conv1d_kernel, dim3(fd_cdiv(To, TT), fd_cdiv(Co, CT), B), dim3(256), lds, st, a);
   FD_LAUNCH_CHECK();

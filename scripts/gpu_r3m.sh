@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O
-rm -rf $O/prof_ndac
+rm -rf $O/prof_ndac; rm -rf gpurun_out/prof_ndac
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ndac -- python $GRAFT_REPO_ROOT/scripts/ndac_bench.py --iters 2 < /dev/null > $O/prof_ndac.log 2>&1); echo "stats rc=$?"
 find $O/prof_ndac -name '*kernel_trace.csv' -size +20M -delete
 python - <<'PY'
