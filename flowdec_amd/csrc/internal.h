@@ -52,7 +52,7 @@ int fd_stft_inverse(fd_stft_plan* p, const float* X, int B, int T, int T_pad, fl
 size_t fd_stft_ws_bytes(int B, int L, int n_fft, int hop);
 // ndac_mfma.hip: the codec's wide convolutions on the matrix cores (split-bf16 operands, f32 tolerance)
 bool fd_ndac_mfma_supported(int Ci, int Co, int K, int stride, int dil, int transposed);
-size_t fd_ndac_mfma_packed_bytes(int Ci, int Co, int K);
+size_t fd_ndac_mfma_packed_bytes(int Ci, int Co, int K, int stride, int transposed);
 void fd_ndac_mfma_pack(const float* w_ci_k_co, int Ci, int Co, int K, int stride, int transposed, void* dst);
 int fd_ndac_mfma_conv(const float* x, const void* wp, const float* bias, const float* res, float* out, float* out_act, const float* alpha_out, int B,
                       int Ci, int T, int Co, int K, int stride, int pad, int dil, int transposed, hipStream_t st);

@@ -551,7 +551,7 @@ struct fd_ndac {
   // per-codebook device pointer tables for rvq_from_codes_kernel
   const float** d_wout = nullptr; const float** d_bout = nullptr; const float** d_cb = nullptr;
   std::vector<float*> cbn, c2;
-  std::map<std::string, void*> packed;   // "<layer>.weight" -> split-bf16 A-operand copy for ndac_mfma.hip (decoder layers it supports)
+  std::map<std::string, void*> packed;   // "<layer>.weight" -> split-bf16 A-operand copy for ndac_mfma.hip (the layers it supports)
   int precision = FD_NDAC_MFMA_DECODER;
   bool finalized = false;
 };
@@ -766,9 +766,11 @@ extern "C" int fd_ndac_finalize(fd_ndac* m, void* stream) {
           for (int co = 0; co < Co; ++co)
             t[((size_t)ci * K + k) * Co + co] = tr ? it->second[((size_t)ci * Co + co) * K + k] : it->second[((size_t)co * Ci + ci) * K + k];
       it->second.swap(t);
-      const int stride = tr ? K / 2 : 1;
-      if (p.name.rfind("decoder.", 0) == 0 && fd_ndac_mfma_supported(Ci, Co, K, stride, tr || K == 1 ? 1 : 9, tr)) {
-        const size_t nb = fd_ndac_mfma_packed_bytes(Ci, Co, K);
+      const bool down = p.name.rfind("encoder.", 0) == 0 && nblk == 2 && p.name.size() > 15 &&
+                        p.name.compare(p.name.size() - 15, 15, ".block.4.weight") == 0;   // encoder.block.<i>.block.4 = the strided WNConv1d (K = 2 s)
+      const int stride = tr || down ? K / 2 : 1;
+      if (fd_ndac_mfma_supported(Ci, Co, K, stride, tr || down || K == 1 ? 1 : 9, tr)) {   // (dilation 9: the widest staged tile of a K = 7 layer)
+        const size_t nb = fd_ndac_mfma_packed_bytes(Ci, Co, K, stride, tr);
         std::vector<unsigned char> hp(nb);
         fd_ndac_mfma_pack(it->second.data(), Ci, Co, K, stride, tr, hp.data());
         void* dp = nullptr;
@@ -826,7 +828,7 @@ extern "C" int fd_ndac_finalize(fd_ndac* m, void* stream) {
 
 extern "C" int fd_ndac_set_precision(fd_ndac* m, int flags) {
   FD_REQUIRE(m, "fd_ndac_set_precision: null codec");
-  FD_REQUIRE((flags & ~FD_NDAC_MFMA_DECODER) == 0, "fd_ndac_set_precision: unknown flags 0x%x", flags);
+  FD_REQUIRE((flags & ~(FD_NDAC_MFMA_DECODER | FD_NDAC_MFMA_ENCODER)) == 0, "fd_ndac_set_precision: unknown flags 0x%x", flags);
   m->precision = flags;
   return FD_OK;
 }
@@ -884,7 +886,7 @@ extern "C" int fd_ndac_encode(fd_ndac* m, const float* x, int B, int L, int n_qu
   const size_t slot = (need - 256) / 5;
   float* buf[5];
   for (int i = 0; i < 5; ++i) buf[i] = (float*)((char*)ws + i * slot);
-  Run r{m, st, B, false};
+  Run r{m, st, B, (m->precision & FD_NDAC_MFMA_ENCODER) != 0};
   int T = L, d = c.encoder_dim;
   float *cur_raw = buf[0], *cur_act = buf[1], *nxt_raw = buf[2], *nxt_act = buf[3], *tmp = buf[4];
   auto alpha_of = [&](const std::string& n) { return r.P(n + ".alpha"); };

@@ -35,6 +35,8 @@ struct MArgs {
   int rbase, rstep;          // LDS row of (local column c, tap j) = c + rbase + j * rstep
   int rows;                  // staged rows = TN + span
   int ostride, ooff;         // output position of column n, phase r = n * ostride + r + ooff
+  int nchunk;                // K-loop chunks of 32 GEMM-K elements
+  int pad;                   // strided form: input position of (row m, residue r) = S m + r - pad
 };
 
 __device__ __forceinline__ float snake_fast(float v, float alpha, float inv) {
@@ -80,7 +82,12 @@ __device__ __forceinline__ void epilogue(const MArgs& a, const Epi& ep, f32x16 (
     }
 }
 
-template <int MT>
+// S == 0: stride-1 convolution / transposed convolution (a chunk = 32 input channels of one position).
+// S >= 2: strided convolution Conv1d(K = m S, stride S) in polyphase form: out[n] = sum_j sum_r W[.., r + j S] x[S (n + j) + r - pad];
+//         an LDS row is output-rate position m, a chunk = floor(32 / S) input channels x S residues (GEMM-K element e = c S + r;
+//         32 - S floor(32 / S) zero columns), taps j = 0 .. m - 1 read rows n + j.  The S residues of a channel are S consecutive
+//         samples: the staging reads of neighbouring lanes are contiguous.
+template <int MT, int S>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(MArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* const xh = smem;
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(MArgs a) {
   const int b = blockIdx.z, n0 = blockIdx.x * TN;
   const int ncob = a.Co / (32 * MT);
   const int vcb = blockIdx.y, phase = vcb / ncob, co0 = (vcb - phase * ncob) * 32 * MT;
-  const int nchunk = a.Ci / CK;
+  const int nchunk = a.nchunk;
   constexpr int STEP = MT * 2 * 64;   // uint4 per (chunk, tap, 16-channel block)
   const uint4* wq = a.wp + (size_t)vcb * nchunk * a.ntaps * 2 * STEP + lane;
 
@@ -110,29 +117,75 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(MArgs a) {
   const int col = wave * 64 + (lane & 31);
   const int koff = (lane >> 5) * 16;
 
+  if (S > 0) {   // the zero columns are written once
+    constexpr int CPC = S > 0 ? CK / S : 1, USED = CPC * S;
+    if (USED < CK)
+      for (int p = tid; p < a.rows; p += 256)
+        for (int e = USED; e < CK; ++e) {
+          *reinterpret_cast<unsigned short*>(xh + p * ROWB + 2 * e) = 0;
+          *reinterpret_cast<unsigned short*>(xl + p * ROWB + 2 * e) = 0;
+        }
+  }
+
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     __syncthreads();
+    if (S == 0) {
 #pragma unroll 1
-    for (int g = 0; g < 4; g += 2) {   // two 8-channel groups per pass: 16 loads in flight per thread
-      const float* const src = xb + (size_t)(chunk * CK + 8 * g) * a.T;
-      for (int p = tid; p < a.rows; p += 256) {
-        const long long tp = pos0 + p;
-        float v[16];
-        if (tp >= 0 && tp < a.T) {
-          const float* q = src + tp;
+      for (int g = 0; g < 4; g += 2) {   // two 8-channel groups per pass: 16 loads in flight per thread
+        const float* const src = xb + (size_t)(chunk * CK + 8 * g) * a.T;
+        for (int p = tid; p < a.rows; p += 256) {
+          const long long tp = pos0 + p;
+          float v[16];
+          if (tp >= 0 && tp < a.T) {
+            const float* q = src + tp;
 #pragma unroll
-          for (int j = 0; j < 16; ++j) { v[j] = *q; q += a.T; }
+            for (int j = 0; j < 16; ++j) { v[j] = *q; q += a.T; }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = 0.f;
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hi[j] = (bf16)v[8 * h + j]; lo[j] = (bf16)(v[8 * h + j] - (float)hi[j]); }
+            *reinterpret_cast<bf16x8*>(xh + p * ROWB + (g + h) * 16) = hi;
+            *reinterpret_cast<bf16x8*>(xl + p * ROWB + (g + h) * 16) = lo;
+          }
+        }
+      }
+    } else {
+      constexpr int CPC = S > 0 ? CK / S : 1;
+      // item = (row p, channel c of the chunk): S consecutive samples -> S consecutive bf16 columns
+      for (int it = tid; it < a.rows * CPC; it += 256) {
+        const int c = it / a.rows, p = it - c * a.rows;
+        const int ci = chunk * CPC + c;
+        const long long q0 = ((long long)n0 + p) * S - a.pad;
+        const float* const src = xb + (size_t)(ci < a.Ci ? ci : 0) * a.T;
+        float v[S > 0 ? S : 1];
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+          const long long q = q0 + r;
+          v[r] = ci < a.Ci && q >= 0 && q < a.T ? src[q] : 0.f;
+        }
+        unsigned char* const dh = xh + p * ROWB + 2 * c * S;
+        unsigned char* const dl = xl + p * ROWB + 2 * c * S;
+        if (S % 2 == 0) {
+#pragma unroll
+          for (int r = 0; r < S; r += 2) {
+            bf16x2 hi, lo;
+            hi[0] = (bf16)v[r]; hi[1] = (bf16)v[r + 1];
+            lo[0] = (bf16)(v[r] - (float)hi[0]); lo[1] = (bf16)(v[r + 1] - (float)hi[1]);
+            *reinterpret_cast<bf16x2*>(dh + 2 * r) = hi;
+            *reinterpret_cast<bf16x2*>(dl + 2 * r) = lo;
+          }
         } else {
 #pragma unroll
-          for (int j = 0; j < 16; ++j) v[j] = 0.f;
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          bf16x8 hi, lo;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { hi[j] = (bf16)v[8 * h + j]; lo[j] = (bf16)(v[8 * h + j] - (float)hi[j]); }
-          *reinterpret_cast<bf16x8*>(xh + p * ROWB + (g + h) * 16) = hi;
-          *reinterpret_cast<bf16x8*>(xl + p * ROWB + (g + h) * 16) = lo;
+          for (int r = 0; r < S; ++r) {
+            const bf16 hi = (bf16)v[r];
+            *reinterpret_cast<bf16*>(dh + 2 * r) = hi;
+            *reinterpret_cast<bf16*>(dl + 2 * r) = (bf16)(v[r] - (float)hi);
+          }
         }
       }
     }
@@ -196,39 +249,76 @@ float bf16_f32(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memc
 
 int block_mt(int Co) { return Co % 96 == 0 ? 3 : (Co % 64 == 0 ? 2 : 0); }
 
+bool strided_form(int stride, int transposed) { return !transposed && stride > 1; }
+bool stride_instantiated(int s) { return s == 2 || s == 4 || s == 5 || s == 8 || s == 10; }
+int chunks_of(int Ci, int stride, int transposed) { return strided_form(stride, transposed) ? fd_cdiv(Ci, CK / stride) : Ci / CK; }
+
+template <int MT>
+int launch(const MArgs& a, int S, dim3 grid, size_t lds, hipStream_t st) {
+  switch (S) {
+    case 0: hipLaunchKernelGGL((conv1d_mfma_kernel<MT, 0>), grid, dim3(256), lds, st, a); break;
+    case 2: hipLaunchKernelGGL((conv1d_mfma_kernel<MT, 2>), grid, dim3(256), lds, st, a); break;
+    case 4: hipLaunchKernelGGL((conv1d_mfma_kernel<MT, 4>), grid, dim3(256), lds, st, a); break;
+    case 5: hipLaunchKernelGGL((conv1d_mfma_kernel<MT, 5>), grid, dim3(256), lds, st, a); break;
+    case 8: hipLaunchKernelGGL((conv1d_mfma_kernel<MT, 8>), grid, dim3(256), lds, st, a); break;
+    case 10: hipLaunchKernelGGL((conv1d_mfma_kernel<MT, 10>), grid, dim3(256), lds, st, a); break;
+    default: return fd_set_error(FD_EINVAL, "ndac mfma conv: stride %d not instantiated", S);
+  }
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}
+
 }  // namespace
 
 bool fd_ndac_mfma_supported(int Ci, int Co, int K, int stride, int dil, int transposed) {
-  if (Ci <= 0 || Ci % CK || !block_mt(Co) || K <= 0 || stride <= 0 || dil <= 0) return false;
-  if (transposed ? (K % stride != 0 || dil != 1) : stride != 1) return false;
-  const int span = transposed ? K / stride - 1 : (K - 1) * dil;
+  if (Ci <= 0 || !block_mt(Co) || K <= 0 || stride <= 0 || dil <= 0) return false;
+  if (strided_form(stride, transposed)) {
+    if (!stride_instantiated(stride) || K % stride != 0 || dil != 1) return false;
+  } else {
+    if (Ci % CK) return false;
+    if (transposed ? (K % stride != 0 || dil != 1) : stride != 1) return false;
+  }
+  const int span = stride > 1 ? K / stride - 1 : (K - 1) * dil;
   return (size_t)(TN + span) * ROWB * 2 <= 64 * 1024;
 }
 
-size_t fd_ndac_mfma_packed_bytes(int Ci, int Co, int K) {   // (phases x taps = K in both cases) + one step of prefetch padding
-  return ((size_t)Ci * K * Co * 2 + 3 * 2 * 64 * 8) * sizeof(unsigned short);
+size_t fd_ndac_mfma_packed_bytes(int Ci, int Co, int K, int stride, int transposed) {   // + one step of prefetch padding
+  const int ntaps = stride > 1 ? K / stride : K, nphase = transposed ? stride : 1;
+  const size_t steps = (size_t)nphase * chunks_of(Ci, stride, transposed) * ntaps * 2;
+  return (steps * Co * 16 * 2 + 3 * 2 * 64 * 8) * sizeof(unsigned short);
 }
 
-// w: [Ci][K][Co] float32 (the codec's own layout for both kinds) -> A-operand order
-//   [phase * Co / CB + co block][chunk of 32 ci][tap][16-ci block][32-co tile][hi | lo][lane][8]
+// w: [Ci][K][Co] float32 (the codec's own layout for all three kinds) -> A-operand order
+//   [phase * Co / CB + co block][chunk of 32 GEMM-K elements][tap][16-element block][32-co tile][hi | lo][lane][8]
+// GEMM-K element e of chunk c:  stride-1 / transposed: input channel 32 c + e;  strided: channel c floor(32 / S) + e / S, residue e % S
+// (kernel tap r + j S), zero beyond floor(32 / S) S or Ci.
 void fd_ndac_mfma_pack(const float* w, int Ci, int Co, int K, int stride, int transposed, void* dst) {
   const int mt_n = block_mt(Co), CB = 32 * mt_n, ncob = Co / CB;
-  const int nphase = transposed ? stride : 1, ntaps = transposed ? K / stride : K;
+  const bool str = strided_form(stride, transposed);
+  const int nphase = transposed ? stride : 1, ntaps = stride > 1 ? K / stride : K, nchunk = chunks_of(Ci, stride, transposed);
+  const int cpc = str ? CK / stride : CK;
   unsigned short* o = static_cast<unsigned short*>(dst);
-  memset(o, 0, fd_ndac_mfma_packed_bytes(Ci, Co, K));
+  memset(o, 0, fd_ndac_mfma_packed_bytes(Ci, Co, K, stride, transposed));
   for (int ph = 0; ph < nphase; ++ph)
     for (int cob = 0; cob < ncob; ++cob)
-      for (int chunk = 0; chunk < Ci / CK; ++chunk)
+      for (int chunk = 0; chunk < nchunk; ++chunk)
         for (int tap = 0; tap < ntaps; ++tap)
           for (int kb = 0; kb < 2; ++kb)
             for (int mt = 0; mt < mt_n; ++mt)
               for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j) {
-                  const int co = cob * CB + 32 * mt + (lane & 31), ci = chunk * CK + kb * 16 + (lane >> 5) * 8 + j;
-                  const int k = transposed ? ph + tap * stride : tap;
+                  const int co = cob * CB + 32 * mt + (lane & 31), e = kb * 16 + (lane >> 5) * 8 + j;
+                  int ci, k;
+                  if (str) {
+                    if (e >= cpc * stride) continue;
+                    ci = chunk * cpc + e / stride; k = e % stride + tap * stride;
+                    if (ci >= Ci) continue;
+                  } else {
+                    ci = chunk * CK + e; k = transposed ? ph + tap * stride : tap;
+                  }
                   const float v = w[((size_t)ci * K + k) * Co + co];
                   const unsigned short h = bf16_rne(v), l = bf16_rne(v - bf16_f32(h));
-                  const size_t step = (((size_t)(ph * ncob + cob) * (Ci / CK) + chunk) * ntaps + tap) * 2 + kb;
+                  const size_t step = (((size_t)(ph * ncob + cob) * nchunk + chunk) * ntaps + tap) * 2 + kb;
                   const size_t base = ((step * mt_n + mt) * 2) * 64 * 8 + (size_t)lane * 8 + j;
                   o[base] = h;
                   o[base + 64 * 8] = l;
@@ -242,14 +332,23 @@ int fd_ndac_mfma_conv(const float* x, const void* wp, const float* bias, const f
   FD_REQUIRE(x && wp && bias && (out || out_act) && (!out_act || alpha_out), "ndac mfma conv: null argument");
   MArgs a{};
   a.x = x; a.wp = static_cast<const uint4*>(wp); a.bias = bias; a.res = res; a.out = out; a.out_act = out_act; a.alpha_out = alpha_out;
-  a.Ci = Ci; a.T = T; a.Co = Co;
+  a.Ci = Ci; a.T = T; a.Co = Co; a.pad = pad;
+  a.nchunk = chunks_of(Ci, stride, transposed);
   long long To;
+  int S = 0;
   if (transposed) {
     a.ntaps = K / stride; a.nphase = stride;
     To = ((long long)T - 1) * stride - 2 * pad + K;
     a.N = T + a.ntaps - 1;
     a.xlo = -(a.ntaps - 1); a.rbase = a.ntaps - 1; a.rstep = -1; a.rows = TN + a.ntaps - 1;
     a.ostride = stride; a.ooff = -pad;
+  } else if (stride > 1) {
+    S = stride;
+    a.ntaps = K / stride; a.nphase = 1;
+    To = ((long long)T + 2 * pad - K) / stride + 1;
+    a.N = (int)To;
+    a.xlo = 0; a.rbase = 0; a.rstep = 1; a.rows = TN + a.ntaps - 1;
+    a.ostride = 1; a.ooff = 0;
   } else {
     a.ntaps = K; a.nphase = 1;
     To = (long long)T + 2 * pad - (long long)dil * (K - 1);
@@ -262,8 +361,5 @@ int fd_ndac_mfma_conv(const float* x, const void* wp, const float* bias, const f
   const int mt = block_mt(Co);
   const dim3 grid(fd_cdiv(a.N, TN), Co / (32 * mt) * a.nphase, B);
   const size_t lds = (size_t)a.rows * ROWB * 2;
-  if (mt == 3) hipLaunchKernelGGL((conv1d_mfma_kernel<3>), grid, dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((conv1d_mfma_kernel<2>), grid, dim3(256), lds, st, a);
-  FD_LAUNCH_CHECK();
-  return FD_OK;
+  return mt == 3 ? launch<3>(a, S, grid, lds, st) : launch<2>(a, S, grid, lds, st);
 }

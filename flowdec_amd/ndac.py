@@ -120,7 +120,9 @@ class DAC(nn.Module):
                  decoder_rates: Sequence[int] = (8, 8, 4, 2), n_codebooks: int = 9, codebook_size: int = 1024, codebook_dim=8, quantizer_dropout: bool = False,
                  sample_rate: int = 44100, precision: str = "mfma_decoder", **ignored):
         super().__init__()
-        self.precision = precision   # "mfma_decoder" (default: decoder on the matrix cores, split-bf16 operands, f32 tolerance) | "exact"
+        # "mfma_decoder" (default: decoder on the matrix cores, split-bf16 operands, f32 tolerance; encoder exact: code indices bit-identical
+        # to the oracle) | "exact" | "mfma" (encoder too: ~3x faster encode, code indices may differ at near-ties)
+        self.precision = precision
         if not isinstance(codebook_dim, int):
             raise NotImplementedError("flowdec_amd.ndac.DAC: per-codebook dimensions (a list) are not supported")
         self.encoder_dim, self.encoder_rates, self.decoder_dim, self.decoder_rates = encoder_dim, tuple(encoder_rates), decoder_dim, tuple(decoder_rates)
@@ -250,7 +252,7 @@ class DAC(nn.Module):
         self._handle, self._handle_sig = h, sig
         return h
 
-    PRECISIONS = {"exact": 0, "mfma_decoder": 1}   # include/flowdec_hip.h FD_NDAC_EXACT / FD_NDAC_MFMA_DECODER
+    PRECISIONS = {"exact": 0, "mfma_decoder": 1, "mfma": 3}   # include/flowdec_hip.h FD_NDAC_EXACT / _MFMA_DECODER / | _MFMA_ENCODER
 
     def _apply_precision(self, h):
         if self.precision not in self.PRECISIONS:
@@ -281,6 +283,7 @@ class DAC(nn.Module):
         lib = L.load()
         with self._lock, torch.cuda.device(x.device):
             h = self.handle()
+            self._apply_precision(h)
             T = lib.fd_ndac_latent_frames(h, Lw)
             z = torch.empty(B, self.latent_dim, T, dtype=torch.float32, device=x.device)
             codes = torch.empty(B, nq, T, dtype=torch.int32, device=x.device)

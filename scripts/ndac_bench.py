@@ -73,8 +73,18 @@ def main():
         finally:
             m.precision = "mfma_decoder"
 
-    for name, fn, fl in (("encode", lambda: m.encode(x, n_quantizers=a.nq), fe), ("from_codes", lambda: m.quantizer.from_codes(codes), 0),
-                         ("decode", lambda: m.decode(zq), fd), ("decode_exact", decode_exact, fd)):
+    def encode_mfma():
+        m.precision = "mfma"
+        try:
+            return m.encode(x, n_quantizers=a.nq)
+        finally:
+            m.precision = "mfma_decoder"
+
+    codes_m = encode_mfma()[1]
+    res["encode_mfma_code_mismatch_fraction"] = float((codes_m != codes).float().mean())
+    for name, fn, fl in (("encode", lambda: m.encode(x, n_quantizers=a.nq), fe), ("encode_mfma", encode_mfma, fe),
+                         ("from_codes", lambda: m.quantizer.from_codes(codes), 0), ("decode", lambda: m.decode(zq), fd),
+                         ("decode_exact", decode_exact, fd)):
         fn(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.iters):

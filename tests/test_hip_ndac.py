@@ -194,3 +194,32 @@ def test_decoder_on_matrix_cores(cfg, frames, batch):
     m.precision = "bf16"
     with pytest.raises(ValueError):
         m.decode(zq)
+
+
+WIDE_ENCODER = dict(NDAC75_LIKE, encoder_dim=32, n_codebooks=4)     # 32 -> 64 (/2) -> 128 (/4) -> 256 (/8) -> 512 (/10): strides 2, 4, 8, 10 on MFMA
+WIDE_ENCODER_S5 = dict(SMALL, encoder_dim=32)                       # 32 -> 64 (/2) -> 128 (/4) -> 256 (/5): the odd stride (16-bit LDS writes)
+
+
+@pytest.mark.parametrize("cfg,hops,batch", [(WIDE_ENCODER, 5, 2), (WIDE_ENCODER, 1, 1), (WIDE_ENCODER_S5, 41, 3)], ids=["wide_5h", "wide_1h", "s5_41h"])
+def test_encoder_on_matrix_cores(cfg, hops, batch):
+    """precision="mfma": the encoder's convolutions (strided ones in polyphase form) on the matrix cores.  The latent entering the
+    quantiser agrees with the oracle to TOL_MFMA_DECODE; code indices may differ from the exact path only at near-ties."""
+    m, o = build(cfg, 9, 0.7)
+    rng = np.random.default_rng(hops)
+    x = (0.3 * rng.standard_normal((batch, 1, hops * o.hop_length))).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    m.precision = "mfma"
+    z, codes, lat, _, _ = m.encode(xd)
+    m.precision = "exact"
+    z_e, codes_e, lat_e, _, _ = m.encode(xd)
+    z_o, codes_o, lat_o, _, _ = o.encode(x)
+    assert np.array_equal(codes_e.cpu().numpy(), codes_o)
+    cd = cfg["codebook_dim"]
+    check(f"ndac_encode_mfma_latent0[{hops}x{batch}]", lat[:, :cd].cpu().numpy(), lat_o[:, :cd], TOL_MFMA_DECODE)   # in_proj_0(encoder(x)): no quantiser decision in it
+    assert not torch.equal(lat[:, :cd], lat_e[:, :cd]), "identical bits: the matrix-core path did not run"
+    frac = float((codes != codes_e).float().mean())
+    report(f"ndac_encode_mfma_code_mismatch_fraction[{hops}x{batch}]", frac, 0.02)
+    assert frac <= 0.02, f"{frac:.4f} of the code indices differ from the exact path"
+    same = (codes == codes_e).all(dim=1, keepdim=True).expand(-1, z.shape[1], -1)    # frames whose whole code stack agrees: same z_q up to rounding
+    if bool(same.any()):
+        assert float((z - z_e)[same].abs().max()) <= 1e-4 * float(z_e.abs().max())
