@@ -7,11 +7,15 @@
 //   RVQ      per codebook: in_proj (1x1) -> L2-normalised nearest neighbour over the codebook -> out_proj (1x1); residual chain
 //   decoder  WNConv1d(latent, D, 7) -> [ Snake -> WNConvTranspose1d(k = 2 s, stride s) -> 3 x ResidualUnit ] per rate -> Snake -> WNConv1d(., 1, 7) -> tanh
 //
-// Layout [B][C][T] float32 (the reference's Conv1d layout); everything is f32 on the vector ALUs -- the codec is ~1.5 % of the
-// post-filter's FLOPs.  Kernels:
-//   conv1d_kernel       LDS-tiled dilated / strided 1-D convolution, 128 outputs x 32 channels per workgroup; the Snake activation of
-//                       the INPUT (every DAC conv but the first of each stack is preceded by one) is applied while the input tile is
-//                       staged, bias / residual add (ResidualUnit: x + block(x)) / tanh in the epilogue
+// Layout [B][C][T] float32 (the reference's Conv1d layout).  This file is the EXACT path: f32 on the vector ALUs in a defined operation
+// order per output (input channels ascending, taps ascending, one fma each; every convolution kernel below produces the same bits),
+// which is what makes the encoder's code indices reproducible.  The wide layers also exist as split-bf16 implicit GEMMs on the matrix
+// cores (ndac_mfma.hip: the decoder's default, the encoder's opt-in -- fd_ndac_set_precision).  Kernels:
+//   conv1d_kernel       LDS-tiled dilated / strided 1-D convolution, 128 outputs x 32 channels per workgroup; optional Snake of the INPUT
+//                       while the tile is staged (operator-level ABI), bias / residual add (ResidualUnit: x + block(x)) / tanh and the
+//                       NEXT layer's Snake (second output) in the epilogue
+//   conv1d_s1_kernel    the stride-1 layers (K = 7 dilation 1 / 3 / 9, K = 1, K = 3): register windows of 4 consecutive outputs
+//   conv1d_ci1_kernel / conv1d_co1_kernel   the one-channel ends of the codec (audio -> d channels, d channels -> audio)
 //   convtr1d_kernel     transposed convolution as a gather: output n takes taps k = (n + p) mod s, + s, ... of inputs (n + p - k) / s
 //   rvq_step_kernel     one residual quantiser: in_proj with f64 accumulation, nearest neighbour with the float32 operation order the
 //                       oracle defines (code indices BIT-EXACT; ties -> lowest index), straight-through value, out_proj, residual update
