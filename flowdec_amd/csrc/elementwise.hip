@@ -225,10 +225,111 @@ __global__ __launch_bounds__(256) void fir_down_kernel(const T* __restrict__ x, 
     }
 }
 
+// down, big grids: one thread = 4 channels of a BX-wide column block, MARCHING down a strip of NR output rows: every input row is
+// loaded and activated once per thread and enters the two output rows it belongs to ((2BX+2)/(2BX) x (2NR+2)/(2NR) = 1.33 SiLU
+// evaluations per input instead of 1.875 with 4x2 blocks).  Per output the fma sequence is the one of fir_down_kernel (horizontal taps
+// ascending from 0, then vertical taps ascending from 0): identical bits.  The FIR arithmetic is written on channel pairs (v_pk_fma_f32).
+typedef float fir_f2 __attribute__((ext_vector_type(2)));
+template <typename T, int BX, int NR>
+__global__ __launch_bounds__(256) void fir_down_march_kernel(const T* __restrict__ x, const float* __restrict__ affine, T* __restrict__ out_raw,
+                                                             T* __restrict__ out_act, int B, int H, int W, int C) {
+  constexpr int VEC = 4, PSX = 2 * BX + 2;
+  const int cvn = C / VEC;
+  const int OH = H >> 1, OW = W >> 1, nbx = (OW + BX - 1) / BX, nst = (OH + NR - 1) / NR;
+  const long long total = (long long)B * nst * nbx * cvn;
+  const long long idx = blockIdx.x * 256ll + threadIdx.x;
+  if (idx >= total) return;
+  const int cv = (int)(idx % cvn);
+  long long q = idx / cvn;
+  const int ox0 = (int)(q % nbx) * BX; q /= nbx;
+  const int oy0 = (int)(q % nst) * NR;
+  const int b = (int)(q / nst);
+  const int c = cv * VEC;
+  float a[VEC], d[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { a[i] = affine[((size_t)b * C + c + i) * 2]; d[i] = affine[((size_t)b * C + c + i) * 2 + 1]; }
+  const fir_f2 wt2[4] = {{0.125f, 0.125f}, {0.375f, 0.375f}, {0.375f, 0.375f}, {0.125f, 0.125f}};
+  // [output row: prev = rp - 1 | cur = rp][column][raw lo, raw hi, act lo, act hi channel pairs]
+  fir_f2 acc[2][BX][4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int px = 0; px < BX; ++px)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[s][px][k] = fir_f2{0.f, 0.f};
+  const size_t img = (size_t)b * H * W;
+  int xi[PSX]; bool xok[PSX];
+#pragma unroll
+  for (int rx = 0; rx < PSX; ++rx) { const int ix = 2 * ox0 - 1 + rx; xok[rx] = ix >= 0 && ix < W; xi[rx] = fir_clamp(ix, W); }
+  const int nrows = OH - oy0 < NR ? OH - oy0 : NR;
+#pragma unroll 1
+  for (int rp = 0; rp <= nrows; ++rp) {       // input rows 2 (oy0 + rp) - 1 and 2 (oy0 + rp): taps (2, 3) of output row rp - 1, (0, 1) of rp
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int iy = 2 * (oy0 + rp) - 1 + par;
+      const bool yok = iy >= 0 && iy < H;
+      const size_t row = (img + (size_t)fir_clamp(iy, H) * W) * C + c;
+      float r[PSX][VEC];
+#pragma unroll
+      for (int rx = 0; rx < PSX; ++rx) fd_load_vec<T, VEC>(x + row + (size_t)xi[rx] * C, r[rx]);
+      fir_f2 h[BX][4];
+#pragma unroll
+      for (int px = 0; px < BX; ++px)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) h[px][k] = fir_f2{0.f, 0.f};
+#pragma unroll
+      for (int rx = 0; rx < PSX; ++rx) {
+        const float m = yok && xok[rx] ? 1.f : 0.f;
+        float ac[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { ac[i] = m * fd_silu(fmaf(r[rx][i], a[i], d[i])); r[rx][i] *= m; }
+        const fir_f2 v[4] = {{r[rx][0], r[rx][1]}, {r[rx][2], r[rx][3]}, {ac[0], ac[1]}, {ac[2], ac[3]}};
+#pragma unroll
+        for (int px = 0; px < BX; ++px) {
+          const int kx = rx - 2 * px;
+          if (kx >= 0 && kx < 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) h[px][k] = __builtin_elementwise_fma(wt2[kx], v[k], h[px][k]);
+          }
+        }
+      }
+      // vertical: this input row is tap (par) of output row rp and tap (2 + par) of output row rp - 1
+#pragma unroll
+      for (int px = 0; px < BX; ++px)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          acc[1][px][k] = __builtin_elementwise_fma(wt2[par], h[px][k], acc[1][px][k]);
+          acc[0][px][k] = __builtin_elementwise_fma(wt2[2 + par], h[px][k], acc[0][px][k]);
+        }
+    }
+    if (rp > 0) {
+      const int oy = oy0 + rp - 1;
+#pragma unroll
+      for (int px = 0; px < BX; ++px) {
+        const int ox = ox0 + px;
+        if (ox < OW) {
+          const size_t o = (((size_t)b * OH + oy) * OW + ox) * C + c;
+          const float vr[VEC] = {acc[0][px][0][0], acc[0][px][0][1], acc[0][px][1][0], acc[0][px][1][1]};
+          const float va[VEC] = {acc[0][px][2][0], acc[0][px][2][1], acc[0][px][3][0], acc[0][px][3][1]};
+          if (out_raw) fd_store_vec<T, VEC>(out_raw + o, vr);
+          if (out_act) fd_store_vec<T, VEC>(out_act + o, va);
+        }
+      }
+    }
+#pragma unroll
+    for (int px = 0; px < BX; ++px)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { acc[0][px][k] = acc[1][px][k]; acc[1][px][k] = fir_f2{0.f, 0.f}; }
+  }
+}
+
+// up: one thread = VEC channels of one input column, N input rows: 2 output columns x 2N output rows.  The arithmetic is written on
+// channel pairs (v_pk_mul_f32 / v_pk_fma_f32: the same IEEE operations per element as the scalar form).
 template <typename T, int VEC, bool ACT, int N>
 __global__ __launch_bounds__(256) void fir_up_kernel(const T* __restrict__ x, const float* __restrict__ affine,
                                                      T* __restrict__ out_raw, T* __restrict__ out_act, int B, int H,
                                                      int W, int C) {
+  constexpr int NP = VEC / 2;
   const int cvn = C / VEC, ns = (H + N - 1) / N;
   const long long total = (long long)B * ns * W * cvn;
   const long long idx = blockIdx.x * 256ll + threadIdx.x;
@@ -247,8 +348,9 @@ __global__ __launch_bounds__(256) void fir_up_kernel(const T* __restrict__ x, co
     for (int i = 0; i < VEC; ++i) { a[i] = affine[((size_t)b * C + c + i) * 2]; d[i] = affine[((size_t)b * C + c + i) * 2 + 1]; }
   }
   const int OW = 2 * W, OH = 2 * H;
+  const fir_f2 w75 = {0.75f, 0.75f}, w25 = {0.25f, 0.25f};
   // horizontally combined rows for the output columns 2ix (px = 0: (x[ix-1] + 3 x[ix]) / 4) and 2ix+1 (px = 1), slot = row % 3
-  float hr[3][2][VEC], ha[3][2][VEC];
+  fir_f2 hr[3][2][NP], ha[3][2][NP];
   const size_t img = (size_t)b * H * W;
 #pragma unroll
   for (int j = 0; j < N + 2; ++j) {              // input row yy = y0 - 1 + j
@@ -261,12 +363,14 @@ __global__ __launch_bounds__(256) void fir_up_kernel(const T* __restrict__ x, co
       fir_load_px<T, VEC, ACT>(x, (img + (size_t)fir_clamp(yy, H) * W + fir_clamp(xx, W)) * C + c, yok && xx >= 0 && xx < W, a, d, r[dx], ac[dx]);
     }
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      hr[j % 3][0][i] = fmaf(0.75f, r[1][i], 0.25f * r[0][i]);
-      hr[j % 3][1][i] = fmaf(0.75f, r[1][i], 0.25f * r[2][i]);
+    for (int i = 0; i < NP; ++i) {
+      const fir_f2 r0 = {r[0][2 * i], r[0][2 * i + 1]}, r1 = {r[1][2 * i], r[1][2 * i + 1]}, r2 = {r[2][2 * i], r[2][2 * i + 1]};
+      hr[j % 3][0][i] = __builtin_elementwise_fma(w75, r1, w25 * r0);
+      hr[j % 3][1][i] = __builtin_elementwise_fma(w75, r1, w25 * r2);
       if (ACT) {
-        ha[j % 3][0][i] = fmaf(0.75f, ac[1][i], 0.25f * ac[0][i]);
-        ha[j % 3][1][i] = fmaf(0.75f, ac[1][i], 0.25f * ac[2][i]);
+        const fir_f2 a0 = {ac[0][2 * i], ac[0][2 * i + 1]}, a1 = {ac[1][2 * i], ac[1][2 * i + 1]}, a2 = {ac[2][2 * i], ac[2][2 * i + 1]};
+        ha[j % 3][0][i] = __builtin_elementwise_fma(w75, a1, w25 * a0);
+        ha[j % 3][1][i] = __builtin_elementwise_fma(w75, a1, w25 * a2);
       }
     }
     if (j >= 2) {                                // rows j-2, j-1, j complete the two output rows of input row iy = yy - 1
@@ -278,12 +382,14 @@ __global__ __launch_bounds__(256) void fir_up_kernel(const T* __restrict__ x, co
           const int other = py == 0 ? up : dn;   // py = 0: (row[iy-1] + 3 row[iy]) / 4; py = 1: (3 row[iy] + row[iy+1]) / 4
           float o0[VEC], o1[VEC], p0[VEC], p1[VEC];
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) {
-            o0[i] = fmaf(0.75f, hr[m][0][i], 0.25f * hr[other][0][i]);
-            o1[i] = fmaf(0.75f, hr[m][1][i], 0.25f * hr[other][1][i]);
+          for (int i = 0; i < NP; ++i) {
+            const fir_f2 t0 = __builtin_elementwise_fma(w75, hr[m][0][i], w25 * hr[other][0][i]);
+            const fir_f2 t1 = __builtin_elementwise_fma(w75, hr[m][1][i], w25 * hr[other][1][i]);
+            o0[2 * i] = t0[0]; o0[2 * i + 1] = t0[1]; o1[2 * i] = t1[0]; o1[2 * i + 1] = t1[1];
             if (ACT) {
-              p0[i] = fmaf(0.75f, ha[m][0][i], 0.25f * ha[other][0][i]);
-              p1[i] = fmaf(0.75f, ha[m][1][i], 0.25f * ha[other][1][i]);
+              const fir_f2 u0 = __builtin_elementwise_fma(w75, ha[m][0][i], w25 * ha[other][0][i]);
+              const fir_f2 u1 = __builtin_elementwise_fma(w75, ha[m][1][i], w25 * ha[other][1][i]);
+              p0[2 * i] = u0[0]; p0[2 * i + 1] = u0[1]; p1[2 * i] = u1[0]; p1[2 * i + 1] = u1[1];
             }
           }
           const size_t o = (((size_t)b * OH + 2 * iy + py) * OW + 2 * ix) * C + c;
@@ -662,12 +768,22 @@ static int launch_fir(const void* x, const float* affine, void* out_raw, void* o
     // output) fits the register budget: 430 us vs 512 us for 8-channel vectors x 4x1 at the same shape
     if (!affine) FD_FIR_DOWN(false, 1, 1);
     else if (VEC == 4 && sizeof(T) == 2) {
-      if (dgrid(4, 2).x >= ENOUGH) FD_FIR_DOWN(true, 4, 2);
+      // round 3: marching strips of NR output rows x 4 columns (1.33 instead of 1.875 activations per input, packed FIR arithmetic)
+      auto mgrid = [&](int nr) { return dim3(fd_cdiv((long long)B * fd_cdiv(H / 2, nr) * fd_cdiv(W / 2, 4) * (C / VEC), 256)); };
+#define FD_FIR_MARCH(NR_) hipLaunchKernelGGL((fir_down_march_kernel<T, 4, NR_>), mgrid(NR_), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C)
+      // measured at B = 8 x 256 channels (scripts/fir_bench.py): 768 x 256: 4x2 blocks 444 us, strips of 4 / 8 / 16 rows 315 / 302 / 292 us;
+      // 384 x 128: 130 us, 102 / 97 / 120 us (16-row strips leave 1.5 workgroups per CU) -> the tallest strip with >= 3 workgroups per CU
+      constexpr unsigned FILL = 768;
+      if (out_act && mgrid(16).x >= FILL) FD_FIR_MARCH(16);
+      else if (out_act && mgrid(8).x >= FILL) FD_FIR_MARCH(8);
+      else if (out_act && mgrid(4).x >= FILL) FD_FIR_MARCH(4);
+      else if (dgrid(4, 2).x >= ENOUGH) FD_FIR_DOWN(true, 4, 2);
       else if (dgrid(2, 1).x >= ENOUGH) FD_FIR_DOWN(true, 2, 1);
       else FD_FIR_DOWN(true, 1, 1);
     } else if (dgrid(4, 1).x >= ENOUGH) FD_FIR_DOWN(true, 4, 1);
     else FD_FIR_DOWN(true, 1, 1);
 #undef FD_FIR_DOWN
+#undef FD_FIR_MARCH
   }
   FD_LAUNCH_CHECK();
   return FD_OK;

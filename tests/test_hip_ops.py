@@ -248,6 +248,20 @@ def test_fir_resample_block_variants(ops, direction, prec):
     assert torch.isfinite(raw_s.float()).all() and torch.isfinite(act_s.float()).all()
 
 
+def test_fir_down_marching_strips_bit_identical(ops):
+    """Grids of >= 1024 workgroups take fir_down_march_kernel (strips of 16 output rows x 4 columns per thread, each input row
+    activated once): same fma sequence per output as the block kernels -- clip by clip the bits of one-clip launches; 244 output rows
+    (ragged last strip), 132 output columns."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, H, W, C = 9, 488, 264, 256
+    x = torch.randn(B, H, W, C, device="cuda", generator=g).to(torch.bfloat16)
+    aff = torch.stack([1 + 0.2 * torch.randn(B, C, device="cuda", generator=g), 0.3 * torch.randn(B, C, device="cuda", generator=g)], -1).contiguous()
+    raw, act = ops.fir_resample(x, -1, affine=aff)
+    for b in (0, 4, B - 1):
+        raw1, act1 = ops.fir_resample(x[b:b + 1].contiguous(), -1, affine=aff[b:b + 1].contiguous())
+        assert torch.equal(raw[b], raw1[0]) and torch.equal(act[b], act1[0])
+
+
 def test_upfirdn2d_golden():
     from flowdec_amd import op
     g = load_golden("g4_upfirdn2d.npz")
