@@ -323,20 +323,22 @@ __global__ __launch_bounds__(256) void fir_down_march_kernel(const T* __restrict
   }
 }
 
-// up: one thread = VEC channels of one input column, N input rows: 2 output columns x 2N output rows.  The arithmetic is written on
-// channel pairs (v_pk_mul_f32 / v_pk_fma_f32: the same IEEE operations per element as the scalar form).
-template <typename T, int VEC, bool ACT, int N>
+// up: one thread = VEC channels of BX input columns, N input rows: 2 BX output columns x 2N output rows; BX + 2 columns are loaded and
+// activated per row ((BX + 2) / BX x (N + 2) / N activations per input: 3.75 at 1 x 8, 2.5 at 2 x 8).  The arithmetic is written on
+// channel pairs (v_pk_mul_f32 / v_pk_fma_f32: the same IEEE operations per element as the scalar form); every output is the same
+// operation sequence for every (N, BX).
+template <typename T, int VEC, bool ACT, int N, int BX>
 __global__ __launch_bounds__(256) void fir_up_kernel(const T* __restrict__ x, const float* __restrict__ affine,
                                                      T* __restrict__ out_raw, T* __restrict__ out_act, int B, int H,
                                                      int W, int C) {
   constexpr int NP = VEC / 2;
-  const int cvn = C / VEC, ns = (H + N - 1) / N;
-  const long long total = (long long)B * ns * W * cvn;
+  const int cvn = C / VEC, ns = (H + N - 1) / N, nbx = (W + BX - 1) / BX;
+  const long long total = (long long)B * ns * nbx * cvn;
   const long long idx = blockIdx.x * 256ll + threadIdx.x;
   if (idx >= total) return;
   const int cv = (int)(idx % cvn);
   long long q = idx / cvn;
-  const int ix = (int)(q % W); q /= W;
+  const int ix0 = (int)(q % nbx) * BX; q /= nbx;
   const int y0 = (int)(q % ns) * N;
   const int b = (int)(q / ns);
   const int c = cv * VEC;
@@ -350,29 +352,31 @@ __global__ __launch_bounds__(256) void fir_up_kernel(const T* __restrict__ x, co
   const int OW = 2 * W, OH = 2 * H;
   const fir_f2 w75 = {0.75f, 0.75f}, w25 = {0.25f, 0.25f};
   // horizontally combined rows for the output columns 2ix (px = 0: (x[ix-1] + 3 x[ix]) / 4) and 2ix+1 (px = 1), slot = row % 3
-  fir_f2 hr[3][2][NP], ha[3][2][NP];
+  fir_f2 hr[3][2 * BX][NP], ha[3][2 * BX][NP];
   const size_t img = (size_t)b * H * W;
 #pragma unroll
   for (int j = 0; j < N + 2; ++j) {              // input row yy = y0 - 1 + j
     const int yy = y0 - 1 + j;
     const bool yok = yy >= 0 && yy < H;
-    float r[3][VEC], ac[3][VEC];
+    float r[BX + 2][VEC], ac[BX + 2][VEC];
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const int xx = ix + dx - 1;
+    for (int dx = 0; dx < BX + 2; ++dx) {
+      const int xx = ix0 + dx - 1;
       fir_load_px<T, VEC, ACT>(x, (img + (size_t)fir_clamp(yy, H) * W + fir_clamp(xx, W)) * C + c, yok && xx >= 0 && xx < W, a, d, r[dx], ac[dx]);
     }
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const fir_f2 r0 = {r[0][2 * i], r[0][2 * i + 1]}, r1 = {r[1][2 * i], r[1][2 * i + 1]}, r2 = {r[2][2 * i], r[2][2 * i + 1]};
-      hr[j % 3][0][i] = __builtin_elementwise_fma(w75, r1, w25 * r0);
-      hr[j % 3][1][i] = __builtin_elementwise_fma(w75, r1, w25 * r2);
-      if (ACT) {
-        const fir_f2 a0 = {ac[0][2 * i], ac[0][2 * i + 1]}, a1 = {ac[1][2 * i], ac[1][2 * i + 1]}, a2 = {ac[2][2 * i], ac[2][2 * i + 1]};
-        ha[j % 3][0][i] = __builtin_elementwise_fma(w75, a1, w25 * a0);
-        ha[j % 3][1][i] = __builtin_elementwise_fma(w75, a1, w25 * a2);
+    for (int bx = 0; bx < BX; ++bx)
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const fir_f2 r0 = {r[bx][2 * i], r[bx][2 * i + 1]}, r1 = {r[bx + 1][2 * i], r[bx + 1][2 * i + 1]}, r2 = {r[bx + 2][2 * i], r[bx + 2][2 * i + 1]};
+        hr[j % 3][2 * bx][i] = __builtin_elementwise_fma(w75, r1, w25 * r0);
+        hr[j % 3][2 * bx + 1][i] = __builtin_elementwise_fma(w75, r1, w25 * r2);
+        if (ACT) {
+          const fir_f2 a0 = {ac[bx][2 * i], ac[bx][2 * i + 1]}, a1 = {ac[bx + 1][2 * i], ac[bx + 1][2 * i + 1]}, a2 = {ac[bx + 2][2 * i], ac[bx + 2][2 * i + 1]};
+          ha[j % 3][2 * bx][i] = __builtin_elementwise_fma(w75, a1, w25 * a0);
+          ha[j % 3][2 * bx + 1][i] = __builtin_elementwise_fma(w75, a1, w25 * a2);
+        }
       }
-    }
     if (j >= 2) {                                // rows j-2, j-1, j complete the two output rows of input row iy = yy - 1
       const int iy = yy - 1;
       if (iy < H) {
@@ -380,21 +384,23 @@ __global__ __launch_bounds__(256) void fir_up_kernel(const T* __restrict__ x, co
 #pragma unroll
         for (int py = 0; py < 2; ++py) {
           const int other = py == 0 ? up : dn;   // py = 0: (row[iy-1] + 3 row[iy]) / 4; py = 1: (3 row[iy] + row[iy+1]) / 4
-          float o0[VEC], o1[VEC], p0[VEC], p1[VEC];
+          const size_t o = (((size_t)b * OH + 2 * iy + py) * OW + 2 * ix0) * C + c;
 #pragma unroll
-          for (int i = 0; i < NP; ++i) {
-            const fir_f2 t0 = __builtin_elementwise_fma(w75, hr[m][0][i], w25 * hr[other][0][i]);
-            const fir_f2 t1 = __builtin_elementwise_fma(w75, hr[m][1][i], w25 * hr[other][1][i]);
-            o0[2 * i] = t0[0]; o0[2 * i + 1] = t0[1]; o1[2 * i] = t1[0]; o1[2 * i + 1] = t1[1];
-            if (ACT) {
-              const fir_f2 u0 = __builtin_elementwise_fma(w75, ha[m][0][i], w25 * ha[other][0][i]);
-              const fir_f2 u1 = __builtin_elementwise_fma(w75, ha[m][1][i], w25 * ha[other][1][i]);
-              p0[2 * i] = u0[0]; p0[2 * i + 1] = u0[1]; p1[2 * i] = u1[0]; p1[2 * i + 1] = u1[1];
+          for (int px = 0; px < 2 * BX; ++px) {
+            if (BX > 1 && ix0 + px / 2 >= W) continue;
+            float o0[VEC], p0[VEC];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+              const fir_f2 t0 = __builtin_elementwise_fma(w75, hr[m][px][i], w25 * hr[other][px][i]);
+              o0[2 * i] = t0[0]; o0[2 * i + 1] = t0[1];
+              if (ACT) {
+                const fir_f2 u0 = __builtin_elementwise_fma(w75, ha[m][px][i], w25 * ha[other][px][i]);
+                p0[2 * i] = u0[0]; p0[2 * i + 1] = u0[1];
+              }
             }
+            if (out_raw) fd_store_vec<T, VEC>(out_raw + o + (size_t)px * C, o0);
+            if (ACT && out_act) fd_store_vec<T, VEC>(out_act + o + (size_t)px * C, p0);
           }
-          const size_t o = (((size_t)b * OH + 2 * iy + py) * OW + 2 * ix) * C + c;
-          if (out_raw) { fd_store_vec<T, VEC>(out_raw + o, o0); fd_store_vec<T, VEC>(out_raw + o + C, o1); }
-          if (ACT && out_act) { fd_store_vec<T, VEC>(out_act + o, p0); fd_store_vec<T, VEC>(out_act + o + C, p1); }
         }
       }
     }
@@ -753,13 +759,17 @@ static int launch_fir(const void* x, const float* affine, void* out_raw, void* o
   // Rows / output block per thread of the fused (activated) variants: big blocks re-use activated inputs (fewer SiLU evaluations per
   // output), small ones make more, shorter threads -- a small image is latency-bound (one clip at 384 x 64: 13-25 us with the big
   // blocks).  Every output is the same fma sequence in every variant, so the choice may depend on the batch size.
-  auto blocks = [&](int rows, int cols, int n) { return dim3(fd_cdiv((long long)B * fd_cdiv(rows, n) * cols * (C / VEC), 256)); };
+  auto blocks = [&](int rows, int cols, int n, int bx = 1) { return dim3(fd_cdiv((long long)B * fd_cdiv(rows, n) * fd_cdiv(cols, bx) * (C / VEC), 256)); };
   constexpr unsigned ENOUGH = 512;   // workgroups that keep 256 CUs busy
   if (direction > 0) {
-    if (!affine) hipLaunchKernelGGL((fir_up_kernel<T, VEC, false, 1>), blocks(H, W, 1), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C);
-    else if (blocks(H, W, 8).x >= ENOUGH) hipLaunchKernelGGL((fir_up_kernel<T, VEC, true, 8>), blocks(H, W, 8), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C);
-    else if (blocks(H, W, 2).x >= ENOUGH) hipLaunchKernelGGL((fir_up_kernel<T, VEC, true, 2>), blocks(H, W, 2), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C);
-    else hipLaunchKernelGGL((fir_up_kernel<T, VEC, true, 1>), blocks(H, W, 1), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C);
+#define FD_FIR_UP(ACT_, N_, BX_) hipLaunchKernelGGL((fir_up_kernel<T, VEC, ACT_, N_, BX_>), blocks(H, W, N_, BX_), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C)
+    if (!affine) FD_FIR_UP(false, 1, 1);
+    // (two columns per thread -- 2.5 instead of 3.75 activations per input -- is SLOWER: 435 vs 410 us at 8 x 384 x 128 x 256: the up
+    //  direction is bound by its 1.6 GB of stores (4 TB/s of writes), not by the activations; BX stays 1)
+    else if (blocks(H, W, 8).x >= ENOUGH) FD_FIR_UP(true, 8, 1);
+    else if (blocks(H, W, 2).x >= ENOUGH) FD_FIR_UP(true, 2, 1);
+    else FD_FIR_UP(true, 1, 1);
+#undef FD_FIR_UP
   } else {
     auto dgrid = [&](int by, int bx) { return dim3(fd_cdiv((long long)B * fd_cdiv(H / 2, by) * fd_cdiv(W / 2, bx) * (C / VEC), 256)); };
 #define FD_FIR_DOWN(ACT_, BY_, BX_) hipLaunchKernelGGL((fir_down_kernel<T, VEC, ACT_, BY_, BX_>), dgrid(BY_, BX_), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C)
@@ -798,7 +808,7 @@ extern "C" int fd_fir_resample(const void* x, const float* affine, void* out_raw
   FD_REQUIRE(out_act == nullptr || affine != nullptr, "fd_fir_resample: out_act needs affine");
   hipStream_t st = fd_stream(stream);
   if (dtype == FD_BF16) {
-    if (direction < 0 && affine) return launch_fir<bf16, 4>(x, affine, out_raw, out_act, B, H, W, C, direction, st);   // fused down: 4x2 blocks
+    if (direction < 0 && affine) return launch_fir<bf16, 4>(x, affine, out_raw, out_act, B, H, W, C, direction, st);   // fused down: strips / 4x2 blocks
     if (C % 8 == 0) return launch_fir<bf16, 8>(x, affine, out_raw, out_act, B, H, W, C, direction, st);
     return launch_fir<bf16, 4>(x, affine, out_raw, out_act, B, H, W, C, direction, st);
   } else if (dtype == FD_F32) {
