@@ -44,22 +44,22 @@ __device__ __forceinline__ float snake_fast(float v, float alpha, float inv) {
   return v + inv * (s * s);
 }
 
-struct Epi { int b, co0, tpos[2]; bool ok[2]; };
+struct Epi { int b, co0, tpos[2]; bool ok[2]; };   // ([2]: NT <= 2)
 
 // 16 rows of a tile at a time: their 16 residual values are requested together (one latency per batch, not per element)
-template <int MT, bool RES, bool OUT, bool ACT>
-__device__ __forceinline__ void epilogue(const MArgs& a, const Epi& ep, f32x16 (&acc)[MT][2]) {
+template <int MT, int NT, bool RES, bool OUT, bool ACT>
+__device__ __forceinline__ void epilogue(const MArgs& a, const Epi& ep, f32x16 (&acc)[MT][NT]) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int eh = 0; eh < 16; eh += 8) {
-      float rv[8][2];
+      float rv[8][NT];
       if (RES) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const size_t rowo = ((size_t)ep.b * a.Co + ep.co0 + 32 * mt + 8 * ((eh + e) >> 2) + (e & 3)) * a.To;
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) rv[e][nt] = a.res[rowo + ep.tpos[nt]];
+          for (int nt = 0; nt < NT; ++nt) rv[e][nt] = a.res[rowo + ep.tpos[nt]];
         }
       }
 #pragma unroll
@@ -70,7 +70,7 @@ __device__ __forceinline__ void epilogue(const MArgs& a, const Epi& ep, f32x16 (
         if (ACT) { ao = a.alpha_out[co]; inv = __builtin_amdgcn_rcpf(ao + 1e-9f); }
         const size_t rowo = ((size_t)ep.b * a.Co + co) * a.To;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
           float v = acc[mt][nt][eh + e] + bv;
           if (RES) v += rv[e][nt];
           if (ep.ok[nt]) {
@@ -87,24 +87,26 @@ __device__ __forceinline__ void epilogue(const MArgs& a, const Epi& ep, f32x16 (
 //         an LDS row is output-rate position m, a chunk = floor(32 / S) input channels x S residues (GEMM-K element e = c S + r;
 //         32 - S floor(32 / S) zero columns), taps j = 0 .. m - 1 read rows n + j.  The S residues of a channel are S consecutive
 //         samples: the staging reads of neighbouring lanes are contiguous.
-template <int MT, int S>
+// NT: 32-column MFMA tiles per wave (2: 256 positions per workgroup; 1: 128 -- twice the workgroups for short sequences / one clip).
+template <int MT, int S, int NT>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(MArgs a) {
+  constexpr int TNK = 128 * NT;
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* const xh = smem;
   unsigned char* const xl = smem + a.rows * ROWB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z, n0 = blockIdx.x * TN;
+  const int b = blockIdx.z, n0 = blockIdx.x * TNK;
   const int ncob = a.Co / (32 * MT);
   const int vcb = blockIdx.y, phase = vcb / ncob, co0 = (vcb - phase * ncob) * 32 * MT;
   const int nchunk = a.nchunk;
   constexpr int STEP = MT * 2 * 64;   // uint4 per (chunk, tap, 16-channel block)
   const uint4* wq = a.wp + (size_t)vcb * nchunk * a.ntaps * 2 * STEP + lane;
 
-  f32x16 acc[MT][2];
+  f32x16 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
 
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(MArgs a) {
 
   const float* const xb = a.x + (size_t)b * a.Ci * a.T;
   const long long pos0 = (long long)n0 + a.xlo;
-  const int col = wave * 64 + (lane & 31);
+  const int col = wave * 32 * NT + (lane & 31);
   const int koff = (lane >> 5) * 16;
 
   if (S > 0) {   // the zero columns are written once
@@ -199,16 +201,16 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(MArgs a) {
         uint4 nh[MT], nl[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { nh[mt] = wq[(mt * 2) * 64]; nl[mt] = wq[(mt * 2 + 1) * 64]; }
-        bf16x8 bh[2], bl[2];
+        bf16x8 bh[NT], bl[NT];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
           bh[nt] = *reinterpret_cast<const bf16x8*>(xh + r0 + nt * 32 * ROWB + kb * 32);
           bl[nt] = *reinterpret_cast<const bf16x8*>(xl + r0 + nt * 32 * ROWB + kb * 32);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
+          for (int nt = 0; nt < NT; ++nt) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[mt]), bh[nt], acc[mt][nt], 0, 0, 0);
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[mt]), bl[nt], acc[mt][nt], 0, 0, 0);
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[mt]), bh[nt], acc[mt][nt], 0, 0, 0);
@@ -223,20 +225,20 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(MArgs a) {
   Epi ep;
   ep.b = b; ep.co0 = co0 + 4 * (lane >> 5);
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
+  for (int nt = 0; nt < NT; ++nt) {
     const long long n = (long long)n0 + col + 32 * nt;
     const long long t = n * a.ostride + phase + a.ooff;
     ep.ok[nt] = n < a.N && t >= 0 && t < a.To;
     ep.tpos[nt] = ep.ok[nt] ? (int)t : 0;   // (clamped: the residual loads are unconditional, the stores predicated)
   }
   if (a.res) {
-    if (a.out) epilogue<MT, true, true, true>(a, ep, acc);
-    else epilogue<MT, true, false, true>(a, ep, acc);
+    if (a.out) epilogue<MT, NT, true, true, true>(a, ep, acc);
+    else epilogue<MT, NT, true, false, true>(a, ep, acc);
   } else if (a.out) {
-    if (a.out_act) epilogue<MT, false, true, true>(a, ep, acc);
-    else epilogue<MT, false, true, false>(a, ep, acc);
+    if (a.out_act) epilogue<MT, NT, false, true, true>(a, ep, acc);
+    else epilogue<MT, NT, false, true, false>(a, ep, acc);
   } else {
-    epilogue<MT, false, false, true>(a, ep, acc);
+    epilogue<MT, NT, false, false, true>(a, ep, acc);
   }
 }
 
@@ -253,15 +255,15 @@ bool strided_form(int stride, int transposed) { return !transposed && stride > 1
 bool stride_instantiated(int s) { return s == 2 || s == 4 || s == 5 || s == 8 || s == 10; }
 int chunks_of(int Ci, int stride, int transposed) { return strided_form(stride, transposed) ? fd_cdiv(Ci, CK / stride) : Ci / CK; }
 
-template <int MT>
+template <int MT, int NT>
 int launch(const MArgs& a, int S, dim3 grid, size_t lds, hipStream_t st) {
   switch (S) {
-    case 0: hipLaunchKernelGGL((conv1d_mfma_kernel<MT, 0>), grid, dim3(256), lds, st, a); break;
-    case 2: hipLaunchKernelGGL((conv1d_mfma_kernel<MT, 2>), grid, dim3(256), lds, st, a); break;
-    case 4: hipLaunchKernelGGL((conv1d_mfma_kernel<MT, 4>), grid, dim3(256), lds, st, a); break;
-    case 5: hipLaunchKernelGGL((conv1d_mfma_kernel<MT, 5>), grid, dim3(256), lds, st, a); break;
-    case 8: hipLaunchKernelGGL((conv1d_mfma_kernel<MT, 8>), grid, dim3(256), lds, st, a); break;
-    case 10: hipLaunchKernelGGL((conv1d_mfma_kernel<MT, 10>), grid, dim3(256), lds, st, a); break;
+    case 0: hipLaunchKernelGGL((conv1d_mfma_kernel<MT, 0, NT>), grid, dim3(256), lds, st, a); break;
+    case 2: hipLaunchKernelGGL((conv1d_mfma_kernel<MT, 2, NT>), grid, dim3(256), lds, st, a); break;
+    case 4: hipLaunchKernelGGL((conv1d_mfma_kernel<MT, 4, NT>), grid, dim3(256), lds, st, a); break;
+    case 5: hipLaunchKernelGGL((conv1d_mfma_kernel<MT, 5, NT>), grid, dim3(256), lds, st, a); break;
+    case 8: hipLaunchKernelGGL((conv1d_mfma_kernel<MT, 8, NT>), grid, dim3(256), lds, st, a); break;
+    case 10: hipLaunchKernelGGL((conv1d_mfma_kernel<MT, 10, NT>), grid, dim3(256), lds, st, a); break;
     default: return fd_set_error(FD_EINVAL, "ndac mfma conv: stride %d not instantiated", S);
   }
   FD_LAUNCH_CHECK();
@@ -335,31 +337,36 @@ int fd_ndac_mfma_conv(const float* x, const void* wp, const float* bias, const f
   a.Ci = Ci; a.T = T; a.Co = Co; a.pad = pad;
   a.nchunk = chunks_of(Ci, stride, transposed);
   long long To;
-  int S = 0;
+  int S = 0, span = 0;
   if (transposed) {
     a.ntaps = K / stride; a.nphase = stride;
     To = ((long long)T - 1) * stride - 2 * pad + K;
     a.N = T + a.ntaps - 1;
-    a.xlo = -(a.ntaps - 1); a.rbase = a.ntaps - 1; a.rstep = -1; a.rows = TN + a.ntaps - 1;
+    a.xlo = -(a.ntaps - 1); a.rbase = a.ntaps - 1; a.rstep = -1; span = a.ntaps - 1;
     a.ostride = stride; a.ooff = -pad;
   } else if (stride > 1) {
     S = stride;
     a.ntaps = K / stride; a.nphase = 1;
     To = ((long long)T + 2 * pad - K) / stride + 1;
     a.N = (int)To;
-    a.xlo = 0; a.rbase = 0; a.rstep = 1; a.rows = TN + a.ntaps - 1;
+    a.xlo = 0; a.rbase = 0; a.rstep = 1; span = a.ntaps - 1;
     a.ostride = 1; a.ooff = 0;
   } else {
     a.ntaps = K; a.nphase = 1;
     To = (long long)T + 2 * pad - (long long)dil * (K - 1);
     a.N = (int)To;
-    a.xlo = -pad; a.rbase = 0; a.rstep = dil; a.rows = TN + (K - 1) * dil;
+    a.xlo = -pad; a.rbase = 0; a.rstep = dil; span = (K - 1) * dil;
     a.ostride = 1; a.ooff = 0;
   }
   FD_REQUIRE(To > 0 && To < (1ll << 31), "ndac mfma conv: empty output");
   a.To = (int)To;
   const int mt = block_mt(Co);
-  const dim3 grid(fd_cdiv(a.N, TN), Co / (32 * mt) * a.nphase, B);
+  // 256 positions per workgroup unless that leaves fewer than two workgroups per CU (short sequences, one clip): then 128
+  const long long wgs256 = (long long)fd_cdiv(a.N, TN) * (Co / (32 * mt)) * a.nphase * B;
+  const int nt = wgs256 >= 512 ? 2 : 1, tn = 128 * nt;
+  a.rows = tn + span;
+  const dim3 grid(fd_cdiv(a.N, tn), Co / (32 * mt) * a.nphase, B);
   const size_t lds = (size_t)a.rows * ROWB * 2;
-  return mt == 3 ? launch<3>(a, S, grid, lds, st) : launch<2>(a, S, grid, lds, st);
+  if (nt == 2) return mt == 3 ? launch<3, 2>(a, S, grid, lds, st) : launch<2, 2>(a, S, grid, lds, st);
+  return mt == 3 ? launch<3, 1>(a, S, grid, lds, st) : launch<2, 1>(a, S, grid, lds, st);
 }
