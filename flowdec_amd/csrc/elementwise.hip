@@ -764,8 +764,9 @@ static int launch_fir(const void* x, const float* affine, void* out_raw, void* o
   if (direction > 0) {
 #define FD_FIR_UP(ACT_, N_, BX_) hipLaunchKernelGGL((fir_up_kernel<T, VEC, ACT_, N_, BX_>), blocks(H, W, N_, BX_), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C)
     if (!affine) FD_FIR_UP(false, 1, 1);
-    // (two columns per thread -- 2.5 instead of 3.75 activations per input -- is SLOWER: 435 vs 410 us at 8 x 384 x 128 x 256: the up
-    //  direction is bound by its 1.6 GB of stores (4 TB/s of writes), not by the activations; BX stays 1)
+    // measured at 8 x 384 x 128 x 256 -> 768 x 256 (1.8 GB moved): 8 rows x 1 column, 8-channel vectors 414 us; 16 rows 446; 4 rows 432;
+    // 4-channel vectors 409 / 458 / 463; two columns per thread (2.5 instead of 3.75 activations per input) 403 (4 ch x 8 rows): the up
+    // direction does not react to the activation count or the vector width (4.4 TB/s, 4.0 of them stores) -- BX stays 1
     else if (blocks(H, W, 8).x >= ENOUGH) FD_FIR_UP(true, 8, 1);
     else if (blocks(H, W, 2).x >= ENOUGH) FD_FIR_UP(true, 2, 1);
     else FD_FIR_UP(true, 1, 1);
