@@ -42,7 +42,7 @@ def main(fetch_dir, write_dir, steps, pixels=0):
         out["kernels"][k] = dict(launches=n, fetch_raw_per_launch=f / n, fetch_corrected_per_launch=2 * f / n, write_per_launch=w / n)
         if k.startswith("conv_mfma_kernel") or k.startswith("conv_wino_kernel") or k.startswith("conv_head_kernel"):
             conv["launches"] += n; conv["fetch_raw"] += f; conv["write"] += w
-        if (k.startswith("fir_up_kernel") or k.startswith("fir_down_kernel")):
+        if k.startswith(("fir_up_kernel", "fir_down_kernel", "fir_down_march_kernel")):
             fir["launches"] += n; fir["fetch_raw"] += f; fir["write"] += w
     n = conv["launches"]
     out["conv_mfma_kernel"] = dict(launches=n, launches_per_step=n // steps, fetch_corrected_per_launch=2 * conv["fetch_raw"] / n,
