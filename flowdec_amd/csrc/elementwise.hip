@@ -2,6 +2,8 @@
 // GroupNorm statistics, FIR x2 resampling (+ fused GroupNorm/SiLU), generic upfirdn2d,
 // fused bias+act, time embedding, the 4-channel convs at the edges of the U-Net, and the
 // ODE state updates fused with the final 1x1 output layer.
+#include <type_traits>
+
 #include "common.h"
 #include "internal.h"
 
@@ -140,6 +142,33 @@ __device__ __forceinline__ void fir_load_px(const T* __restrict__ x, size_t base
 }
 __device__ __forceinline__ int fir_clamp(int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
 
+// A pixel's VEC channels as loaded (not yet converted): the marching kernels request the NEXT row before they store the current one.
+// Loads and stores return in order on this ISA (one vmcnt counter): a wait for loads issued AFTER a row's stores is a wait for the
+// stores' acknowledgement as well -- measured on fir_up: 194 us of loads + arithmetic and 237 us of stores ran back to back (431 us).
+template <typename T, int VEC> struct fir_raw;
+template <> struct fir_raw<bf16, 8> { bf16x8 v; __device__ void load(const bf16* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ void get(float (&f)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i]; } };
+template <> struct fir_raw<bf16, 4> { bf16x4 v; __device__ void load(const bf16* p) { v = *reinterpret_cast<const bf16x4*>(p); }
+  __device__ void get(float (&f)[4]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = (float)v[i]; } };
+template <> struct fir_raw<float, 4> { f32x4 v; __device__ void load(const float* p) { v = *reinterpret_cast<const f32x4*>(p); }
+  __device__ void get(float (&f)[4]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = v[i]; } };
+// activation + zero padding of an already loaded pixel (the arithmetic of fir_load_px)
+template <int VEC, bool ACT>
+__device__ __forceinline__ void fir_act_px(bool ok, const float (&a)[VEC], const float (&d)[VEC], float (&r)[VEC], float (&ac)[VEC]) {
+  const float m = ok ? 1.f : 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    ac[i] = ACT ? m * fd_silu(fmaf(r[i], a[i], d[i])) : 0.f;
+    r[i] *= m;
+  }
+}
+
 // down: one thread = one VEC-channel vector of a BY x BX block of output pixels: the (2BY+2) x (2BX+2) input patch is
 // loaded and activated once (2x2: 9 instead of 16 SiLU evaluations per output; 1x1 is the direct form).
 template <typename T, int VEC, bool ACT, int BY, int BX>
@@ -230,7 +259,11 @@ __global__ __launch_bounds__(256) void fir_down_kernel(const T* __restrict__ x, 
 // evaluations per input instead of 1.875 with 4x2 blocks).  Per output the fma sequence is the one of fir_down_kernel (horizontal taps
 // ascending from 0, then vertical taps ascending from 0): identical bits.  The FIR arithmetic is written on channel pairs (v_pk_fma_f32).
 typedef float fir_f2 __attribute__((ext_vector_type(2)));
-template <typename T, int BX, int NR>
+// FAST (every strip and column block full, both outputs): the stores are unconditional and the row-pair step exists three times --
+// without stores (row pair 0), with stores (row pair 1, peeled) and as the loop body -- so that every path into a wait for the next
+// input row carries the same memory operations: hipcc's s_waitcnt vmcnt(n) then counts the stores still in flight instead of waiting
+// for them (see fir_raw).
+template <typename T, int BX, int NR, bool FAST = false>
 __global__ __launch_bounds__(256) void fir_down_march_kernel(const T* __restrict__ x, const float* __restrict__ affine, T* __restrict__ out_raw,
                                                              T* __restrict__ out_act, int B, int H, int W, int C) {
   constexpr int VEC = 4, PSX = 2 * BX + 2;
@@ -261,17 +294,25 @@ __global__ __launch_bounds__(256) void fir_down_march_kernel(const T* __restrict
   int xi[PSX]; bool xok[PSX];
 #pragma unroll
   for (int rx = 0; rx < PSX; ++rx) { const int ix = 2 * ox0 - 1 + rx; xok[rx] = ix >= 0 && ix < W; xi[rx] = fir_clamp(ix, W); }
-  const int nrows = OH - oy0 < NR ? OH - oy0 : NR;
-#pragma unroll 1
-  for (int rp = 0; rp <= nrows; ++rp) {       // input rows 2 (oy0 + rp) - 1 and 2 (oy0 + rp): taps (2, 3) of output row rp - 1, (0, 1) of rp
+  const int nrows = FAST ? NR : (OH - oy0 < NR ? OH - oy0 : NR);
+  fir_raw<T, VEC> nxt[PSX];
+  auto request_row = [&](int iy) {              // (clamped: the zero padding is a factor later)
+    const size_t row = (img + (size_t)fir_clamp(iy, H) * W) * C + c;
+#pragma unroll
+    for (int rx = 0; rx < PSX; ++rx) nxt[rx].load(x + row + (size_t)xi[rx] * C);
+  };
+  // row pair rp = input rows 2 (oy0 + rp) - 1 and 2 (oy0 + rp): taps (2, 3) of output row rp - 1, (0, 1) of rp; then output row rp - 1 is
+  // complete (stored when `store`), and rp becomes the previous row
+  auto step = [&](int rp, auto store) __attribute__((always_inline)) {
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
       const int iy = 2 * (oy0 + rp) - 1 + par;
       const bool yok = iy >= 0 && iy < H;
-      const size_t row = (img + (size_t)fir_clamp(iy, H) * W) * C + c;
       float r[PSX][VEC];
 #pragma unroll
-      for (int rx = 0; rx < PSX; ++rx) fd_load_vec<T, VEC>(x + row + (size_t)xi[rx] * C, r[rx]);
+      for (int rx = 0; rx < PSX; ++rx) nxt[rx].get(r[rx]);
+      request_row(iy + 1);                      // the next row, before this row pair's stores; one row past the strip at the end
+      __builtin_amdgcn_sched_barrier(0);
       fir_f2 h[BX][4];
 #pragma unroll
       for (int px = 0; px < BX; ++px)
@@ -293,7 +334,6 @@ __global__ __launch_bounds__(256) void fir_down_march_kernel(const T* __restrict
           }
         }
       }
-      // vertical: this input row is tap (par) of output row rp and tap (2 + par) of output row rp - 1
 #pragma unroll
       for (int px = 0; px < BX; ++px)
 #pragma unroll
@@ -302,17 +342,17 @@ __global__ __launch_bounds__(256) void fir_down_march_kernel(const T* __restrict
           acc[0][px][k] = __builtin_elementwise_fma(wt2[2 + par], h[px][k], acc[0][px][k]);
         }
     }
-    if (rp > 0) {
+    if (decltype(store)::value) {
       const int oy = oy0 + rp - 1;
 #pragma unroll
       for (int px = 0; px < BX; ++px) {
         const int ox = ox0 + px;
-        if (ox < OW) {
+        if (FAST || ox < OW) {
           const size_t o = (((size_t)b * OH + oy) * OW + ox) * C + c;
           const float vr[VEC] = {acc[0][px][0][0], acc[0][px][0][1], acc[0][px][1][0], acc[0][px][1][1]};
           const float va[VEC] = {acc[0][px][2][0], acc[0][px][2][1], acc[0][px][3][0], acc[0][px][3][1]};
-          if (out_raw) fd_store_vec<T, VEC>(out_raw + o, vr);
-          if (out_act) fd_store_vec<T, VEC>(out_act + o, va);
+          if (FAST || out_raw) fd_store_vec<T, VEC>(out_raw + o, vr);
+          if (FAST || out_act) fd_store_vec<T, VEC>(out_act + o, va);
         }
       }
     }
@@ -320,6 +360,16 @@ __global__ __launch_bounds__(256) void fir_down_march_kernel(const T* __restrict
     for (int px = 0; px < BX; ++px)
 #pragma unroll
       for (int k = 0; k < 4; ++k) { acc[0][px][k] = acc[1][px][k]; acc[1][px][k] = fir_f2{0.f, 0.f}; }
+  };
+  request_row(2 * oy0 - 1);
+  step(0, std::false_type{});
+  if (FAST) {
+    step(1, std::true_type{});
+#pragma unroll 1
+    for (int rp = 2; rp <= NR; ++rp) step(rp, std::true_type{});
+  } else {
+#pragma unroll 1
+    for (int rp = 1; rp <= nrows; ++rp) step(rp, std::true_type{});
   }
 }
 
@@ -327,7 +377,10 @@ __global__ __launch_bounds__(256) void fir_down_march_kernel(const T* __restrict
 // activated per row ((BX + 2) / BX x (N + 2) / N activations per input: 3.75 at 1 x 8, 2.5 at 2 x 8).  The arithmetic is written on
 // channel pairs (v_pk_mul_f32 / v_pk_fma_f32: the same IEEE operations per element as the scalar form); every output is the same
 // operation sequence for every (N, BX).
-template <typename T, int VEC, bool ACT, int N, int BX>
+// FAST: every strip is full (H % N == 0, W % BX == 0) and both outputs exist: the stores are UNCONDITIONAL -- no control flow between a
+// row's loads and the next row's use, so hipcc's s_waitcnt vmcnt(n) counts the stores in flight exactly instead of joining a path
+// without them (which made every wait for a row also a wait for the previous row's stores).
+template <typename T, int VEC, bool ACT, int N, int BX, bool FAST = false>
 __global__ __launch_bounds__(256) void fir_up_kernel(const T* __restrict__ x, const float* __restrict__ affine,
                                                      T* __restrict__ out_raw, T* __restrict__ out_act, int B, int H,
                                                      int W, int C) {
@@ -354,15 +407,26 @@ __global__ __launch_bounds__(256) void fir_up_kernel(const T* __restrict__ x, co
   // horizontally combined rows for the output columns 2ix (px = 0: (x[ix-1] + 3 x[ix]) / 4) and 2ix+1 (px = 1), slot = row % 3
   fir_f2 hr[3][2 * BX][NP], ha[3][2 * BX][NP];
   const size_t img = (size_t)b * H * W;
+  fir_raw<T, VEC> nxt[BX + 2];
+  auto request_row = [&](int j) {                // input row y0 - 1 + j (clamped: the zero padding is a factor later)
+    const size_t row = (img + (size_t)fir_clamp(y0 - 1 + j, H) * W) * C + c;
+#pragma unroll
+    for (int dx = 0; dx < BX + 2; ++dx) nxt[dx].load(x + row + (size_t)fir_clamp(ix0 + dx - 1, W) * C);
+  };
+  request_row(0);
 #pragma unroll
   for (int j = 0; j < N + 2; ++j) {              // input row yy = y0 - 1 + j
     const int yy = y0 - 1 + j;
     const bool yok = yy >= 0 && yy < H;
     float r[BX + 2][VEC], ac[BX + 2][VEC];
 #pragma unroll
+    for (int dx = 0; dx < BX + 2; ++dx) nxt[dx].get(r[dx]);
+    if (j + 1 < N + 2) request_row(j + 1);       // before this row's stores (see fir_raw)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
     for (int dx = 0; dx < BX + 2; ++dx) {
       const int xx = ix0 + dx - 1;
-      fir_load_px<T, VEC, ACT>(x, (img + (size_t)fir_clamp(yy, H) * W + fir_clamp(xx, W)) * C + c, yok && xx >= 0 && xx < W, a, d, r[dx], ac[dx]);
+      fir_act_px<VEC, ACT>(yok && xx >= 0 && xx < W, a, d, r[dx], ac[dx]);
     }
 #pragma unroll
     for (int bx = 0; bx < BX; ++bx)
@@ -379,7 +443,7 @@ __global__ __launch_bounds__(256) void fir_up_kernel(const T* __restrict__ x, co
       }
     if (j >= 2) {                                // rows j-2, j-1, j complete the two output rows of input row iy = yy - 1
       const int iy = yy - 1;
-      if (iy < H) {
+      if (FAST || iy < H) {
         const int up = (j - 2) % 3, m = (j - 1) % 3, dn = j % 3;
 #pragma unroll
         for (int py = 0; py < 2; ++py) {
@@ -387,7 +451,7 @@ __global__ __launch_bounds__(256) void fir_up_kernel(const T* __restrict__ x, co
           const size_t o = (((size_t)b * OH + 2 * iy + py) * OW + 2 * ix0) * C + c;
 #pragma unroll
           for (int px = 0; px < 2 * BX; ++px) {
-            if (BX > 1 && ix0 + px / 2 >= W) continue;
+            if (!FAST && BX > 1 && ix0 + px / 2 >= W) continue;
             float o0[VEC], p0[VEC];
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
@@ -398,8 +462,8 @@ __global__ __launch_bounds__(256) void fir_up_kernel(const T* __restrict__ x, co
                 p0[2 * i] = u0[0]; p0[2 * i + 1] = u0[1];
               }
             }
-            if (out_raw) fd_store_vec<T, VEC>(out_raw + o + (size_t)px * C, o0);
-            if (ACT && out_act) fd_store_vec<T, VEC>(out_act + o + (size_t)px * C, p0);
+            if (FAST || out_raw) fd_store_vec<T, VEC>(out_raw + o + (size_t)px * C, o0);
+            if (ACT && (FAST || out_act)) fd_store_vec<T, VEC>(out_act + o + (size_t)px * C, p0);
           }
         }
       }
@@ -767,6 +831,8 @@ static int launch_fir(const void* x, const float* affine, void* out_raw, void* o
     // measured at 8 x 384 x 128 x 256 -> 768 x 256 (1.8 GB moved): 8 rows x 1 column, 8-channel vectors 414 us; 16 rows 446; 4 rows 432;
     // 4-channel vectors 409 / 458 / 463; two columns per thread (2.5 instead of 3.75 activations per input) 403 (4 ch x 8 rows): the up
     // direction does not react to the activation count or the vector width (4.4 TB/s, 4.0 of them stores) -- BX stays 1
+    else if (blocks(H, W, 8).x >= ENOUGH && H % 8 == 0 && out_raw && out_act)
+      hipLaunchKernelGGL((fir_up_kernel<T, VEC, true, 8, 1, true>), blocks(H, W, 8, 1), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C);
     else if (blocks(H, W, 8).x >= ENOUGH) FD_FIR_UP(true, 8, 1);
     else if (blocks(H, W, 2).x >= ENOUGH) FD_FIR_UP(true, 2, 1);
     else FD_FIR_UP(true, 1, 1);
@@ -781,7 +847,13 @@ static int launch_fir(const void* x, const float* affine, void* out_raw, void* o
     else if (VEC == 4 && sizeof(T) == 2) {
       // round 3: marching strips of NR output rows x 4 columns (1.33 instead of 1.875 activations per input, packed FIR arithmetic)
       auto mgrid = [&](int nr) { return dim3(fd_cdiv((long long)B * fd_cdiv(H / 2, nr) * fd_cdiv(W / 2, 4) * (C / VEC), 256)); };
-#define FD_FIR_MARCH(NR_) hipLaunchKernelGGL((fir_down_march_kernel<T, 4, NR_>), mgrid(NR_), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C)
+#define FD_FIR_MARCH(NR_)                                                                                                                             \
+  do {                                                                                                                                             \
+    if (out_raw && (H / 2) % NR_ == 0 && (W / 2) % 4 == 0)                                                                                         \
+      hipLaunchKernelGGL((fir_down_march_kernel<T, 4, NR_, true>), mgrid(NR_), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C); \
+    else                                                                                                                                           \
+      hipLaunchKernelGGL((fir_down_march_kernel<T, 4, NR_, false>), mgrid(NR_), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C); \
+  } while (0)
       // measured at B = 8 x 256 channels (scripts/fir_bench.py): 768 x 256: 4x2 blocks 444 us, strips of 4 / 8 / 16 rows 315 / 302 / 292 us;
       // 384 x 128: 130 us, 102 / 97 / 120 us (16-row strips leave 1.5 workgroups per CU) -> the tallest strip with >= 3 workgroups per CU
       constexpr unsigned FILL = 768;

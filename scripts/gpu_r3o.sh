@@ -1,5 +1,6 @@
 #!/bin/bash
+# FIR kernels: parity tests + micro-benchmark
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-for v in 81 161 41; do echo "VEC8 N*10+BX=$v"; FD_EXP_UP=$v timeout 300 python scripts/fir_bench.py 2>&1 | grep "dir +1"; done
-for v in 81 161 41 82 42; do echo "VEC4 N*10+BX=$v"; FD_EXP_UP4=1 FD_EXP_UP=$v timeout 300 python scripts/fir_bench.py 2>&1 | grep "dir +1"; done
+timeout 600 python -m pytest tests/test_hip_ops.py -m gpu -q -k "fir or resblock or upfirdn" < /dev/null 2>&1 | tail -3
+timeout 300 python scripts/fir_bench.py 2>&1 | grep dir

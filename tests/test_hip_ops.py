@@ -248,12 +248,13 @@ def test_fir_resample_block_variants(ops, direction, prec):
     assert torch.isfinite(raw_s.float()).all() and torch.isfinite(act_s.float()).all()
 
 
-def test_fir_down_marching_strips_bit_identical(ops):
-    """Grids of >= 1024 workgroups take fir_down_march_kernel (strips of 16 output rows x 4 columns per thread, each input row
-    activated once): same fma sequence per output as the block kernels -- clip by clip the bits of one-clip launches; 244 output rows
-    (ragged last strip), 132 output columns."""
+@pytest.mark.parametrize("B,H,W", [(9, 488, 264), (9, 512, 256), (8, 384, 128)], ids=["ragged", "full_strips_16", "full_strips_8"])
+def test_fir_down_marching_strips_bit_identical(ops, B, H, W):
+    """Big grids take fir_down_march_kernel (strips of 16 / 8 output rows x 4 columns per thread, each input row activated once): same
+    fma sequence per output as the block kernels -- clip by clip the bits of one-clip launches.  ragged: 244 output rows, 132 columns
+    (guarded stores); full strips: the variant with unconditional stores and peeled row pairs."""
     g = torch.Generator(device="cuda").manual_seed(3)
-    B, H, W, C = 9, 488, 264, 256
+    C = 256
     x = torch.randn(B, H, W, C, device="cuda", generator=g).to(torch.bfloat16)
     aff = torch.stack([1 + 0.2 * torch.randn(B, C, device="cuda", generator=g), 0.3 * torch.randn(B, C, device="cuda", generator=g)], -1).contiguous()
     raw, act = ops.fir_resample(x, -1, affine=aff)
