@@ -830,7 +830,8 @@ static int launch_fir(const void* x, const float* affine, void* out_raw, void* o
     if (!affine) FD_FIR_UP(false, 1, 1);
     // measured at 8 x 384 x 128 x 256 -> 768 x 256 (1.8 GB moved): 8 rows x 1 column, 8-channel vectors 414 us; 16 rows 446; 4 rows 432;
     // 4-channel vectors 409 / 458 / 463; two columns per thread (2.5 instead of 3.75 activations per input) 403 (4 ch x 8 rows): the up
-    // direction does not react to the activation count or the vector width (4.4 TB/s, 4.0 of them stores) -- BX stays 1
+    // direction does not react to the activation count or the vector width (4.4 TB/s, 4.0 of them stores) -- BX stays 1.  What it reacts
+    // to is the store accounting (FAST): 357-361 us; FAST variants of the other shapes: 4 rows 404, 16 rows 392, 4-channel vectors 380-448
     else if (blocks(H, W, 8).x >= ENOUGH && H % 8 == 0 && out_raw && out_act)
       hipLaunchKernelGGL((fir_up_kernel<T, VEC, true, 8, 1, true>), blocks(H, W, 8, 1), dim3(256), 0, st, (const T*)x, affine, (T*)out_raw, (T*)out_act, B, H, W, C);
     else if (blocks(H, W, 8).x >= ENOUGH) FD_FIR_UP(true, 8, 1);

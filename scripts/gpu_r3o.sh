@@ -1,6 +1,6 @@
 #!/bin/bash
-# FIR kernels: parity tests + micro-benchmark
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_hip_ops.py -m gpu -q -k "fir or resblock or upfirdn" < /dev/null 2>&1 | tail -3
-timeout 300 python scripts/fir_bench.py 2>&1 | grep dir
+echo "VEC8 8x1"; timeout 300 python scripts/fir_bench.py 2>&1 | grep "dir +1"
+for v in 3 4; do echo "VEC8 exp=$v"; FD_EXP_UP=$v timeout 300 python scripts/fir_bench.py 2>&1 | grep "dir +1"; done
+for v in 1 2 3 4; do echo "VEC4 exp=$v (1 = 8x1, 2 = 8x2, 3 = 4x1, 4 = 16x1)"; FD_EXP_UP4=1 FD_EXP_UP=$v timeout 300 python scripts/fir_bench.py 2>&1 | grep "dir +1"; done
