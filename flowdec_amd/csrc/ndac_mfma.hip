@@ -46,24 +46,39 @@ __device__ __forceinline__ float snake_fast(float v, float alpha, float inv) {
 
 struct Epi { int b, co0, tpos[2]; bool ok[2]; };   // ([2]: NT <= 2)
 
-// 16 rows of a tile at a time: their 16 residual values are requested together (one latency per batch, not per element)
-template <int MT, int NT, bool RES, bool OUT, bool ACT>
+// 8 rows of a tile at a time; the residual values of the NEXT 8 rows are requested before the current rows are stored.  FULL (every
+// column of the wave's tile is a real output): the stores are unconditional -- loads and stores return in order through one counter
+// (vmcnt), and with control flow between them hipcc has to wait as if no store were in flight, i.e. for all of them (elementwise.hip,
+// fir_raw).
+template <int MT, int NT, bool RES, bool OUT, bool ACT, bool FULL>
 __device__ __forceinline__ void epilogue(const MArgs& a, const Epi& ep, f32x16 (&acc)[MT][NT]) {
+  constexpr int EB = 4;   // rows per batch
+  float rn[EB][NT];
+  auto request = [&](int mt, int eh) {
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+      const size_t rowo = ((size_t)ep.b * a.Co + ep.co0 + 32 * mt + 8 * ((eh + e) >> 2) + (e & 3)) * a.To;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) rn[e][nt] = a.res[rowo + ep.tpos[nt]];
+    }
+  };
+  if (RES) request(0, 0);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int eh = 0; eh < 16; eh += 8) {
-      float rv[8][NT];
+    for (int eh = 0; eh < 16; eh += EB) {
+      float rv[EB][NT];
       if (RES) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const size_t rowo = ((size_t)ep.b * a.Co + ep.co0 + 32 * mt + 8 * ((eh + e) >> 2) + (e & 3)) * a.To;
+        for (int e = 0; e < EB; ++e)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) rv[e][nt] = a.res[rowo + ep.tpos[nt]];
-        }
+          for (int nt = 0; nt < NT; ++nt) rv[e][nt] = rn[e][nt];
+        if (eh + EB < 16) request(mt, eh + EB);
+        else if (mt + 1 < MT) request(mt + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int e = 0; e < EB; ++e) {
         const int co = ep.co0 + 32 * mt + 8 * ((eh + e) >> 2) + (e & 3);
         const float bv = a.bias[co];
         float ao = 0.f, inv = 0.f;
@@ -73,13 +88,26 @@ __device__ __forceinline__ void epilogue(const MArgs& a, const Epi& ep, f32x16 (
         for (int nt = 0; nt < NT; ++nt) {
           float v = acc[mt][nt][eh + e] + bv;
           if (RES) v += rv[e][nt];
-          if (ep.ok[nt]) {
+          if (FULL || ep.ok[nt]) {
             if (OUT) a.out[rowo + ep.tpos[nt]] = v;
             if (ACT) a.out_act[rowo + ep.tpos[nt]] = snake_fast(v, ao, inv);
           }
         }
       }
     }
+}
+
+template <int MT, int NT, bool FULL>
+__device__ __forceinline__ void epilogue_dispatch(const MArgs& a, const Epi& ep, f32x16 (&acc)[MT][NT]) {
+  if (a.res) {
+    if (a.out) epilogue<MT, NT, true, true, true, FULL>(a, ep, acc);
+    else epilogue<MT, NT, true, false, true, FULL>(a, ep, acc);
+  } else if (a.out) {
+    if (a.out_act) epilogue<MT, NT, false, true, true, FULL>(a, ep, acc);
+    else epilogue<MT, NT, false, true, false, FULL>(a, ep, acc);
+  } else {
+    epilogue<MT, NT, false, false, true, FULL>(a, ep, acc);
+  }
 }
 
 // S == 0: stride-1 convolution / transposed convolution (a chunk = 32 input channels of one position).
@@ -231,15 +259,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(MArgs a) {
     ep.ok[nt] = n < a.N && t >= 0 && t < a.To;
     ep.tpos[nt] = ep.ok[nt] ? (int)t : 0;   // (clamped: the residual loads are unconditional, the stores predicated)
   }
-  if (a.res) {
-    if (a.out) epilogue<MT, NT, true, true, true>(a, ep, acc);
-    else epilogue<MT, NT, true, false, true>(a, ep, acc);
-  } else if (a.out) {
-    if (a.out_act) epilogue<MT, NT, false, true, true>(a, ep, acc);
-    else epilogue<MT, NT, false, true, false>(a, ep, acc);
-  } else {
-    epilogue<MT, NT, false, false, true>(a, ep, acc);
-  }
+  // uniform per wave: columns that are all real outputs take the branch-free epilogue
+  bool full = true;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) full = full && ep.ok[nt];
+  if (__builtin_amdgcn_ballot_w64(!full) == 0) epilogue_dispatch<MT, NT, true>(a, ep, acc);
+  else epilogue_dispatch<MT, NT, false>(a, ep, acc);
 }
 
 unsigned short bf16_rne(float f) {
