@@ -845,7 +845,7 @@ static int launch_fir(const void* x, const float* affine, void* out_raw, void* o
     // round 2 (profiles/r02_fir_down_variants.txt): with 4-channel vectors the 4x2 block (6.25 instead of 10 SiLU evaluations per
     // output) fits the register budget: 430 us vs 512 us for 8-channel vectors x 4x1 at the same shape
     if (!affine) FD_FIR_DOWN(false, 1, 1);
-    else if (VEC == 4 && sizeof(T) == 2) {
+    else if (VEC == 4) {
       // round 3: marching strips of NR output rows x 4 columns (1.33 instead of 1.875 activations per input, packed FIR arithmetic)
       auto mgrid = [&](int nr) { return dim3(fd_cdiv((long long)B * fd_cdiv(H / 2, nr) * fd_cdiv(W / 2, 4) * (C / VEC), 256)); };
 #define FD_FIR_MARCH(NR_)                                                                                                                             \
@@ -861,8 +861,9 @@ static int launch_fir(const void* x, const float* affine, void* out_raw, void* o
       if (out_act && mgrid(16).x >= FILL) FD_FIR_MARCH(16);
       else if (out_act && mgrid(8).x >= FILL) FD_FIR_MARCH(8);
       else if (out_act && mgrid(4).x >= FILL) FD_FIR_MARCH(4);
-      else if (dgrid(4, 2).x >= ENOUGH) FD_FIR_DOWN(true, 4, 2);
-      else if (dgrid(2, 1).x >= ENOUGH) FD_FIR_DOWN(true, 2, 1);
+      else if (sizeof(T) == 2 && dgrid(4, 2).x >= ENOUGH) FD_FIR_DOWN(true, 4, 2);
+      else if (sizeof(T) == 2 && dgrid(2, 1).x >= ENOUGH) FD_FIR_DOWN(true, 2, 1);
+      else if (sizeof(T) == 4 && dgrid(4, 1).x >= ENOUGH) FD_FIR_DOWN(true, 4, 1);
       else FD_FIR_DOWN(true, 1, 1);
     } else if (dgrid(4, 1).x >= ENOUGH) FD_FIR_DOWN(true, 4, 1);
     else FD_FIR_DOWN(true, 1, 1);
