@@ -125,6 +125,8 @@ __global__ __launch_bounds__(256) void conv1d_kernel(Conv1dArgs a) {
 // channel the 4 + (K - 1) DIL inputs a group needs are read ONCE as aligned ds_read_b128 (lane stride 16 B: conflict-free) into a
 // register window and all K taps run out of registers -- 13 wide LDS reads per 224 packed-FMA pairs (K = 7, DIL = 1) where the generic
 // kernel above issues one ds_read_b32 per 4 FMAs and is bound by the LDS pipe.  256 outputs x 32 channels per workgroup.
+// (8 channels per thread -- 64 per workgroup, twice the FMAs per weight read -- measured SLOWER: encode 26.7 -> 31.1 ms at 146-166
+// registers, three waves per SIMD instead of five.)
 constexpr int TT1 = 256;
 template <int K, int DIL>
 __global__ __launch_bounds__(256) void conv1d_s1_kernel(Conv1dArgs a) {
