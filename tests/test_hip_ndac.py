@@ -223,3 +223,32 @@ def test_encoder_on_matrix_cores(cfg, hops, batch):
     same = (codes == codes_e).all(dim=1, keepdim=True).expand(-1, z.shape[1], -1)    # frames whose whole code stack agrees: same z_q up to rounding
     if bool(same.any()):
         assert float((z - z_e)[same].abs().max()) <= 1e-4 * float(z_e.abs().max())
+
+
+FULL_WIDTH = dict(encoder_dim=64, encoder_rates=(2, 4, 8, 10), decoder_dim=1536, decoder_rates=(10, 8, 4, 2), n_codebooks=10, codebook_size=1024,
+                  codebook_dim=8, sample_rate=48000)   # DAC's published widths at ndac-75's frame rate: what scripts/ndac_bench.py times
+
+
+def test_codec_full_width_three_frames():
+    """Every layer shape of the full-width codec (1536 ... 96 decoder channels, 64 ... 1024 encoder channels, strides 2 / 4 / 8 / 10 both
+    ways) on three frames: exact encode (code indices = oracle), matrix-core decode and exact decode against the oracle, matrix-core
+    encode against the exact one."""
+    m, o = build(FULL_WIDTH, 5, 0.55)
+    rng = np.random.default_rng(11)
+    x = (0.3 * rng.standard_normal((1, 1, 3 * o.hop_length))).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    z, codes, lat, _, _ = m.encode(xd)
+    z_o, codes_o, lat_o, _, _ = o.encode(x)
+    assert np.array_equal(codes.cpu().numpy(), codes_o)
+    check("ndac_full_encode_latents", lat.cpu().numpy(), lat_o, 2e-5)
+    zq = m.quantizer.from_codes(codes)[0]
+    y_o = o.decode(o.from_codes(codes_o)[0])
+    assert float(np.abs(y_o).max()) < 0.999   # (tanh not saturated: the comparison sees the decoder)
+    check("ndac_full_decode_mfma", m.decode(zq).cpu().numpy(), y_o, TOL_MFMA_DECODE)
+    m.precision = "exact"
+    check("ndac_full_decode_exact", m.decode(zq).cpu().numpy(), y_o, 2e-5)
+    m.precision = "mfma"
+    _, codes_m, lat_m, _, _ = m.encode(xd)
+    cd = FULL_WIDTH["codebook_dim"]
+    check("ndac_full_encode_mfma_latent0", lat_m[:, :cd].cpu().numpy(), lat_o[:, :cd], TOL_MFMA_DECODE)
+    assert float((codes_m != codes).float().mean()) <= 0.1   # 30 indices: at most 3 near-ties
