@@ -243,9 +243,15 @@ def test_fir_resample_block_variants(ops, direction, prec):
     for b in (0, B - 1):
         raw1, act1 = ops.fir_resample(x[b:b + 1].contiguous(), direction, affine=aff[b:b + 1].contiguous())
         assert torch.equal(raw[b], raw1[0]) and torch.equal(act[b], act1[0])
+    # a crop small enough for the one-row / one-pixel kernels: away from the cut edges it must give the big launch's bits (this is the
+    # cross-check of the full-strip variants -- unconditional stores, next row requested early -- against the plain kernels)
     small = x[:1, :24, :16].contiguous()
     raw_s, act_s = ops.fir_resample(small, direction, affine=aff[:1].contiguous())
     assert torch.isfinite(raw_s.float()).all() and torch.isfinite(act_s.float()).all()
+    if direction > 0:
+        assert torch.equal(raw_s[0, :44, :28], raw[0, :44, :28]) and torch.equal(act_s[0, :44, :28], act[0, :44, :28])
+    else:
+        assert torch.equal(raw_s[0, :11, :7], raw[0, :11, :7]) and torch.equal(act_s[0, :11, :7], act[0, :11, :7])
 
 
 @pytest.mark.parametrize("B,H,W", [(9, 488, 264), (9, 512, 256), (8, 384, 128)], ids=["ragged", "full_strips_16", "full_strips_8"])
