@@ -252,3 +252,37 @@ def test_codec_full_width_three_frames():
     cd = FULL_WIDTH["codebook_dim"]
     check("ndac_full_encode_mfma_latent0", lat_m[:, :cd].cpu().numpy(), lat_o[:, :cd], TOL_MFMA_DECODE)
     assert float((codes_m != codes).float().mean()) <= 0.1   # 30 indices: at most 3 near-ties
+
+
+def test_codec_full_size_batch_independence():
+    """BASELINE-sized codec calls (full width, 8 x 2 s) through properties that need no oracle: a clip gives the same bits alone and in
+    the batch (the matrix-core kernels pick 128- or 256-position workgroups by the GRID size, the K order per output is the same), for
+    encode (exact path: codes, latents), from_codes and decode (matrix cores and exact); decode(from_codes(encode(x))) is finite, inside
+    (-1, 1) and as long as the input."""
+    from flowdec_amd.ndac import DAC
+    torch.manual_seed(0)
+    m = DAC(**FULL_WIDTH)
+    for k, p in m.named_parameters():          # keep activations O(1): g = 0.8 ||v||
+        if k.endswith("weight_g"):
+            v = dict(m.named_parameters())[k[:-1] + "v"]
+            p.data = 0.8 * v.data.pow(2).sum(dim=tuple(range(1, v.ndim)), keepdim=True).sqrt()
+    m = m.cuda()
+    x = m.preprocess(0.3 * torch.randn(8, 1, 96000, device="cuda"), 48000)
+    z, codes, lat, _, _ = m.encode(x)
+    zq = m.quantizer.from_codes(codes)[0]
+    y = m.decode(zq)
+    assert y.shape == x.shape and torch.isfinite(y).all() and float(y.abs().max()) <= 1.0
+    for b in (0, 5):
+        z1, c1, l1, _, _ = m.encode(x[b:b + 1])
+        assert torch.equal(c1[0], codes[b]) and torch.equal(l1[0], lat[b]) and torch.equal(z1[0], z[b])
+        assert torch.equal(m.quantizer.from_codes(codes[b:b + 1])[0][0], zq[b])
+        assert torch.equal(m.decode(zq[b:b + 1])[0], y[b])
+    m.precision = "exact"
+    ye = m.decode(zq)
+    assert torch.equal(m.decode(zq[3:4])[0], ye[3])
+    assert float((y - ye).abs().max()) <= TOL_MFMA_DECODE * float(ye.abs().max())
+    m.precision = "mfma"
+    zm, cm, lm, _, _ = m.encode(x)
+    z1, c1, l1, _, _ = m.encode(x[2:3])
+    assert torch.equal(c1[0], cm[2]) and torch.equal(l1[0], lm[2])
+    assert float((cm != codes).float().mean()) <= 0.02
