@@ -337,7 +337,8 @@ struct Fwd {
   bool auto_wino(const Tens& out) const { return fd_cdiv(out.H, 16) * fd_cdiv(out.W, 16) <= 96; }
   // FD_LOW_LATENCY (one short clip on the whole chip; profiles/r02_latency_tiles.txt): images of at most 24 tiles run the direct
   // kernel with 32-channel workgroups and chunk-resident weights (8 x the workgroups, one barrier per chunk); the Winograd kernel
-  // (128-channel workgroups) takes everything else up to 512 tiles unless a 1x1 shortcut is folded in.  By image size only.
+  // (128-channel workgroups) takes everything else up to 512 tiles unless a 1x1 shortcut is folded in; those run the direct kernel with
+  // 128-channel workgroups up to 128 tiles.  By image size only.
   int conv(const Tens& a, const Tens* b, size_t aff, const Tens* s0, const Tens* s1, const void* w, const float* bias, int bias_rows,
            const Tens* skip, float scale, Tens& out, int ks, bool want_stats, bool wino = false, const void* w_wino = nullptr) {
     int tile = 0;
@@ -350,6 +351,9 @@ struct Fwd {
     // (never with a folded 1x1 shortcut: its input is the UN-NORMALISED residual stream, which the Winograd kernel would narrow to
     // the fp16 range; GroupNorm+SiLU outputs and their FIR-resampled versions are bounded)
     else if (w_wino && !s0 && (auto_wino(out) || (latency && px_tiles <= 512))) { w = w_wino; wino = true; }
+    // one clip, folded-shortcut convolutions of the 384 x 64 level (96 tiles): 96 workgroups of 256 channels leave 160 CUs idle; 128-channel
+    // workgroups are 1.28-1.39x per launch there (scripts/ab_conv_b1.py with AB_H=384 AB_W=64), same bits
+    else if (latency && px_tiles <= 128 && out.C >= 256 && out.C % 128 == 0) tile = FD_TILE_BN128;
     if (want_stats) {
       out.tiles = fd_conv_stats_tiles(out.H, out.W);
       out.stride = fd_conv_cout_pad(out.C);

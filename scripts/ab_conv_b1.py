@@ -7,11 +7,11 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scripts"))
 from ab_conv import SHAPES
 from flowdec_amd import ops
 g = torch.Generator(device="cuda").manual_seed(1)
-B = int(os.environ.get("AB_B", "1")); Wd = int(os.environ.get("AB_W", "128"))
+B = int(os.environ.get("AB_B", "1")); Wd = int(os.environ.get("AB_W", "128")); Hd = int(os.environ.get("AB_H", "768"))
 for name, H, W, C0, C1, Cout, k, aff, skip, S in SHAPES:
     if Cout < 128 or not name.startswith("L0"):
         continue
-    W = Wd
+    W = Wd; H = Hd
     Cin = C0 + C1
     x0 = torch.randn(B, H, W, C0, device="cuda", generator=g).bfloat16()
     x1 = torch.randn(B, H, W, C1, device="cuda", generator=g).bfloat16() if C1 else None
@@ -27,7 +27,7 @@ for name, H, W, C0, C1, Cout, k, aff, skip, S in SHAPES:
     pw = ops.pack_conv_weight(w, C0=C0, dtype=torch.bfloat16, w_sc=wsc, S0=min(S, 256) if S else None)
     cells = []
     base = None
-    for tile in (0, 128, "duo", 64):
+    for tile in (0, 128, "duo", 64, "64c", 32):
         try:
             f = lambda: ops.conv2d(x0, pw, Cout, k, x1=x1, affine=affine, bias=bias, skip=skp, scale=0.7071, sc0=sc0, sc1=sc1, want_stats=True, tile_bn=tile)
             for _ in range(3):
