@@ -82,7 +82,8 @@ extern "C" {
 #define FD_TILE_MASK 0xf000
 /* fd_model_config.act_dtype only: low-latency schedule for ONE short clip -- both packings are kept (as with FD_WINOGRAD_AUTO) and
  * every convolution picks kernel and workgroup width by its IMAGE size (never by the batch size): FD_TILE_BN32_CHUNK for images of
- * at most 24 tiles, Winograd up to 512 tiles (unless a 1x1 shortcut is folded in), direct otherwise. */
+ * at most 24 tiles, Winograd up to 512 tiles (unless a 1x1 shortcut is folded in), direct otherwise -- with FD_TILE_BN128 workgroups
+ * for images of at most 128 tiles. */
 #define FD_LOW_LATENCY 0x800
 /* fd_model_config.act_dtype only: keep the side branches of a network evaluation (time embedding, pyramid-head chain) on the caller's
  * stream instead of forking them onto the model's second stream (default: forked; inside a graph capture they become parallel
