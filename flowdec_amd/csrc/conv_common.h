@@ -50,6 +50,14 @@ int fd_wino_launch(fdconv::ConvArgs a, hipStream_t st);
 int fd_wino_init_attributes();
 bool fd_wino_supported(int Cout, int C0, int C1, int S0, int S1, int ksize);
 
+// conv_wino4.hip (Winograd F(4,3) along W, 256-cout workgroups; bf16 storage, whole 16 x 16 tiles)
+long long fd_wino4_packed_bytes(int Cout, int C0, int C1, int S0, int S1);
+int fd_wino4_pack_weights(const float* w, const float* w_sc, void* packed, int Cout, int C0, int C1, int S0, int S1, hipStream_t st);
+int fd_wino4_launch(fdconv::ConvArgs a, hipStream_t st);
+int fd_wino4_init_attributes();
+bool fd_wino4_supported(int Cout, int C0, int C1, int S0, int S1, int ksize);
+bool fd_wino4_shape_ok(int H, int W);
+
 // conv_head.hip (Cout = 4 pyramid heads, bf16)
 bool fd_head_supported(const fdconv::ConvArgs& a, int ksize, int dtype);
 int fd_head_launch(fdconv::ConvArgs a, hipStream_t st);

@@ -1263,6 +1263,7 @@ int fd_conv_init_attributes() {
   FD_TRY((set_attr_re<2, 4, 4, 2>())); FD_TRY((set_attr_re<4, 2, 2, 2>()));
   if (known) FD_HIP(hipDeviceGetAttribute(&g_num_cu[dev], hipDeviceAttributeMultiprocessorCount, dev));
   FD_TRY(fd_wino_init_attributes());
+  FD_TRY(fd_wino4_init_attributes());
   FD_TRY(fd_head_init_attributes());
   if (known) done_dev[dev] = true;
   return FD_OK;
@@ -1276,6 +1277,7 @@ extern "C" int fd_conv_cout_pad(int Cout) { return cout_pad(Cout); }
 extern "C" int fd_conv_stats_tiles(int H, int W) { return fd_cdiv(H, 16) * fd_cdiv(W, 16); }
 
 extern "C" long long fd_conv_packed_bytes(int Cout, int C0, int C1, int ksize, int S0, int S1, int wdtype) {
+  if (wdtype & FD_WINOGRAD4) return fd_wino4_supported(Cout, C0, C1, S0, S1, ksize) && (wdtype & 0xff) == FD_BF16 ? fd_wino4_packed_bytes(Cout, C0, C1, S0, S1) : 0;
   if (wdtype & FD_WINOGRAD) return fd_wino_supported(Cout, C0, C1, S0, S1, ksize) && (wdtype & 0xff) == FD_BF16 ? fd_wino_packed_bytes(Cout, C0, C1, S0, S1) : 0;
   if (wdtype == (FD_F32 | FD_BF16_OPERANDS)) wdtype = FD_BF16;   // weights follow the OPERAND type
   const int CK = wdtype == FD_BF16 ? 32 : 16;                    // (FD_F32 | FD_BF16X3_OPERANDS: 16 channels per step, hi + lo per row)
@@ -1290,6 +1292,11 @@ extern "C" int fd_conv_pack_weights(const float* w, const float* w_sc, void* pac
   FD_REQUIRE(w && packed, "fd_conv_pack_weights: null pointer");
   FD_REQUIRE(ksize == 1 || ksize == 3, "fd_conv_pack_weights: ksize must be 1 or 3");
   FD_REQUIRE((S0 + S1 == 0) == (w_sc == nullptr), "fd_conv_pack_weights: shortcut weight / channel mismatch");
+  if (wdtype & FD_WINOGRAD4) {
+    FD_REQUIRE((wdtype & 0xff) == FD_BF16 && fd_wino4_supported(Cout, C0, C1, S0, S1, ksize),
+               "fd_conv_pack_weights: FD_WINOGRAD4 needs bf16 storage, ksize 3, Cout == 256 and channel counts %% 32 == 0");
+    return fd_wino4_pack_weights(w, w_sc, packed, Cout, C0, C1, S0, S1, fd_stream(stream));
+  }
   if (wdtype & FD_WINOGRAD) {
     FD_REQUIRE((wdtype & 0xff) == FD_BF16 && fd_wino_supported(Cout, C0, C1, S0, S1, ksize),
                "fd_conv_pack_weights: FD_WINOGRAD needs bf16 storage, ksize 3, Cout %% 128 == 0 and channel counts %% 32 == 0");
@@ -1327,7 +1334,8 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
                          float scale, void* out, int Cout, float* stats, int B, int H, int W, int ksize, int dtype, void* stream) {
   FD_REQUIRE(in0 && packed_w && out, "fd_conv2d: null pointer");
   FD_REQUIRE(ksize == 1 || ksize == 3, "fd_conv2d: ksize must be 1 or 3 (got %d)", ksize);
-  const bool wino = (dtype & FD_WINOGRAD) != 0;
+  const bool wino = (dtype & FD_WINOGRAD) != 0, wino4 = (dtype & FD_WINOGRAD4) != 0;
+  FD_REQUIRE(!(wino && wino4), "fd_conv2d: FD_WINOGRAD and FD_WINOGRAD4 exclude each other");
   const bool mixed = (dtype & FD_BF16_OPERANDS) != 0, split = (dtype & FD_BF16X3_OPERANDS) != 0;
   FD_REQUIRE(!(mixed || split) || dtype == (FD_F32 | FD_BF16_OPERANDS) || dtype == (FD_F32 | FD_BF16X3_OPERANDS),
              "fd_conv2d: FD_BF16_OPERANDS / FD_BF16X3_OPERANDS go with FD_F32 storage and the default direct configuration only");
@@ -1335,6 +1343,8 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   const int bn_hint = tile == FD_TILE_DUO128 ? -128 : (tile == FD_TILE_BN32 || tile == FD_TILE_BN32_CHUNK) ? 32 : (tile == FD_TILE_BN64 || tile == FD_TILE_BN64_CHUNK) ? 64 : tile == FD_TILE_BN128 ? 128 : 0;
   FD_REQUIRE(tile == 0 || bn_hint != 0 || tile == FD_TILE_PERSIST, "fd_conv2d: bad FD_TILE_* flag");
   dtype &= 0xff;
+  FD_REQUIRE(!wino4 || (dtype == FD_BF16 && fd_wino4_supported(Cout, C0, C1, S0, S1, ksize) && fd_wino4_shape_ok(H, W)),
+             "fd_conv2d: FD_WINOGRAD4 needs bf16 storage, ksize 3, Cout == 256, channel counts %% 32 == 0, H %% 16 == W %% 16 == 0");
   FD_REQUIRE(!wino || (dtype == FD_BF16 && fd_wino_supported(Cout, C0, C1, S0, S1, ksize)),
              "fd_conv2d: FD_WINOGRAD needs bf16 storage, ksize 3, Cout %% 128 == 0 and channel counts %% 32 == 0");
   FD_REQUIRE(dtype == FD_BF16 || dtype == FD_F32, "fd_conv2d: dtype must be FD_BF16 (bf16 MFMA) or FD_F32 (f32 MFMA)");
@@ -1359,7 +1369,7 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   if (S1) a.seg[ns++] = Seg{sc1, S1, -1, 1};
   a.nseg = ns;
   a.affine = affine; a.affC = C0 + C1;
-  a.w = packed_w; a.w_bytes = fd_conv_packed_bytes(Cout, C0, C1, ksize, S0, S1, dtype | (wino ? FD_WINOGRAD : 0) | (mixed ? FD_BF16_OPERANDS : 0) | (split ? FD_BF16X3_OPERANDS : 0));
+  a.w = packed_w; a.w_bytes = fd_conv_packed_bytes(Cout, C0, C1, ksize, S0, S1, dtype | (wino ? FD_WINOGRAD : 0) | (wino4 ? FD_WINOGRAD4 : 0) | (mixed ? FD_BF16_OPERANDS : 0) | (split ? FD_BF16X3_OPERANDS : 0));
   a.bias = bias; a.bias_rows = bias_rows; a.skip = skip; a.scale = scale; a.out = out; a.Cout = Cout; a.CoutPad = cout_pad(Cout);
   a.stats = stats; a.B = B; a.H = H; a.W = W;
 #ifdef FD_TIMING2
@@ -1367,6 +1377,7 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
 #endif
   FD_REQUIRE(a.w_bytes < (1ll << 31), "fd_conv2d: packed weights exceed 2 GiB");
   FD_REQUIRE(affine == nullptr || (C0 + C1) * 8 <= AFF_BYTES, "fd_conv2d: at most %d activated input channels", AFF_BYTES / 8);
+  if (wino4) return fd_wino4_launch(a, fd_stream(stream));
   if (wino) return fd_wino_launch(a, fd_stream(stream));
   if (mixed) return dispatch_conv_mixed(a, fd_stream(stream));
   if (split) return dispatch_conv_split(a, fd_stream(stream));

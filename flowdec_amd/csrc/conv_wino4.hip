@@ -1,0 +1,616 @@
+// conv_wino4.hip -- 3x3 convolution as Winograd F(4,3) along W (time frames) x direct along H on the gfx950 matrix cores.
+//
+// Same contract as conv_mfma.hip (ddpm_conv3x3, flowdec/backbones/ncsnpp_utils/layers.py:128-134, with the ResnetBlockBigGANpp
+// surroundings of layerspp.py:252-284 fused in: GroupNorm+SiLU operand transform, time/conv bias, residual, 1/sqrt(2), statistics
+// of the output for the next GroupNorm, virtual channel concat) -- with HALF the MFMAs of the direct kernel: for four outputs
+// y0..y3 = pixels 4j..4j+3 of a row and the six inputs d0..d5 = pixels 4j-1..4j+4
+//   V = B^T d,  U = G g (one kernel row g),  M_xi = U_xi V_xi (6 products instead of 12),  y = A^T M
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// summed over the three kernel rows dy and all input channels in the accumulators of position xi = 0..5.
+//
+// Design (round 4; what the round-2 F(2,3) kernel conv_wino.hip got wrong is in DESIGN.md section 4):
+//   * one workgroup = 16 x 16 output pixels (64 Winograd tiles of 1 x 4) x ALL 256 output channels: the input is activated once
+//     per pixel tile, as in the direct kernel (the F(2,3) kernel's 128-channel workgroups activated everything twice);
+//   * the input transform happens ONCE per workgroup and chunk, when the activated halo is stored: halo -> silu(a x + d) -> fp16 ->
+//     LDS (z) -> packed-fp16 transform (12 v_pk ops per 2 channels x 6 planes) -> LDS (V planes).  The K loop then reads plain
+//     fragments: no VALU work per fragment (the F(2,3) kernel transformed at fragment-read time, in every wave, for every cout tile);
+//   * 6 x 256 x 64 accumulators = 96 K registers = 192 per lane of the 8 waves: wave (cq, xt) owns positions xi = 0, 1, 2 (xt = 0) or 5, 3, 4 (xt = 1)
+//     for couts {ct * 128 + cq * 32 + 0..31, ct = 0, 1} and all 64 tiles: 3 x (2 x 2) MFMA tiles of 32 x 32 (v_mfma_f32_32x32x16_f16),
+//     one operand read per MFMA;
+//   * K walks 16-channel chunks; per chunk a wave runs the 9 steps (xi, dy), 4 MFMAs each.  A step needs a 2-KiB weight piece that
+//     only THIS wave reads: every wave streams its own pieces through a private ring of 6 LDS slots by direct-to-LDS DMA -- no
+//     barrier for the weights at all, counted s_waitcnt vmcnt for this wave's own traffic (the halo loads are inline asm too, so
+//     that every vector-memory operation of the loop is counted by hand);
+//   * two barriers per chunk (z complete / V planes complete), both in the middle of a step with the fragments pipelined across;
+//   * epilogue: partial output transforms in registers (xt = 0: M0+M1+M2, M1-M2, M1+M2; xt = 1: M3+M4, 2(M3-M4), 4(M3+M4),
+//     8(M3-M4)+M5), the two waves of a cout block swap two planes each through LDS, then the direct kernel's staged sweep
+//     (bias / residual / scale / statistics / bf16 store with 16 bytes per lane).
+// Operands are fp16 (3 more mantissa bits than bf16 and packed add / fma for the transform); storage stays bf16, accumulation f32.
+// Error of a 256-channel convolution against f64: 1.0e-3 (direct bf16 kernel: 2.4e-3; both below the bf16 output rounding).
+#include <type_traits>
+
+#include "conv_common.h"
+
+namespace {
+
+using namespace fdconv;
+
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// ---- geometry -------------------------------------------------------------------------------------------------------------
+constexpr int NTH = 512, TH = 16, TW = 16, HH = TH + 2, HW = TW + 2, BN = 256;
+constexpr int CK = 16;                              // channels per K chunk (one 32-byte LDS row: two 16-byte halves)
+constexpr int SLAB = BN * 32;                       // 8 KiB: the weights of one (chunk, xi, dy) step, [256 couts][16 ch] fp16
+constexpr int RSLOT = 2048, NRING = 6;              // per-wave ring: 6 slots of 64 couts x 32 B
+constexpr int RING_BYTES = 8 * NRING * RSLOT;       // 96 KiB
+constexpr int VXI = HH * 4 * 32;                    // one position plane: [18 halo rows][4 tiles][32 B]
+constexpr int V_BYTES = 6 * VXI;                    // 13824
+constexpr int V_OFF = RING_BYTES;
+constexpr int Z_OFF = V_OFF + 2 * V_BYTES;
+constexpr int Z_BYTES = HH * HW * 32;               // activated halo, [18][18][32 B]
+constexpr int RAW_OFF = Z_OFF + Z_BYTES;            // raw halo (bf16) as the DMA delivers it: slot s at s * 16, padded to 1024 slots
+constexpr int RAW_BYTES = 2 * NTH * 16;
+constexpr int AFF_OFF = RAW_OFF + RAW_BYTES;
+constexpr int MAIN_BYTES = AFF_OFF + AFF_BYTES;     // 156800
+// epilogue: exchange buffer [wave][plane][4][64 lanes x 16 B] = the staging of one round (128 pixels x 128 couts f32, padded rows)
+// in the same bytes (a barrier apart), two residual buffers (one round each: 4 passes x 512 threads x 16 B), bias, statistics
+constexpr int S_PITCH = 128 * 4 + 16;
+constexpr int S_BYTES = 128 * S_PITCH;              // 67584 >= 8 x 8192
+constexpr int SK_OFF = S_BYTES, SK_BYTES = 4 * NTH * 16;
+constexpr int BIAS_OFF = SK_OFF + 2 * SK_BYTES;     // [256] f32
+constexpr int STAT_OFF = BIAS_OFF + 1024;           // [2][8 waves][16 octets][16] f32 = 16 KiB
+constexpr int LDS_BYTES = cmax(MAIN_BYTES, STAT_OFF + 16384);
+constexpr int NSLOT = HH * HW * 2;                  // 648 halo slots of 16 B (8 channels) per chunk
+static_assert(LDS_BYTES <= 160 * 1024 && NSLOT <= 2 * NTH, "LDS layout");
+constexpr float RAW_MAX = 6000.f;                   // raw (not activated) inputs saturate here: |V| <= 10 |z| stays finite in fp16
+
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {
+  f16x2 r = {(f16)a, (f16)b};
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ f16x2 h2(unsigned u) { return __builtin_bit_cast(f16x2, u); }
+__device__ __forceinline__ unsigned u2(f16x2 v) { return __builtin_bit_cast(unsigned, v); }
+
+// LDS-DMA of 64 x 16 B (one 1-KiB piece), inline asm: not counted by hipcc (cdna_hip_programming.md 5.7: M0 written in the same
+// statement that reads it); every wait for it is an explicit counted s_waitcnt vmcnt(N) below.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// the same from a wave-uniform base + a 32-bit byte offset per lane
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+template <bool ACT, bool SKIP>
+__global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const afftab = smem + AFF_OFF;
+#ifdef FD_TIMING2
+  const unsigned long long t2_entry = __builtin_amdgcn_s_memtime();
+#endif
+
+  // ---- tile decode with XCD-aware remap (as conv_mfma.hip) ------------------------------------------------------------
+  const int bid = blockIdx.x, nblk = gridDim.x;
+  int lid;
+  {
+    const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
+    lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  }
+  int pt = lid;
+  const int tw_i = pt % p.tiles_w; pt /= p.tiles_w;
+  const int th_i = pt % p.tiles_h;
+  const int b = pt / p.tiles_h;
+  const int h0 = th_i * TH, w0 = tw_i * TW;
+  const int H = p.H, W = p.W;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int cq = wave & 3, xt = wave >> 2;
+
+  // ---- halo loader: slot s = t and s = t + 512 of the 648 (pixel, 8-channel half) slots.  The raw bf16 slots go straight to LDS
+  // by DMA (RAW buffer, slot s at s * 16: a wave's 64 lanes write 1 KiB; the slots 648..1023 are padding that is never read); the
+  // thread that requested a slot later reads it back, activates it and stores it as fp16 into z -- no registers are held while the
+  // load is in flight, and nobody but the requesting thread touches a RAW slot (no barrier between the DMA and the read).
+  // Register budget: 192 accumulators + 24 fragment registers leave ~40 for everything else, so whatever is needed once per chunk
+  // (slot coordinates, transform addresses) is recomputed from the thread index where it is used (`opaque`: not hoisted). ----------
+  auto opaque = [&](int v) { asm volatile("" : "+v"(v)); return v; };
+  const size_t img_elems = (size_t)H * W;
+  // state of the chunk whose halo is in flight / being converted (wave-uniform)
+  const bf16* nbase = reinterpret_cast<const bf16*>(p.seg[0].src);
+  int nC2 = 0, ncb = 0, naffb = 0;   // bytes per pixel, byte offset of the chunk's first channel, byte offset of its first (a, d) pair
+  int cs = 0, cch = -1;
+  bool cur_end = false;
+  auto next_chunk = [&]() {
+    if (!cur_end) {
+      ++cch;
+      if (cch >= p.seg[cs].C / CK) { ++cs; cch = 0; }
+      if (cs >= p.nseg) cur_end = true;
+    }
+    if (cur_end) return;
+    const Seg sg = p.seg[cs];
+    nbase = reinterpret_cast<const bf16*>(sg.src) + (size_t)b * img_elems * sg.C;
+    nC2 = sg.C * 2;
+    ncb = cch * CK * 2;
+    naffb = sg.aff_off >= 0 ? (sg.aff_off + cch * CK) * 8 : 0;
+  };
+  // halo slot s (0 .. NSLOT - 1): pixel offset (clamped to pixel 0 outside the image) and validity
+  auto slot_pixel = [&](int s, bool& ok) {
+    const int hp = s >> 1;
+    const int hr = (hp * 3641) >> 16;   // hp / 18 for hp < 324
+    const int hc = hp - hr * HW;
+    const int gh = h0 - 1 + hr, gw = w0 - 1 + hc;
+    ok = gh >= 0 && gh < H && gw >= 0 && gw < W;
+    return ok ? gh * W + gw : 0;
+  };
+  // thread tt's i-th slot; threads without a second slot redo their first one (same load, same bytes to the same LDS address)
+  auto slot_of = [&](int tt, int i) { return tt + i * NTH < NSLOT ? tt + i * NTH : tt; };
+  // past the end of the K loop every lane re-reads element 0 of the last tensor (one cache line; the data is never used)
+  const unsigned rawdst = (unsigned)(RAW_OFF + wave * 1024);
+  auto load_halo = [&]() {
+    const int tt = opaque(t);
+    const int on = cur_end ? 0 : 1;
+    const int hq16 = (tt & 1) * 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      bool ok;
+      const int px = slot_pixel(slot_of(tt, i), ok);
+      glds16s(nbase, (unsigned)((px * nC2 + ncb + hq16) * on), rawdst + i * NTH * 16);
+    }
+  };
+  // one slot: RAW (bf16) -> [silu(a x + d)] -> fp16 -> z, zero padding AFTER the activation (an AND: no branch)
+  auto conv_slot = [&](int i) {
+    const int tt = opaque(t);
+    bool ok;
+    (void)slot_pixel(slot_of(tt, i), ok);
+    const int sadr = slot_of(tt, i) * 16;
+    u32x4 raw = *reinterpret_cast<const u32x4*>(smem + RAW_OFF + sadr);
+    const unsigned vm = ok ? 0xffffffffu : 0u;
+    const char* const ad = afftab + naffb + (tt & 1) * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned u = raw[j];
+      const float x0 = __builtin_bit_cast(float, u << 16), x1 = __builtin_bit_cast(float, u & 0xffff0000u);
+      unsigned r;
+      if constexpr (ACT) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ad + 16 * j);
+        r = pack_f16(fd_silu(fmaf(x0, a[0], a[1])), fd_silu(fmaf(x1, a[2], a[3])));
+      } else {   // raw input (activated / resampled upstream): saturate so that the transform cannot overflow to inf
+        r = pack_f16(__builtin_amdgcn_fmed3f(x0, -RAW_MAX, RAW_MAX), __builtin_amdgcn_fmed3f(x1, -RAW_MAX, RAW_MAX));
+      }
+      raw[j] = r & vm;
+    }
+    *reinterpret_cast<u32x4*>(smem + Z_OFF + sadr) = raw;
+  };
+
+  // ---- input transform z -> V planes: item (halo row, tile, 4-channel group) = threads 0..287, two channels per pass ------------
+  auto transform = [&](int vbuf) {
+    const int tt = opaque(t);
+    const int tg = tt & 3, twt = (tt >> 2) & 3, thr = tt >> 4;
+    const char* const zp = smem + Z_OFF + (thr * HW + 4 * twt) * 32 + tg * 8;
+    const int tidx = thr * 4 + twt;
+    char* const vb = smem + V_OFF + vbuf * V_BYTES + tidx * 32 + (((tg >> 1) ^ ((tidx >> 3) & 1)) * 16) + (tg & 1) * 8;
+    const f16x2 c4 = {(f16)4.f, (f16)4.f}, cm4 = {(f16)-4.f, (f16)-4.f}, cm5 = {(f16)-5.f, (f16)-5.f}, c2 = {(f16)2.f, (f16)2.f},
+                cm2 = {(f16)-2.f, (f16)-2.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {   // 6 words in, 6 words out
+      unsigned w_[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) w_[j] = *reinterpret_cast<const unsigned*>(zp + j * 32 + k * 4);
+      const f16x2 z0 = h2(w_[0]), z1 = h2(w_[1]), z2 = h2(w_[2]), z3 = h2(w_[3]), z4 = h2(w_[4]), z5 = h2(w_[5]);
+      const f16x2 t1 = __builtin_elementwise_fma(z2, cm4, z4);   // z4 - 4 z2
+      const f16x2 t2 = __builtin_elementwise_fma(z1, cm4, z3);   // z3 - 4 z1
+      const f16x2 t3 = z4 - z2, t4 = z3 - z1;
+      *reinterpret_cast<unsigned*>(vb + 0 * VXI + k * 4) =  /* xi = 0 */ u2(__builtin_elementwise_fma(z0, c4, __builtin_elementwise_fma(z2, cm5, z4)));
+      *reinterpret_cast<unsigned*>(vb + 1 * VXI + k * 4) =  /* xi = 1 */ u2(t1 + t2);
+      *reinterpret_cast<unsigned*>(vb + 2 * VXI + k * 4) =  /* xi = 2 */ u2(t1 - t2);
+      *reinterpret_cast<unsigned*>(vb + 4 * VXI + k * 4) =  /* xi = 3 */ u2(__builtin_elementwise_fma(t4, c2, t3));
+      *reinterpret_cast<unsigned*>(vb + 5 * VXI + k * 4) =  /* xi = 4 */ u2(__builtin_elementwise_fma(t4, cm2, t3));
+      *reinterpret_cast<unsigned*>(vb + 3 * VXI + k * 4) =  /* xi = 5 */ u2(__builtin_elementwise_fma(z1, c4, __builtin_elementwise_fma(z3, cm5, z5)));
+    }
+  };
+
+  // ---- weight stream: this wave's two 1-KiB pieces (cout blocks ct = 0, 1) of its step f -> ring slot f % 6 -------------------
+  // packed layout: [chunk][xt][xi][dy][256 couts][32 B]; the wave's 9 steps of a chunk are 9 consecutive slabs
+  const char* wsrc = reinterpret_cast<const char*>(p.w) + (size_t)xt * 9 * SLAB + cq * 1024;
+  asm volatile("" : "+s"(wsrc));
+  const unsigned lane16 = (unsigned)(lane * 16);
+  const unsigned wring = (unsigned)(wave * NRING * RSLOT);
+  int n3 = 0;
+  for (int s = 0; s < p.nseg; ++s) n3 += p.seg[s].C / CK;
+  int fleft = n3 * 9;          // steps of this wave still to fetch
+  int fsub = 0;                // index of the next one inside its chunk
+  auto dma_next = [&](int slot) {
+    const char* src = fleft > 0 ? wsrc : reinterpret_cast<const char*>(p.w);   // past the end: a harmless re-read
+    glds16s(src, lane16, wring + slot * RSLOT);
+    glds16s(src + 4096, lane16, wring + slot * RSLOT + 1024);
+    --fleft;
+    wsrc += SLAB;
+    if (++fsub == 9) { fsub = 0; wsrc += 9 * SLAB; }
+    asm volatile("" : "+s"(wsrc));
+  };
+
+  // ---- per-lane fragment coordinates --------------------------------------------------------------------------------------
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wa_lane = (int)wring + l31 * 32 + ((lh ^ ((l31 >> 3) & 1)) * 16);   // A: row l31 of the slot, cout block ct at + 1024
+  int vb_lane[3];                                                             // B: tile l31 (+ 32 at + 1024), halo row shift dy
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int idx = l31 + 4 * dy;
+    vb_lane[dy] = V_OFF + xt * 3 * VXI + idx * 32   /* plane slots 0 1 2 | 5 3 4 */ + ((lh ^ ((idx >> 3) & 1)) * 16);
+  }
+
+  f32x16 acc[3][2][2];
+#pragma unroll
+  for (int x = 0; x < 3; ++x)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[x][ct][nt][e] = 0.f;
+
+  auto lds_wait = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+  auto barrier = [&]() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  // Fragments: three quads per operand.  Step k multiplies A0 = qa[2k % 3], A1 = qa[(2k + 1) % 3] with B0 = qb[2k % 3], B1 = qb[(2k + 1) % 3]
+  // in the order (A0,B0) (A0,B1) (A1,B0) (A1,B1); the spare quads (2k + 2) % 3 receive A0 / B0 of step k + 1 at the start of step k,
+  // A1 of step k + 1 goes into A0's quad after the second MFMA, B1 of step k + 1 into B0's quad after the third (so the roles turn as
+  // (A0, A1, spare) -> (spare, A0, A1)): every fragment is requested two to four MFMAs before its first use with 24 registers.
+  u32x4 qa[3], qb[3];
+  auto mma = [&](int xl, int ct, int nt, const u32x4& a, const u32x4& bq) {
+    acc[xl][ct][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bq), acc[xl][ct][nt], 0, 0, 0);
+  };
+  auto rd = [&](int off) { return *reinterpret_cast<const u32x4*>(smem + off); };
+  // LDS offsets of the fragments of step k18 (0..17 inside the chunk pair; 18 = step 0 of the next pair)
+  auto a_off = [&](int k18, int ct) { return wa_lane + (k18 % NRING) * RSLOT + ct * 1024; };
+  auto b_off = [&](int k18, int nt) {
+    const int s = k18 % 9, half = (k18 / 9) & 1;
+    return vb_lane[s % 3] + half * V_BYTES + (s / 3) * VXI + nt * 1024;
+  };
+
+  // ---- prologue: first halo, the first six weight steps and the affine table in one memory round trip --------------------------
+  next_chunk();
+  load_halo();
+#pragma unroll
+  for (int k = 0; k < NRING; ++k) dma_next(k);
+  if (ACT) {
+    const float* ap = p.affine + (size_t)b * p.affC * 2;
+    for (int i = t; i < p.affC / 2; i += NTH) *reinterpret_cast<f32x4*>(afftab + i * 16) = *reinterpret_cast<const f32x4*>(ap + i * 4);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();          // affine table published; this wave's RAW slots and weight pieces have landed
+  conv_slot(0);
+  conv_slot(1);
+  next_chunk();
+  lds_wait();
+  load_halo();              // halo of chunk 1 (converted during chunk 0): this thread's RAW slots are free again
+  barrier();
+  if (t < 288) transform(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  lds_wait();
+  barrier();
+#ifdef FD_TIMING2
+  const unsigned long long t2_first = __builtin_amdgcn_s_memtime();
+#endif
+  qa[0] = rd(a_off(0, 0)); qb[0] = rd(b_off(0, 0)); qb[1] = rd(b_off(0, 1)); qa[1] = rd(a_off(0, 1));
+
+  // ---- K loop.  Chunk c multiplies V[c & 1]; meanwhile the halo of chunk c + 1 (in RAW since chunk c - 1) is activated and stored
+  // (steps 1, 2), transformed into V[(c + 1) & 1] (step 4), and the halo of chunk c + 2 is requested (step 3).  A step starts with a
+  // counted wait for the weights of the NEXT step (its first fragments are requested right away); in flight on this wave's
+  // vector-memory counter at that wait, oldest first: the weight pieces of steps s + 1 .. s + 5 (2 each) and, in steps 4..8, the two
+  // halo pieces issued in step 3 behind the weights of step 9: vmcnt(8 / 10).  The halo pieces are older than everything the wait of
+  // the next chunk's step 0 leaves in flight.  The weights of step s + 6 are requested after the third MFMA of step s: by then both
+  // weight fragments of step s have arrived and its ring slot is free.
+  // Two chunks per iteration: 18 steps = three turns of the ring = six turns of the fragment quads, and the V buffers swap back, so
+  // that every LDS offset is an immediate and the loop has ONE set of MFMA sites (two bodies in one loop double the accumulators).
+  for (int c = 0; c < n3; c += 2) {
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+      const int s = k % 9, half = k / 9;
+      const int vn = half ^ 1;
+      const int xl = s / 3;
+      u32x4 &A0 = qa[(2 * k) % 3], &A1 = qa[(2 * k + 1) % 3], &A2 = qa[(2 * k + 2) % 3];
+      u32x4 &B0 = qb[(2 * k) % 3], &B1 = qb[(2 * k + 1) % 3], &B2 = qb[(2 * k + 2) % 3];
+      if (s <= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      if (s == 3 || s == 8) { lds_wait(); barrier(); }   // s == 3: z complete;  s == 8: V[vn] complete, every wave has its last V[vc] fragments
+      A2 = rd(a_off(k + 1, 0));
+      B2 = rd(b_off(k + 1, 0));
+      __builtin_amdgcn_sched_barrier(0);
+      mma(xl, 0, 0, A0, B0);
+      mma(xl, 0, 1, A0, B1);
+      __builtin_amdgcn_sched_barrier(0);
+      A0 = rd(a_off(k + 1, 1));
+      mma(xl, 1, 0, A1, B0);
+      __builtin_amdgcn_sched_barrier(0);
+      B0 = rd(b_off(k + 1, 1));
+      dma_next(k % NRING);                         // step s + 6 into the slot whose fragments have both arrived
+      if (s == 3) { next_chunk(); load_halo(); }
+      mma(xl, 1, 1, A1, B1);
+      __builtin_amdgcn_sched_barrier(0);
+      // the chunk's vector work, while the quads A1 / B1 are dead
+      if (s == 1) conv_slot(0);
+      if (s == 2) conv_slot(1);
+      if (s == 4) { if (t < 288) transform(vn); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // all fragment reads / DMA done before the epilogue reuses the LDS
+#ifdef FD_TIMING2
+  const unsigned long long t2_loop = __builtin_amdgcn_s_memtime();
+#endif
+
+  // ---- epilogue -------------------------------------------------------------------------------------------------------
+  // Lane (l31, lh) of wave (cq, xt) holds, for cout block ct and tile block nt, acc[x][ct][nt][e]: cout ct * 128 + cq * 32 + 8 (e >> 2)
+  // + 4 lh + (e & 3) of tile nt * 32 + l31 (row nt * 8 + (l31 >> 2), pixels 4 (l31 & 3) .. + 3), position 3 xt + x.
+  //   xt = 0:  a0 = M0 + M1 + M2   a1 = M1 - M2   a2 = M1 + M2          y0 = a0 + b0   y1 = a1 + b1
+  //   xt = 1:  b0 = M3 + M4   b1 = 2 (M3 - M4)   b2 = 4 (M3 + M4)   b3 = 8 (M3 - M4) + M5     y2 = a2 + b2   y3 = a1 + b3
+  // xt = 0 finishes y0, y1 (receives b0, b1), xt = 1 finishes y2, y3 (receives a2, a1).  Four rounds (ct, nt): swap through LDS,
+  // stage the round's 128 pixels x 128 couts as [pixel plane j][tile][cout] f32, sweep with 8 couts (16 B of bf16) per lane.
+  bf16* const out = reinterpret_cast<bf16*>(p.out) + (size_t)b * img_elems * p.Cout;
+  const bf16* const skip = SKIP ? reinterpret_cast<const bf16*>(p.skip) + (size_t)b * img_elems * p.Cout : nullptr;
+  float* const biast = reinterpret_cast<float*>(smem + BIAS_OFF);      // [256] f32 (zeros without a bias)
+  float* const statt = reinterpret_cast<float*>(smem + STAT_OFF);      // [ct][wave][oct 16][16] f32 partial sums
+  if (t < BN) biast[t] = p.bias ? p.bias[(size_t)(p.bias_rows > 1 ? b : 0) * p.Cout + t] : 0.f;
+  // element offset of pass ps of round (ct, nt) for this thread: staged pixel pp + 32 ps = plane ps of tile pp, cout octet oct
+  auto out_off = [&](int tt, int ct, int nt, int ps) {
+    const int oct = tt & 15, pp = tt >> 4;
+    const int gh = h0 + nt * 8 + (pp >> 2), gw = w0 + 4 * (pp & 3) + ps;
+    return (gh * W + gw) * p.Cout + ct * 128 + oct * 8;
+  };
+  // residual of round r -> SK[r & 1] by DMA: thread t requests exactly the 16 bytes it adds in the sweep (pass ps at (ps * 512 + t) * 16),
+  // so the only synchronisation is this wave's own counted vmcnt
+  auto skip_dma = [&](int r) {
+    if constexpr (SKIP) {
+      const int tt = opaque(t);
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps)
+        glds16s(skip, (unsigned)(out_off(tt, r >> 1, r & 1, ps) * 2), (unsigned)(SK_OFF + (r & 1) * SK_BYTES + ps * NTH * 16 + wave * 1024));
+    }
+  };
+  skip_dma(0);
+  const float ka = xt ? 0.f : 1.f, ks = xt ? 4.f : 1.f, kb = xt ? 1.f : 0.f, kd = xt ? 8.f : 1.f, kq = xt ? 0.25f : 1.f;
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int rd_ = 0; rd_ < 4; ++rd_) {
+    const int ct = rd_ >> 1, nt = rd_ & 1;
+    f32x16 &m0 = acc[0][ct][nt], &m1 = acc[1][ct][nt], &m2 = acc[2][ct][nt];
+    if (nt == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ssum[j] = ssq[j] = 0.f;
+    }
+    if (rd_ < 3) skip_dma(rd_ + 1);
+    // (a) partial output transform in place, (b) send two planes, (c) receive two planes and finish in place (ya -> m0, yb -> m1).
+    // Both wave groups run the same code with wave-uniform coefficients (a branch here costs two spilled accumulator tiles):
+    //   s = m1 + m2, d = m1 - m2;   send0 = s, send1 = ke d;   ya = ka m0 + ks s + recv0,  yb = kb m0 + kd d + recv1
+    //   xt = 0 (m = M0, M1, M2): sends a2 = s, a1 = d;   y0 = M0 + s + b0,  y1 = d + b1             (ka ks kb kd ke = 1 1 0 1 1)
+    //   xt = 1 (m = M5, M3, M4): sends b0 = s, b1 = 2 d;  y2 = 4 s + a2,     y3 = M5 + 8 d + a1      (ka ks kb kd ke = 0 4 1 8 2)
+    {
+      char* const xmine = smem + wave * 8192 + lane * 16;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float s_ = m1[e] + m2[e], d_ = m1[e] - m2[e];
+        m2[e] = s_;
+        m1[e] = kd * d_;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<f32x4*>(xmine + g * 1024) = f32x4{m2[4 * g], m2[4 * g + 1], m2[4 * g + 2], m2[4 * g + 3]};
+        *reinterpret_cast<f32x4*>(xmine + 4096 + g * 1024) = f32x4{kq * m1[4 * g], kq * m1[4 * g + 1], kq * m1[4 * g + 2], kq * m1[4 * g + 3]};   // ke d = (ke / kd) kd d
+      }
+    }
+    lds_wait();
+    barrier();
+    {
+      const char* const xpeer = smem + (wave ^ 4) * 8192 + lane * 16;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(xpeer + g * 1024), r1 = *reinterpret_cast<const f32x4*>(xpeer + 4096 + g * 1024);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = 4 * g + k;
+          const float mm = m0[e];
+          m0[e] = fmaf(ka, mm, fmaf(ks, m2[e], r0[k]));
+          m1[e] = fmaf(kb, mm, m1[e] + r1[k]);
+        }
+      }
+    }
+    lds_wait();
+    barrier();   // every wave has read its peer's planes: the exchange buffer becomes the staging buffer
+    {
+      char* const sbase = smem + ((2 * xt) * 32 + l31) * S_PITCH + (cq * 32 + 4 * lh) * 4;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<f32x4*>(sbase + g * 32) = f32x4{m0[4 * g], m0[4 * g + 1], m0[4 * g + 2], m0[4 * g + 3]};
+        *reinterpret_cast<f32x4*>(sbase + 32 * S_PITCH + g * 32) = f32x4{m1[4 * g], m1[4 * g + 1], m1[4 * g + 2], m1[4 * g + 3]};
+      }
+    }
+    lds_wait();
+    barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // sweep in two batches of two passes: computed into registers first, stores back to back afterwards.  The residual of this round
+    // is in SK[rd_ & 1]: older than the stores of the previous round and the DMA of the next one (8 operations may stay in flight).
+    if constexpr (SKIP) {
+      if (rd_ == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (rd_ < 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    {
+      const int tt = opaque(t);
+      const int oct = tt & 15, pp = tt >> 4;
+      const f32x4 bA = *reinterpret_cast<const f32x4*>(biast + ct * 128 + oct * 8), bB = *reinterpret_cast<const f32x4*>(biast + ct * 128 + oct * 8 + 4);
+      const float bv[8] = {bA[0], bA[1], bA[2], bA[3], bB[0], bB[1], bB[2], bB[3]};
+#pragma unroll
+      for (int bt = 0; bt < 2; ++bt) {
+        u32x4 packed[2];
+        int ooff[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int ps = 2 * bt + q;
+          ooff[q] = out_off(tt, ct, nt, ps);
+          const float* sp = reinterpret_cast<const float*>(smem + (pp + ps * 32) * S_PITCH) + oct * 8;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          if constexpr (SKIP) {
+            const u32x4 skr = *reinterpret_cast<const u32x4*>(smem + SK_OFF + (rd_ & 1) * SK_BYTES + (ps * NTH + tt) * 16);
+            const bf16x8 sk = __builtin_bit_cast(bf16x8, skr);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)sk[j];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+#pragma clang fp contract(off)
+            f32x2 x = {v[2 * k], v[2 * k + 1]};
+            const f32x2 b2 = {bv[2 * k], bv[2 * k + 1]}, sc2 = {p.scale, p.scale};
+            f32x2 s1 = {ssum[2 * k], ssum[2 * k + 1]}, s2 = {ssq[2 * k], ssq[2 * k + 1]};
+            x = (x + b2) * sc2;
+            s1 += x;
+            s2 = __builtin_elementwise_fma(x, x, s2);
+            v[2 * k] = x[0]; v[2 * k + 1] = x[1];
+            ssum[2 * k] = s1[0]; ssum[2 * k + 1] = s1[1];
+            ssq[2 * k] = s2[0]; ssq[2 * k + 1] = s2[1];
+          }
+          bf16x8 tv;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) tv[j] = (bf16)v[j];
+          packed[q] = __builtin_bit_cast(u32x4, tv);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x4*>(out + ooff[q]) = packed[q];
+      }
+    }
+    if (nt == 1 && p.stats) {
+      // channel sums of this cout half over the tile: fold the four 16-lane rows of the wave (they share the octets), then one
+      // record per (wave, octet): 16 floats {sum, sumsq} x 8 channels
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ssum[j] += __shfl_xor(ssum[j], 16, 64); ssq[j] += __shfl_xor(ssq[j], 16, 64);
+        ssum[j] += __shfl_xor(ssum[j], 32, 64); ssq[j] += __shfl_xor(ssq[j], 32, 64);
+      }
+      if (lane < 16) {
+        float* rec = statt + ((ct * 8 + wave) * 16 + lane) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(rec + 4 * j) = f32x4{ssum[2 * j], ssq[2 * j], ssum[2 * j + 1], ssq[2 * j + 1]};
+      }
+    }
+    lds_wait();
+    barrier();   // the staging buffer is the next round's exchange buffer
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (p.stats) {
+    // o = 2 * channel + which = t;  channel = ct * 128 + oct * 8 + j  (the records were published by the last round's barrier)
+    const int ch = t >> 1, which = t & 1;
+    const int ct = ch >> 7, oc = (ch >> 3) & 15, j = ch & 7;
+    const float* src = statt + (ct * 8 * 16 + oc) * 16 + 2 * j + which;
+    float a = 0.f;
+#pragma unroll
+    for (int w_ = 0; w_ < 8; ++w_) a += src[w_ * 256];
+    const int tile = th_i * p.tiles_w + tw_i;
+    p.stats[((size_t)b * p.tiles_h * p.tiles_w + tile) * p.CoutPad * 2 + t] = a;
+  }
+#ifdef FD_TIMING2
+  if (p.dbg && t == 0 && bid < 8192) {
+    const unsigned long long t2_end = __builtin_amdgcn_s_memtime();
+    unsigned long long* d = p.dbg + (size_t)bid * 8;
+    d[0] = t2_first - t2_entry; d[1] = t2_loop - t2_first; d[2] = t2_end - t2_loop; d[3] = 0; d[4] = 0; d[5] = 0; d[6] = 0;
+  }
+#endif
+}
+
+// ---- weight packing: [Cout][Cin][3][3] f32 -> [chunk][xt][xi][dy][256 couts][32 B] fp16 ------------------------------------
+// U_xi = G(xi) . w[dy][0..2]; a row's two 16-byte halves (channels 0-7 / 8-15 of the chunk) are XOR-swizzled by (cout >> 3) & 1.
+__global__ void wino4_pack_kernel(const float* __restrict__ w, f16* __restrict__ dst, int Cout, int C0, int C1) {
+  const int Cin = C0 + C1, nchunks = Cin / CK;
+  const long long total = (long long)nchunks * 18 * BN * CK;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % CK);
+    long long r = i / CK;
+    const int n = (int)(r % BN); r /= BN;
+    const int dy = (int)(r % 3); r /= 3;
+    const int slot = (int)(r % 6);                          // wave group xt = slot / 3 owns the slabs slot % 3 = 0..2
+    const int xi = slot < 3 ? slot : (slot == 3 ? 5 : slot - 1);   // positions in the order 0 1 2 | 5 3 4 (see the epilogue)
+    const int chunk = (int)(r / 6);
+    const int c = chunk * CK + k;   // (concat segments are multiples of 16 channels: a chunk never straddles them)
+    float v = 0.f;
+    if (n < Cout) {
+      const float* g = w + (((size_t)n * Cin + c) * 3 + dy) * 3;
+      const float g0 = g[0], g1 = g[1], g2 = g[2];
+      switch (xi) {
+        case 0: v = 0.25f * g0; break;
+        case 1: v = -(g0 + g1 + g2) / 6.f; break;
+        case 2: v = (-g0 + g1 - g2) / 6.f; break;
+        case 3: v = g0 / 24.f + g1 / 12.f + g2 / 6.f; break;
+        case 4: v = g0 / 24.f - g1 / 12.f + g2 / 6.f; break;
+        default: v = g2; break;
+      }
+    }
+    const int half = (k >> 3) ^ ((n >> 3) & 1);
+    dst[(i - k) + half * 8 + (k & 7)] = (f16)v;
+  }
+}
+
+}  // namespace
+
+bool fd_wino4_supported(int Cout, int C0, int C1, int S0, int S1, int ksize) {
+  return ksize == 3 && Cout == BN && C0 > 0 && C0 % 32 == 0 && C1 % 32 == 0 && S0 == 0 && S1 == 0 && (C0 + C1) * 8 <= AFF_BYTES;
+}
+bool fd_wino4_shape_ok(int H, int W) { return H % TH == 0 && W % TW == 0; }
+
+long long fd_wino4_packed_bytes(int Cout, int C0, int C1, int S0, int S1) {
+  (void)Cout; (void)S0; (void)S1;
+  return (long long)((C0 + C1) / CK) * 18 * SLAB + 16 * 1024;
+}
+
+int fd_wino4_pack_weights(const float* w, const float* w_sc, void* packed, int Cout, int C0, int C1, int S0, int S1, hipStream_t st) {
+  (void)w_sc; (void)S0; (void)S1;
+  const long long total = (long long)((C0 + C1) / CK) * 18 * BN * CK;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(wino4_pack_kernel, dim3(blocks), dim3(256), 0, st, w, (f16*)packed, Cout, C0, C1);
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}
+
+int fd_wino4_init_attributes() {
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  return FD_OK;
+}
+
+int fd_wino4_launch(ConvArgs a, hipStream_t st) {
+  FD_REQUIRE(fd_wino4_shape_ok(a.H, a.W), "fd_conv2d: FD_WINOGRAD4 needs H %% 16 == 0 and W %% 16 == 0 (got %d x %d)", a.H, a.W);
+  a.tiles_h = a.H / TH;
+  a.tiles_w = a.W / TW;
+  a.tiles_n = 1;
+  a.CoutPad = BN;
+  const long long nblk = (long long)a.B * a.tiles_h * a.tiles_w;
+  FD_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
+  const dim3 grid((unsigned)nblk), block(NTH);
+  if (a.affine) {
+    if (a.skip) hipLaunchKernelGGL((conv_wino4_kernel<true, true>), grid, block, LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((conv_wino4_kernel<true, false>), grid, block, LDS_BYTES, st, a);
+  } else {
+    if (a.skip) hipLaunchKernelGGL((conv_wino4_kernel<false, true>), grid, block, LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((conv_wino4_kernel<false, false>), grid, block, LDS_BYTES, st, a);
+  }
+  FD_LAUNCH_CHECK();
+  return FD_OK;
+}

@@ -63,10 +63,13 @@ def fir_resample(x, direction, affine=None, want_raw=True):
     return raw, act
 
 
+_WINO = {False: 0, 0: 0, True: L.FD_WINOGRAD, 4: L.FD_WINOGRAD4}   # (True == 1: the F(2,3) kernel)
+
+
 def pack_conv_weight(w, C0=None, dtype=torch.bfloat16, w_sc=None, S0=None, winograd=False, bf16_operands=False):
     """w: [Cout, Cin, k, k] float32 (GPU); C0 = channels of the first concat segment (default: all).
     w_sc: optional 1x1 shortcut weight [Cout, S, 1, 1] folded behind the main K loop (S0 = first segment).
-    winograd: pack for the F(2,3) kernel (FD_WINOGRAD; pass the same flag to conv2d).
+    winograd: True = pack for the F(2,3) kernel (FD_WINOGRAD), 4 = for the F(4,3) kernel (FD_WINOGRAD4); pass the same value to conv2d.
     bf16_operands (with dtype=float32): True = FD_BF16_OPERANDS (f32 activations, bf16 weights / MFMA operands), "x3" =
     FD_BF16X3_OPERANDS (two-term bf16 split, three MFMAs per product); pass the same value to conv2d."""
     L.require_cuda(w, w_sc)
@@ -77,7 +80,7 @@ def pack_conv_weight(w, C0=None, dtype=torch.bfloat16, w_sc=None, S0=None, winog
     S0 = S if S0 is None else S0
     if w_sc is not None:
         w_sc = w_sc.contiguous().float()
-    dt = L.dtype_id(dtype) | (L.FD_WINOGRAD if winograd else 0) | {False: 0, True: L.FD_BF16_OPERANDS, "x3": L.FD_BF16X3_OPERANDS}[bf16_operands]
+    dt = L.dtype_id(dtype) | _WINO[winograd] | {False: 0, True: L.FD_BF16_OPERANDS, "x3": L.FD_BF16X3_OPERANDS}[bf16_operands]
     nbytes = L.load().fd_conv_packed_bytes(Cout, C0, Cin - C0, k, S0, S - S0, dt)
     if nbytes <= 0:
         raise RuntimeError("flowdec_hip: this convolution shape has no %s packing" % ("Winograd" if winograd else "MFMA"))
@@ -99,7 +102,7 @@ def conv2d(x0, packed_w, Cout, ksize, x1=None, affine=None, bias=None, skip=None
     rows = 0 if bias is None else (1 if bias.ndim == 1 else bias.shape[0])
     L.check(lib.fd_conv2d(L.ptr(x0), C0, L.ptr(x1), C1, L.ptr(affine), L.ptr(sc0), S0, L.ptr(sc1), S1, L.ptr(packed_w), L.ptr(bias), rows,
                           L.ptr(skip), float(scale), L.ptr(out), Cout, L.ptr(stats), B, H, W, ksize,
-                          L.dtype_id(x0.dtype) | (L.FD_WINOGRAD if winograd else 0) | L.FD_TILE[tile_bn] | {False: 0, True: L.FD_BF16_OPERANDS, "x3": L.FD_BF16X3_OPERANDS}[bf16_operands],
+                          L.dtype_id(x0.dtype) | _WINO[winograd] | L.FD_TILE[tile_bn] | {False: 0, True: L.FD_BF16_OPERANDS, "x3": L.FD_BF16X3_OPERANDS}[bf16_operands],
                           L.stream()))
     return (out, stats) if want_stats else out
 

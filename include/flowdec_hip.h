@@ -48,6 +48,11 @@ extern "C" {
  * (1.5x fewer MFMAs; bf16 storage, fp16 MFMA operands, f32 accumulation; conv_wino.hip).  The packed weights of the two
  * algorithms differ: pack and launch with the same flag. */
 #define FD_WINOGRAD 0x100
+/* Same places as FD_WINOGRAD: 3x3 convolutions with Cout == 256, all channel counts % 32 == 0 and whole 16 x 16 pixel tiles
+ * (H % 16 == W % 16 == 0) as Winograd F(4,3) along W -- HALF the MFMAs of the direct kernel; 256-cout workgroups with the input
+ * transform done once per workgroup when the activated halo is stored (conv_wino4.hip).  bf16 storage, fp16 MFMA operands, f32
+ * accumulation; raw (not activated) inputs saturate at +-6000.  Pack and launch with the same flag. */
+#define FD_WINOGRAD4 0x80000
 /* fd_model_config.act_dtype only: Winograd for the blocks of resolution level >= 2 (small grids, where its 128-cout workgroups
  * fill the chip better), direct MFMA convolution elsewhere. */
 #define FD_WINOGRAD_LOWRES 0x200
