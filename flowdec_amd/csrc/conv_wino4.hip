@@ -49,7 +49,11 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int NTH = 512, TH = 16, TW = 16, HH = TH + 2, HW = TW + 2, BN = 256;
 constexpr int CK = 16;                              // channels per K chunk (one 32-byte LDS row: two 16-byte halves)
 constexpr int SLAB = BN * 32;                       // 8 KiB: the weights of one (chunk, xi, dy) step, [256 couts][16 ch] fp16
-constexpr int RSLOT = 2048, NRING = 6;              // per-wave ring: 6 slots of 64 couts x 32 B
+#ifndef W4_NRING
+#define W4_NRING 6
+#endif
+constexpr int RSLOT = 2048, NRING = W4_NRING;       // per-wave ring: 6 slots of 64 couts x 32 B (18 % NRING == 0)
+static_assert(18 % NRING == 0, "the two-chunk loop body turns the ring a whole number of times");
 constexpr int RING_BYTES = 8 * NRING * RSLOT;       // 96 KiB
 constexpr int VXI = HH * 4 * 32;                    // one position plane: [18 halo rows][4 tiles][32 B]
 constexpr int V_BYTES = 6 * VXI;                    // 13824
@@ -58,8 +62,7 @@ constexpr int Z_OFF = V_OFF + 2 * V_BYTES;
 constexpr int Z_BYTES = HH * HW * 32;               // activated halo, [18][18][32 B]
 constexpr int RAW_OFF = Z_OFF + Z_BYTES;            // raw halo (bf16) as the DMA delivers it: slot s at s * 16, padded to 1024 slots
 constexpr int RAW_BYTES = 2 * NTH * 16;
-constexpr int AFF_OFF = RAW_OFF + RAW_BYTES;
-constexpr int MAIN_BYTES = AFF_OFF + AFF_BYTES;     // 156800
+constexpr int MAIN_BYTES = RAW_OFF + RAW_BYTES;     // 152704
 // epilogue: exchange buffer [wave][plane][4][64 lanes x 16 B] = the staging of one round (128 pixels x 128 couts f32, padded rows)
 // in the same bytes (a barrier apart), two residual buffers (one round each: 4 passes x 512 threads x 16 B), bias, statistics
 constexpr int S_PITCH = 128 * 4 + 16;
@@ -79,24 +82,22 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b) {
 __device__ __forceinline__ f16x2 h2(unsigned u) { return __builtin_bit_cast(f16x2, u); }
 __device__ __forceinline__ unsigned u2(f16x2 v) { return __builtin_bit_cast(unsigned, v); }
 
-// LDS-DMA of 64 x 16 B (one 1-KiB piece), inline asm: not counted by hipcc (cdna_hip_programming.md 5.7: M0 written in the same
-// statement that reads it); every wait for it is an explicit counted s_waitcnt vmcnt(N) below.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-// the same from a wave-uniform base + a 32-bit byte offset per lane
+// LDS-DMA from inline asm: not counted by hipcc, every wait for it is an explicit counted s_waitcnt vmcnt(N) below.  Each lane's 16 bytes
+// come from (wave-uniform base + per-lane 32-bit byte offset) and land at LDS byte (M0 + instruction offset + lane * 16).  M0 is written
+// in the same statement that uses it (cdna_hip_programming.md 5.7) and NOT restored: nothing else in this file uses M0 (gfx9+ LDS
+// instructions do not; the build checks the ISA for foreign M0 uses -- tests/test_host_cpu.py).
 __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+// two consecutive 1-KiB pieces (global and LDS both + 1024 for the second)
+__device__ __forceinline__ void glds16s_x2(const void* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
 }
 
 template <bool ACT, bool SKIP>
 __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const afftab = smem + AFF_OFF;
 #ifdef FD_TIMING2
   const unsigned long long t2_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -120,137 +121,141 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int cq = wave & 3, xt = wave >> 2;
 
-  // ---- halo loader: slot s = t and s = t + 512 of the 648 (pixel, 8-channel half) slots.  The raw bf16 slots go straight to LDS
-  // by DMA (RAW buffer, slot s at s * 16: a wave's 64 lanes write 1 KiB; the slots 648..1023 are padding that is never read); the
-  // thread that requested a slot later reads it back, activates it and stores it as fp16 into z -- no registers are held while the
-  // load is in flight, and nobody but the requesting thread touches a RAW slot (no barrier between the DMA and the read).
-  // Register budget: 192 accumulators + 24 fragment registers leave ~40 for everything else, so whatever is needed once per chunk
-  // (slot coordinates, transform addresses) is recomputed from the thread index where it is used (`opaque`: not hoisted). ----------
+  // ---- halo loader.  A chunk's halo is 324 pixels x two 8-channel halves (16 B of bf16 each).  Wave w loads half hq = w & 1 of the
+  // pixels hp = i * 256 + (w >> 1) * 64 + lane in pass i = 0, 1 (pass 1: 68 pixels, waves 0..3 only) -- the half is WAVE-UNIFORM, so
+  // the GroupNorm affine (a, d) of the wave's 8 channels is 16 scalar registers (one s_load_dwordx16 per chunk: no LDS table, no LDS
+  // reads in the conversion).  The raw bf16 slots go straight to LDS by DMA (RAW buffer: pass i of wave w at (i * 8 + w) KiB, lane
+  // order); the lane that requested a slot later reads it back, activates it and stores it as fp16 into z -- nothing is held in
+  // registers while the load is in flight, nobody else touches a RAW slot (no barrier between the DMA and the read).
+  // The K loop is bound by vector-instruction issue as soon as the per-chunk work costs more than a few hundred instructions per wave
+  // (SQ counters, profiles/r04_wino4_*): everything a lane needs per chunk is computed ONCE here and kept in registers. ----------
   auto opaque = [&](int v) { asm volatile("" : "+v"(v)); return v; };
   const size_t img_elems = (size_t)H * W;
-  // state of the chunk whose halo is in flight / being converted (wave-uniform)
-  const bf16* nbase = reinterpret_cast<const bf16*>(p.seg[0].src);
-  int nC2 = 0, ncb = 0, naffb = 0;   // bytes per pixel, byte offset of the chunk's first channel, byte offset of its first (a, d) pair
-  int cs = 0, cch = -1;
-  bool cur_end = false;
-  auto next_chunk = [&]() {
-    if (!cur_end) {
-      ++cch;
-      if (cch >= p.seg[cs].C / CK) { ++cs; cch = 0; }
-      if (cs >= p.nseg) cur_end = true;
-    }
-    if (cur_end) return;
-    const Seg sg = p.seg[cs];
-    nbase = reinterpret_cast<const bf16*>(sg.src) + (size_t)b * img_elems * sg.C;
-    nC2 = sg.C * 2;
-    ncb = cch * CK * 2;
-    naffb = sg.aff_off >= 0 ? (sg.aff_off + cch * CK) * 8 : 0;
-  };
-  // halo slot s (0 .. NSLOT - 1): pixel offset (clamped to pixel 0 outside the image) and validity
-  auto slot_pixel = [&](int s, bool& ok) {
-    const int hp = s >> 1;
-    const int hr = (hp * 3641) >> 16;   // hp / 18 for hp < 324
-    const int hc = hp - hr * HW;
+  // the (at most two) concat segments in scalar registers: no kernel-argument loads inside the K loop
+  const bf16* const sb0 = reinterpret_cast<const bf16*>(p.seg[0].src) + (size_t)b * img_elems * p.seg[0].C;
+  const bf16* const sb1 = p.nseg > 1 ? reinterpret_cast<const bf16*>(p.seg[1].src) + (size_t)b * img_elems * p.seg[1].C : sb0;
+  const int sC0 = p.seg[0].C, sC1 = p.nseg > 1 ? p.seg[1].C : 0;
+  const int nch0 = sC0 / CK, n3 = nch0 + sC1 / CK;
+  const int hq = wave & 1;
+  const bool pass1 = wave < 4;       // (the other waves request a duplicate in pass 1 -- every wave has the same number of
+                                     //  vector-memory operations in flight -- and skip its conversion)
+  // per-lane halo constants: pixel index inside the image (0 when outside: the load is harmless, the value is masked), validity,
+  // z address.  Lanes without a pixel in pass 1 redo pass 0 (same load, same bytes to the same z address).
+  int hpix[2], zadr[2];
+  unsigned hvalid = 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int base = ((t >> 7) << 6) + lane;
+    const bool has = i == 0 || base + 256 < HH * HW;
+    const int hp = has ? base + i * 256 : base;
+    const int hr = hp / HW, hc = hp - hr * HW;
     const int gh = h0 - 1 + hr, gw = w0 - 1 + hc;
-    ok = gh >= 0 && gh < H && gw >= 0 && gw < W;
-    return ok ? gh * W + gw : 0;
+    const bool ok = gh >= 0 && gh < H && gw >= 0 && gw < W;
+    hpix[i] = ok ? gh * W + gw : 0;
+    zadr[i] = (has ? i * 8192 : 0) + t * 16 + ((hp * 32 + hq * 16) << 16);   // low half: RAW slot offset, high half: z offset
+    if (ok) hvalid |= 1u << i;
+  }
+  // state of the chunk whose halo is in flight / being converted (wave-uniform)
+  const bf16* nbase = sb0;
+  int nC2 = 0, ncb = 0;              // bytes per pixel, byte offset of this wave's 8 channels inside a pixel
+  int cnext = 0;                     // index of the next chunk to request
+  f32x16 aff;                        // (a, d) x 8 channels of the chunk being converted (scalar registers)
+  const float* const affp = ACT ? p.affine + ((size_t)b * p.affC + hq * 8) * 2 : nullptr;
+  auto next_chunk = [&]() {          // (past the last chunk the state stays: load_halo turns the request into a harmless re-read)
+    if (cnext < n3) {
+      const bool first = cnext < nch0;
+      const int cch = first ? cnext : cnext - nch0;
+      nbase = first ? sb0 : sb1;
+      nC2 = (first ? sC0 : sC1) * 2;
+      ncb = (cch * CK + hq * 8) * 2;
+      if constexpr (ACT)             // affine table = [C0 + C1] pairs in concat order (fd_conv2d: aff_off = 0 / C0)
+        asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(aff) : "s"(affp + (size_t)cnext * CK * 2) : "memory");
+    }
+    ++cnext;
   };
-  // thread tt's i-th slot; threads without a second slot redo their first one (same load, same bytes to the same LDS address)
-  auto slot_of = [&](int tt, int i) { return tt + i * NTH < NSLOT ? tt + i * NTH : tt; };
+  auto aff_wait = [&]() {            // the scalar load is invisible to hipcc: wait for it (and re-define the registers) before the first use
+    if constexpr (ACT) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(aff)::"memory");
+  };
   // past the end of the K loop every lane re-reads element 0 of the last tensor (one cache line; the data is never used)
   const unsigned rawdst = (unsigned)(RAW_OFF + wave * 1024);
   auto load_halo = [&]() {
-    const int tt = opaque(t);
-    const int on = cur_end ? 0 : 1;
-    const int hq16 = (tt & 1) * 16;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      bool ok;
-      const int px = slot_pixel(slot_of(tt, i), ok);
-      glds16s(nbase, (unsigned)((px * nC2 + ncb + hq16) * on), rawdst + i * NTH * 16);
-    }
+    const int on = cnext <= n3 ? 1 : 0;   // (next_chunk has already counted this request)
+    glds16s(nbase, (unsigned)((hpix[0] * nC2 + ncb) * on), rawdst);
+    glds16s(nbase, (unsigned)((hpix[1] * nC2 + ncb) * on), rawdst + 8192);
   };
   // one slot: RAW (bf16) -> [silu(a x + d)] -> fp16 -> z, zero padding AFTER the activation (an AND: no branch)
   auto conv_slot = [&](int i) {
-    const int tt = opaque(t);
-    bool ok;
-    (void)slot_pixel(slot_of(tt, i), ok);
-    const int sadr = slot_of(tt, i) * 16;
-    u32x4 raw = *reinterpret_cast<const u32x4*>(smem + RAW_OFF + sadr);
-    const unsigned vm = ok ? 0xffffffffu : 0u;
-    const char* const ad = afftab + naffb + (tt & 1) * 64;
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(smem + RAW_OFF + (zadr[i] & 0xffff));
+    const unsigned vm = ((hvalid >> i) & 1u) ? 0xffffffffu : 0u;
+    u32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const unsigned u = raw[j];
       const float x0 = __builtin_bit_cast(float, u << 16), x1 = __builtin_bit_cast(float, u & 0xffff0000u);
       unsigned r;
-      if constexpr (ACT) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(ad + 16 * j);
-        r = pack_f16(fd_silu(fmaf(x0, a[0], a[1])), fd_silu(fmaf(x1, a[2], a[3])));
-      } else {   // raw input (activated / resampled upstream): saturate so that the transform cannot overflow to inf
+      if constexpr (ACT) r = pack_f16(fd_silu(fmaf(x0, aff[4 * j], aff[4 * j + 1])), fd_silu(fmaf(x1, aff[4 * j + 2], aff[4 * j + 3])));
+      else   // raw input (activated / resampled upstream): saturate so that the transform cannot overflow to inf
         r = pack_f16(__builtin_amdgcn_fmed3f(x0, -RAW_MAX, RAW_MAX), __builtin_amdgcn_fmed3f(x1, -RAW_MAX, RAW_MAX));
-      }
-      raw[j] = r & vm;
+      o[j] = r & vm;
     }
-    *reinterpret_cast<u32x4*>(smem + Z_OFF + sadr) = raw;
+    *reinterpret_cast<u32x4*>(smem + Z_OFF + ((unsigned)zadr[i] >> 16)) = o;
   };
 
-  // ---- input transform z -> V planes: item (halo row, tile, 4-channel group) = threads 0..287, two channels per pass ------------
-  auto transform = [&](int vbuf) {
-    const int tt = opaque(t);
-    const int tg = tt & 3, twt = (tt >> 2) & 3, thr = tt >> 4;
-    const char* const zp = smem + Z_OFF + (thr * HW + 4 * twt) * 32 + tg * 8;
-    const int tidx = thr * 4 + twt;
-    char* const vb = smem + V_OFF + vbuf * V_BYTES + tidx * 32 + (((tg >> 1) ^ ((tidx >> 3) & 1)) * 16) + (tg & 1) * 8;
+  // ---- input transform z -> V planes.  Item = (halo row, tile, 4-channel group): 288 of them; wave group xt transforms channel pair
+  // k = xt of every item (two channels: 6 words in, 6 words out): its 256 threads take item t & 255, and one wave of the group the
+  // 32 items 256 .. 287 a step later
+  auto item_z = [&](int item, int k) { return Z_OFF + ((item >> 4) * HW + 4 * ((item >> 2) & 3)) * 32 + (item & 3) * 8 + k * 4; };
+  auto item_v = [&](int item, int k) {
+    const int tg = item & 3, tidx = (item >> 4) * 4 + ((item >> 2) & 3);
+    return V_OFF + tidx * 32 + (((tg >> 1) ^ ((tidx >> 3) & 1)) * 16) + (tg & 1) * 8 + k * 4;
+  };
+  const int tz0 = item_z(t & 255, xt), tv0 = item_v(t & 255, xt);
+  auto transform_at = [&](int za, int va, int vbuf) {
+    const char* const zp = smem + za;
+    char* const vb = smem + va + vbuf * V_BYTES;
     const f16x2 c4 = {(f16)4.f, (f16)4.f}, cm4 = {(f16)-4.f, (f16)-4.f}, cm5 = {(f16)-5.f, (f16)-5.f}, c2 = {(f16)2.f, (f16)2.f},
                 cm2 = {(f16)-2.f, (f16)-2.f};
+    unsigned w_[6];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {   // 6 words in, 6 words out
-      unsigned w_[6];
-#pragma unroll
-      for (int j = 0; j < 6; ++j) w_[j] = *reinterpret_cast<const unsigned*>(zp + j * 32 + k * 4);
-      const f16x2 z0 = h2(w_[0]), z1 = h2(w_[1]), z2 = h2(w_[2]), z3 = h2(w_[3]), z4 = h2(w_[4]), z5 = h2(w_[5]);
-      const f16x2 t1 = __builtin_elementwise_fma(z2, cm4, z4);   // z4 - 4 z2
-      const f16x2 t2 = __builtin_elementwise_fma(z1, cm4, z3);   // z3 - 4 z1
-      const f16x2 t3 = z4 - z2, t4 = z3 - z1;
-      *reinterpret_cast<unsigned*>(vb + 0 * VXI + k * 4) =  /* xi = 0 */ u2(__builtin_elementwise_fma(z0, c4, __builtin_elementwise_fma(z2, cm5, z4)));
-      *reinterpret_cast<unsigned*>(vb + 1 * VXI + k * 4) =  /* xi = 1 */ u2(t1 + t2);
-      *reinterpret_cast<unsigned*>(vb + 2 * VXI + k * 4) =  /* xi = 2 */ u2(t1 - t2);
-      *reinterpret_cast<unsigned*>(vb + 4 * VXI + k * 4) =  /* xi = 3 */ u2(__builtin_elementwise_fma(t4, c2, t3));
-      *reinterpret_cast<unsigned*>(vb + 5 * VXI + k * 4) =  /* xi = 4 */ u2(__builtin_elementwise_fma(t4, cm2, t3));
-      *reinterpret_cast<unsigned*>(vb + 3 * VXI + k * 4) =  /* xi = 5 */ u2(__builtin_elementwise_fma(z1, c4, __builtin_elementwise_fma(z3, cm5, z5)));
-    }
+    for (int j = 0; j < 6; ++j) w_[j] = *reinterpret_cast<const unsigned*>(zp + j * 32);
+    const f16x2 z0 = h2(w_[0]), z1 = h2(w_[1]), z2 = h2(w_[2]), z3 = h2(w_[3]), z4 = h2(w_[4]), z5 = h2(w_[5]);
+    const f16x2 t1 = __builtin_elementwise_fma(z2, cm4, z4);   // z4 - 4 z2
+    const f16x2 t2 = __builtin_elementwise_fma(z1, cm4, z3);   // z3 - 4 z1
+    const f16x2 t3 = z4 - z2, t4 = z3 - z1;
+    // plane slots in the order xi = 0 1 2 | 5 3 4 (see the epilogue)
+    *reinterpret_cast<unsigned*>(vb + 0 * VXI) = u2(__builtin_elementwise_fma(z0, c4, __builtin_elementwise_fma(z2, cm5, z4)));   // xi = 0
+    *reinterpret_cast<unsigned*>(vb + 1 * VXI) = u2(t1 + t2);                                                                    // xi = 1
+    *reinterpret_cast<unsigned*>(vb + 2 * VXI) = u2(t1 - t2);                                                                    // xi = 2
+    *reinterpret_cast<unsigned*>(vb + 4 * VXI) = u2(__builtin_elementwise_fma(t4, c2, t3));                                       // xi = 3
+    *reinterpret_cast<unsigned*>(vb + 5 * VXI) = u2(__builtin_elementwise_fma(t4, cm2, t3));                                      // xi = 4
+    *reinterpret_cast<unsigned*>(vb + 3 * VXI) = u2(__builtin_elementwise_fma(z1, c4, __builtin_elementwise_fma(z3, cm5, z5)));   // xi = 5
+  };
+  // the wave of each group that takes the 32 extra items: wave 1 (group 0, SIMD 2) and wave 6 (group 1, SIMD 1), lanes 0..31
+  const bool extra_wave = wave == 1 || wave == 6;
+  auto transform_extra = [&](int vbuf) {
+    if (extra_wave && lane < 32) transform_at(item_z(256 + lane, xt), item_v(256 + lane, xt), vbuf);
   };
 
-  // ---- weight stream: this wave's two 1-KiB pieces (cout blocks ct = 0, 1) of its step f -> ring slot f % 6 -------------------
-  // packed layout: [chunk][xt][xi][dy][256 couts][32 B]; the wave's 9 steps of a chunk are 9 consecutive slabs
-  const char* wsrc = reinterpret_cast<const char*>(p.w) + (size_t)xt * 9 * SLAB + cq * 1024;
-  asm volatile("" : "+s"(wsrc));
+  // ---- weight stream: this wave's 2 KiB (cout blocks ct = 0, 1: two consecutive 1-KiB pieces) of its step f -> ring slot f % NRING.
+  // packed layout: [chunk][xt][xi][dy][cq][ct][32 couts][32 B]; the wave's 9 steps of a chunk are 9 consecutive slabs.  The stream
+  // runs up to a ring length past the wave's last step: fd_wino4_packed_bytes pads the buffer by one chunk (what lands is never read).
+  const char* wp = reinterpret_cast<const char*>(p.w) + (size_t)xt * 9 * SLAB + cq * 2048;   // first step of the current chunk pair
+  asm volatile("" : "+s"(wp));
   const unsigned lane16 = (unsigned)(lane * 16);
   const unsigned wring = (unsigned)(wave * NRING * RSLOT);
-  int n3 = 0;
-  for (int s = 0; s < p.nseg; ++s) n3 += p.seg[s].C / CK;
-  int fleft = n3 * 9;          // steps of this wave still to fetch
-  int fsub = 0;                // index of the next one inside its chunk
-  auto dma_next = [&](int slot) {
-    const char* src = fleft > 0 ? wsrc : reinterpret_cast<const char*>(p.w);   // past the end: a harmless re-read
-    glds16s(src, lane16, wring + slot * RSLOT);
-    glds16s(src + 4096, lane16, wring + slot * RSLOT + 1024);
-    --fleft;
-    wsrc += SLAB;
-    if (++fsub == 9) { fsub = 0; wsrc += 9 * SLAB; }
-    asm volatile("" : "+s"(wsrc));
+  auto dma_step = [&](int f, int slot) {   // f = step index relative to the current chunk pair (compile-time)
+#ifndef W4_EXP_NO_WDMA
+    glds16s_x2(wp + (f / 9) * 18 * SLAB + (f % 9) * SLAB, lane16, wring + slot * RSLOT);
+#endif
   };
 
   // ---- per-lane fragment coordinates --------------------------------------------------------------------------------------
   const int l31 = lane & 31, lh = lane >> 5;
   const int wa_lane = (int)wring + l31 * 32 + ((lh ^ ((l31 >> 3) & 1)) * 16);   // A: row l31 of the slot, cout block ct at + 1024
-  int vb_lane[3];                                                             // B: tile l31 (+ 32 at + 1024), halo row shift dy
-#pragma unroll
-  for (int dy = 0; dy < 3; ++dy) {
-    const int idx = l31 + 4 * dy;
-    vb_lane[dy] = V_OFF + xt * 3 * VXI + idx * 32   /* plane slots 0 1 2 | 5 3 4 */ + ((lh ^ ((idx >> 3) & 1)) * 16);
-  }
+  // B: tile l31 (+ 32 at + 1024), halo row shift dy: row idx = l31 + 4 dy at idx * 32, half lh ^ ((idx >> 3) & 1).  dy = 2 flips the half
+  // of every lane (idx + 8), dy = 1 that of the lanes with l31 & 4 (the carry into bit 3)
+  const int vb0 = V_OFF + xt * 3 * VXI /* plane slots 0 1 2 | 5 3 4 */ + l31 * 32 + ((lh ^ ((l31 >> 3) & 1)) * 16);
+  const int vb1 = (vb0 ^ ((l31 & 4) << 2)) + 128;
 
   f32x16 acc[3][2][2];
 #pragma unroll
@@ -281,54 +286,64 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   auto a_off = [&](int k18, int ct) { return wa_lane + (k18 % NRING) * RSLOT + ct * 1024; };
   auto b_off = [&](int k18, int nt) {
     const int s = k18 % 9, half = (k18 / 9) & 1;
-    return vb_lane[s % 3] + half * V_BYTES + (s / 3) * VXI + nt * 1024;
+    const int dy = s % 3;
+    return (dy == 0 ? vb0 : dy == 1 ? vb1 : (vb0 ^ 16) + 256) + half * V_BYTES + (s / 3) * VXI + nt * 1024;
   };
 
-  // ---- prologue: first halo, the first six weight steps and the affine table in one memory round trip --------------------------
+  // ---- prologue: first halo, the first ring of weight steps and the affine of chunk 0 in one memory round trip ----------------------
   next_chunk();
   load_halo();
 #pragma unroll
-  for (int k = 0; k < NRING; ++k) dma_next(k);
-  if (ACT) {
-    const float* ap = p.affine + (size_t)b * p.affC * 2;
-    for (int i = t; i < p.affC / 2; i += NTH) *reinterpret_cast<f32x4*>(afftab + i * 16) = *reinterpret_cast<const f32x4*>(ap + i * 4);
-  }
+  for (int k = 0; k < NRING; ++k) dma_step(k, k);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();          // affine table published; this wave's RAW slots and weight pieces have landed
+  aff_wait();
   conv_slot(0);
-  conv_slot(1);
+  if (pass1) conv_slot(1);
   next_chunk();
   lds_wait();
-  load_halo();              // halo of chunk 1 (converted during chunk 0): this thread's RAW slots are free again
+  load_halo();              // halo of chunk 1: this lane's RAW slots are free again
   barrier();
-  if (t < 288) transform(0);
+  transform_at(tz0, tv0, 0);
+  transform_extra(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_wait();
   barrier();
+  aff_wait();
+  if (xt == 0) conv_slot(0);   // wave group 0 is one step ahead with its conversions (see below)
 #ifdef FD_TIMING2
   const unsigned long long t2_first = __builtin_amdgcn_s_memtime();
 #endif
   qa[0] = rd(a_off(0, 0)); qb[0] = rd(b_off(0, 0)); qb[1] = rd(b_off(0, 1)); qa[1] = rd(a_off(0, 1));
 
-  // ---- K loop.  Chunk c multiplies V[c & 1]; meanwhile the halo of chunk c + 1 (in RAW since chunk c - 1) is activated and stored
-  // (steps 1, 2), transformed into V[(c + 1) & 1] (step 4), and the halo of chunk c + 2 is requested (step 3).  A step starts with a
-  // counted wait for the weights of the NEXT step (its first fragments are requested right away); in flight on this wave's
-  // vector-memory counter at that wait, oldest first: the weight pieces of steps s + 1 .. s + 5 (2 each) and, in steps 4..8, the two
-  // halo pieces issued in step 3 behind the weights of step 9: vmcnt(8 / 10).  The halo pieces are older than everything the wait of
-  // the next chunk's step 0 leaves in flight.  The weights of step s + 6 are requested after the third MFMA of step s: by then both
-  // weight fragments of step s have arrived and its ring slot is free.
+  // ---- K loop.  Chunk c multiplies V[c & 1]; meanwhile the halo of chunk c + 1 (in RAW) is activated and stored into z, transformed
+  // into V[(c + 1) & 1], and the halo of chunk c + 2 is requested.  z may be written between the barrier of step 8 (all transforms of
+  // the previous chunk have read it) and the barrier of step 3; the transforms run between the barrier of step 3 and that of step 8.
+  // The two waves of a SIMD (groups xt = 0 / 1) do this vector work in DIFFERENT steps:
+  //   group 0: pass 0 converted in step 8 (of the previous chunk), pass 1 in step 0, next halo + affine requested in step 1,
+  //            transform in step 4 (channel pair 0), the 32 extra items in step 5 (wave 1)
+  //   group 1: conversions in steps 1 and 2, request in step 3, transform in step 5 (channel pair 1), extra items in step 6 (wave 6)
+  // A step starts with a counted wait for the weights of the NEXT step (its first fragments are requested right away); in flight on
+  // this wave's vector-memory counter at that wait, oldest first: the weight pieces of steps s + 1 .. s + 5 (2 each) and, in the five
+  // steps after the halo request, its two pieces: vmcnt(8 / 10).  The weights of step s + 6 are requested after the third MFMA of step
+  // s: by then both weight fragments of step s have arrived and its ring slot is free.
   // Two chunks per iteration: 18 steps = three turns of the ring = six turns of the fragment quads, and the V buffers swap back, so
   // that every LDS offset is an immediate and the loop has ONE set of MFMA sites (two bodies in one loop double the accumulators).
+  constexpr int NW = 2 * (NRING - 2);   // weight pieces that may stay in flight at the wait
   for (int c = 0; c < n3; c += 2) {
-#pragma unroll
+    int xg = xt;                       // (opaque per iteration: hipcc otherwise unswitches the loop on the wave group -- two loop bodies,
+    asm volatile("" : "+s"(xg));       //  two sets of MFMA sites, spilled accumulators)
+#pragma clang loop unroll(full)
     for (int k = 0; k < 18; ++k) {
       const int s = k % 9, half = k / 9;
       const int vn = half ^ 1;
       const int xl = s / 3;
       u32x4 &A0 = qa[(2 * k) % 3], &A1 = qa[(2 * k + 1) % 3], &A2 = qa[(2 * k + 2) % 3];
       u32x4 &B0 = qb[(2 * k) % 3], &B1 = qb[(2 * k + 1) % 3], &B2 = qb[(2 * k + 2) % 3];
-      if (s <= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      // halo request in step h: its pieces are younger than the awaited weights in steps h + 1 .. h + 5
+      if (s >= 2 && s <= 3) { if (xg == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW + 2) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory"); }
+      else if (s >= 4 && s <= 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW + 2) : "memory");
+      else if (s >= 7) { if (xg == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW + 2) : "memory"); }
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
       if (s == 3 || s == 8) { lds_wait(); barrier(); }   // s == 3: z complete;  s == 8: V[vn] complete, every wave has its last V[vc] fragments
       A2 = rd(a_off(k + 1, 0));
       B2 = rd(b_off(k + 1, 0));
@@ -340,16 +355,32 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
       mma(xl, 1, 0, A1, B0);
       __builtin_amdgcn_sched_barrier(0);
       B0 = rd(b_off(k + 1, 1));
-      dma_next(k % NRING);                         // step s + 6 into the slot whose fragments have both arrived
-      if (s == 3) { next_chunk(); load_halo(); }
+      dma_step(k + NRING, k % NRING);              // step s + 6 into the slot whose fragments have both arrived
+#ifndef W4_EXP_NO_PROD
+#ifndef W4_EXP_NO_HALO
+      if ((s == 1 && xg == 0) || (s == 3 && xg == 1)) { next_chunk(); load_halo(); }
+#endif
+#endif
       mma(xl, 1, 1, A1, B1);
       __builtin_amdgcn_sched_barrier(0);
       // the chunk's vector work, while the quads A1 / B1 are dead
-      if (s == 1) conv_slot(0);
-      if (s == 2) conv_slot(1);
-      if (s == 4) { if (t < 288) transform(vn); }
+#ifndef W4_EXP_NO_PROD
+#ifndef W4_EXP_NO_CONV
+      if (s == 8) { if (xg == 0) { aff_wait(); conv_slot(0); } }
+      if (s == 0) { if (xg == 0 && pass1) conv_slot(1); }
+      if (s == 1) { if (xg == 1) { aff_wait(); conv_slot(0); } }
+      if (s == 2) { if (xg == 1 && pass1) conv_slot(1); }
+#endif
+#ifndef W4_EXP_NO_TRANS
+      if (s == 4) { if (xg == 0) transform_at(tz0, tv0, vn); }
+      if (s == 5) { if (xg == 1) transform_at(tz0, tv0, vn); else transform_extra(vn); }
+      if (s == 6) { if (xg == 1) transform_extra(vn); }
+#endif
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
+    wp += 36 * SLAB;
+    asm volatile("" : "+s"(wp));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // all fragment reads / DMA done before the epilogue reuses the LDS
@@ -548,9 +579,10 @@ __global__ void wino4_pack_kernel(const float* __restrict__ w, f16* __restrict__
     const int xi = slot < 3 ? slot : (slot == 3 ? 5 : slot - 1);   // positions in the order 0 1 2 | 5 3 4 (see the epilogue)
     const int chunk = (int)(r / 6);
     const int c = chunk * CK + k;   // (concat segments are multiples of 16 channels: a chunk never straddles them)
+    const int co = ((n >> 5) & 1) * 128 + (n >> 6) * 32 + (n & 31);   // slab row n = [cq][ct][32] holds cout ct * 128 + cq * 32 + m
     float v = 0.f;
-    if (n < Cout) {
-      const float* g = w + (((size_t)n * Cin + c) * 3 + dy) * 3;
+    if (co < Cout) {
+      const float* g = w + (((size_t)co * Cin + c) * 3 + dy) * 3;
       const float g0 = g[0], g1 = g[1], g2 = g[2];
       switch (xi) {
         case 0: v = 0.25f * g0; break;
@@ -575,7 +607,7 @@ bool fd_wino4_shape_ok(int H, int W) { return H % TH == 0 && W % TW == 0; }
 
 long long fd_wino4_packed_bytes(int Cout, int C0, int C1, int S0, int S1) {
   (void)Cout; (void)S0; (void)S1;
-  return (long long)((C0 + C1) / CK) * 18 * SLAB + 16 * 1024;
+  return (long long)((C0 + C1) / CK + 1) * 18 * SLAB + 16 * 1024;   // + one chunk: the weight stream runs a ring length past the last step
 }
 
 int fd_wino4_pack_weights(const float* w, const float* w_sc, void* packed, int Cout, int C0, int C1, int S0, int S1, hipStream_t st) {
