@@ -419,6 +419,12 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   skip_dma(0);
   const float ka = xt ? 0.f : 1.f, ks = xt ? 4.f : 1.f, kb = xt ? 1.f : 0.f, kd = xt ? 8.f : 1.f, kq = xt ? 0.25f : 1.f;
   float ssum[8], ssq[8];
+#ifdef FD_TIMING2
+  unsigned long long t2_r[5] = {0, 0, 0, 0, 0};
+#define W4_STAMP(i) if (rd_ == 0) t2_r[i] = __builtin_amdgcn_s_memtime();
+#else
+#define W4_STAMP(i)
+#endif
 #pragma unroll
   for (int rd_ = 0; rd_ < 4; ++rd_) {
     const int ct = rd_ >> 1, nt = rd_ & 1;
@@ -427,44 +433,56 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) ssum[j] = ssq[j] = 0.f;
     }
+    W4_STAMP(0)
     if (rd_ < 3) skip_dma(rd_ + 1);
     // (a) partial output transform in place, (b) send two planes, (c) receive two planes and finish in place (ya -> m0, yb -> m1).
     // Both wave groups run the same code with wave-uniform coefficients (a branch here costs two spilled accumulator tiles):
     //   s = m1 + m2, d = m1 - m2;   send0 = s, send1 = ke d;   ya = ka m0 + ks s + recv0,  yb = kb m0 + kd d + recv1
     //   xt = 0 (m = M0, M1, M2): sends a2 = s, a1 = d;   y0 = M0 + s + b0,  y1 = d + b1             (ka ks kb kd ke = 1 1 0 1 1)
     //   xt = 1 (m = M5, M3, M4): sends b0 = s, b1 = 2 d;  y2 = 4 s + a2,     y3 = M5 + 8 d + a1      (ka ks kb kd ke = 0 4 1 8 2)
-    {
+    {   // (two channels per instruction: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 on consecutive accumulator registers)
       char* const xmine = smem + wave * 8192 + lane * 16;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float s_ = m1[e] + m2[e], d_ = m1[e] - m2[e];
-        m2[e] = s_;
-        m1[e] = kd * d_;
-      }
+      const f32x2 kd2 = {kd, kd}, kq2 = {kq, kq};
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
+        f32x2 snd[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int e = 4 * g + 2 * h;
+          const f32x2 a1 = {m1[e], m1[e + 1]}, a2 = {m2[e], m2[e + 1]};
+          const f32x2 s_ = a1 + a2, d_ = (a1 - a2) * kd2;
+          m2[e] = s_[0]; m2[e + 1] = s_[1];
+          m1[e] = d_[0]; m1[e + 1] = d_[1];
+          snd[h] = d_ * kq2;                                     // ke d = (ke / kd) kd d
+        }
         *reinterpret_cast<f32x4*>(xmine + g * 1024) = f32x4{m2[4 * g], m2[4 * g + 1], m2[4 * g + 2], m2[4 * g + 3]};
-        *reinterpret_cast<f32x4*>(xmine + 4096 + g * 1024) = f32x4{kq * m1[4 * g], kq * m1[4 * g + 1], kq * m1[4 * g + 2], kq * m1[4 * g + 3]};   // ke d = (ke / kd) kd d
+        *reinterpret_cast<f32x4*>(xmine + 4096 + g * 1024) = f32x4{snd[0][0], snd[0][1], snd[1][0], snd[1][1]};
       }
     }
     lds_wait();
     barrier();
+    W4_STAMP(1)
     {
       const char* const xpeer = smem + (wave ^ 4) * 8192 + lane * 16;
+      const f32x2 ka2 = {ka, ka}, ks2 = {ks, ks}, kb2 = {kb, kb};
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 r0 = *reinterpret_cast<const f32x4*>(xpeer + g * 1024), r1 = *reinterpret_cast<const f32x4*>(xpeer + 4096 + g * 1024);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int e = 4 * g + k;
-          const float mm = m0[e];
-          m0[e] = fmaf(ka, mm, fmaf(ks, m2[e], r0[k]));
-          m1[e] = fmaf(kb, mm, m1[e] + r1[k]);
+        for (int h = 0; h < 2; ++h) {
+          const int e = 4 * g + 2 * h;
+          const f32x2 mm = {m0[e], m0[e + 1]}, ss = {m2[e], m2[e + 1]}, dd = {m1[e], m1[e + 1]};
+          const f32x2 q0 = {r0[2 * h], r0[2 * h + 1]}, q1 = {r1[2 * h], r1[2 * h + 1]};
+          const f32x2 ya = __builtin_elementwise_fma(ka2, mm, __builtin_elementwise_fma(ks2, ss, q0));
+          const f32x2 yb = __builtin_elementwise_fma(kb2, mm, dd + q1);
+          m0[e] = ya[0]; m0[e + 1] = ya[1];
+          m1[e] = yb[0]; m1[e + 1] = yb[1];
         }
       }
     }
     lds_wait();
     barrier();   // every wave has read its peer's planes: the exchange buffer becomes the staging buffer
+    W4_STAMP(2)
     {
       char* const sbase = smem + ((2 * xt) * 32 + l31) * S_PITCH + (cq * 32 + 4 * lh) * 4;
 #pragma unroll
@@ -475,6 +493,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
     }
     lds_wait();
     barrier();
+    W4_STAMP(3)
     __builtin_amdgcn_sched_barrier(0);
     // sweep in two batches of two passes: computed into registers first, stores back to back afterwards.  The residual of this round
     // is in SK[rd_ & 1]: older than the stores of the previous round and the DMA of the next one (8 operations may stay in flight).
@@ -543,6 +562,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
     }
     lds_wait();
     barrier();   // the staging buffer is the next round's exchange buffer
+    W4_STAMP(4)
     __builtin_amdgcn_sched_barrier(0);
   }
   if (p.stats) {
@@ -560,7 +580,8 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   if (p.dbg && t == 0 && bid < 8192) {
     const unsigned long long t2_end = __builtin_amdgcn_s_memtime();
     unsigned long long* d = p.dbg + (size_t)bid * 8;
-    d[0] = t2_first - t2_entry; d[1] = t2_loop - t2_first; d[2] = t2_end - t2_loop; d[3] = 0; d[4] = 0; d[5] = 0; d[6] = 0;
+    d[0] = t2_first - t2_entry; d[1] = t2_loop - t2_first; d[2] = t2_end - t2_loop;
+    d[3] = t2_r[1] - t2_r[0]; d[4] = t2_r[2] - t2_r[1]; d[5] = t2_r[3] - t2_r[2]; d[6] = t2_r[4] - t2_r[3]; d[7] = t2_r[0] - t2_loop;
   }
 #endif
 }

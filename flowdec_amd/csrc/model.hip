@@ -29,6 +29,7 @@ struct Mod {
   int level = 0;                 // resolution level the block's convolutions run at (0 = full resolution)
   bool wino0 = false, wino1 = false;   // Conv_0 / Conv_1 (+ folded Conv_2) packed for the Winograd kernel
   void* w0w = nullptr; void* w1w = nullptr;   // FD_WINOGRAD_AUTO: second (Winograd) packing next to the direct one in w0 / w1
+  void* w0w4 = nullptr; void* w1w4 = nullptr; // FD_WINOGRAD_AUTO: third packing, for the F(4,3) kernel (conv_wino4.hip), where its shape rules allow
   // device pointers (filled by finalize)
   void* w0 = nullptr; void* w1 = nullptr; void* w2 = nullptr;   // packed conv weights
   float *gn0_g = nullptr, *gn0_b = nullptr, *gn1_g = nullptr, *gn1_b = nullptr;
@@ -340,8 +341,10 @@ struct Fwd {
   // (128-channel workgroups) takes everything else up to 512 tiles unless a 1x1 shortcut is folded in; those run the direct kernel with
   // 128-channel workgroups up to 128 tiles.  By image size only.
   int conv(const Tens& a, const Tens* b, size_t aff, const Tens* s0, const Tens* s1, const void* w, const float* bias, int bias_rows,
-           const Tens* skip, float scale, Tens& out, int ks, bool want_stats, bool wino = false, const void* w_wino = nullptr) {
+           const Tens* skip, float scale, Tens& out, int ks, bool want_stats, bool wino = false, const void* w_wino = nullptr,
+           const void* w_wino4 = nullptr) {
     int tile = 0;
+    bool wino4 = false;
     const int opflag = m ? (m->cfg.act_dtype & (FD_BF16_OPERANDS | FD_BF16X3_OPERANDS)) : 0;
     const int px_tiles = fd_cdiv(out.H, 16) * fd_cdiv(out.W, 16);
     const bool latency = m && (m->cfg.act_dtype & FD_LOW_LATENCY) && dt == FD_BF16;
@@ -351,6 +354,10 @@ struct Fwd {
     // (never with a folded 1x1 shortcut: its input is the UN-NORMALISED residual stream, which the Winograd kernel would narrow to
     // the fp16 range; GroupNorm+SiLU outputs and their FIR-resampled versions are bounded)
     else if (w_wino && !s0 && (auto_wino(out) || (latency && px_tiles <= 512))) { w = w_wino; wino = true; }
+    // images of more than 96 tiles (the two upper resolution levels of a 2 s clip): Winograd F(4,3) with 256-cout workgroups -- half the
+    // MFMAs of the direct kernel, 1.09-1.19x per launch (profiles/r04_wino4_vs_direct.txt); whole 16 x 16 tiles only
+    // (not the 64-channel input of the first block: 0.93-1.0x there)
+    else if (autosel && w_wino4 && !s0 && out.H % 16 == 0 && out.W % 16 == 0 && a.C + (b ? b->C : 0) >= 128) { w = w_wino4; wino4 = true; }
     // one clip, folded-shortcut convolutions of the 384 x 64 level (96 tiles): 96 workgroups of 256 channels leave 160 CUs idle; 128-channel
     // workgroups are 1.28-1.39x per launch there (scripts/ab_conv_b1.py with AB_H=384 AB_W=64), same bits
     else if (latency && px_tiles <= 128 && out.C >= 256 && out.C % 128 == 0) tile = FD_TILE_BN128;
@@ -371,7 +378,7 @@ struct Fwd {
     const int rc = fd_conv2d(ptr(a.off), a.C, b ? ptr(b->off) : nullptr, b ? b->C : 0, aff == (size_t)-1 ? nullptr : (const float*)ptr(aff),
                              s0 ? ptr(s0->off) : nullptr, s0 ? s0->C : 0, s1 ? ptr(s1->off) : nullptr, s1 ? s1->C : 0, w, bias, bias_rows,
                              skip ? ptr(skip->off) : nullptr, scale, ptr(out.off), out.C, want_stats ? (float*)ptr(out.sums) : nullptr, B,
-                             out.H, out.W, ks, dt | (wino ? FD_WINOGRAD : 0) | tile | opflag, st);
+                             out.H, out.W, ks, dt | (wino ? FD_WINOGRAD : 0) | (wino4 ? FD_WINOGRAD4 : 0) | tile | opflag, st);
     if (m && m->profiling) {
       FD_HIP(hipEventRecord(m->ev[m->ev_used].second, st));
       ++m->ev_used;
@@ -415,10 +422,10 @@ struct Fwd {
     if (md.up || md.down) {
       xr = talloc(md.cin, OH, OW); hr = talloc(md.cin, OH, OW);
       if (!dry) FD_TRY(fir(ptr(x0.off), (const float*)ptr(aff0), ptr(xr.off), ptr(hr.off), H, W, md.cin, md.up ? 1 : -1));
-      FD_TRY(conv(hr, nullptr, (size_t)-1, nullptr, nullptr, md.w0, md.bias0_eff, nt, nullptr, 1.f, h1, 3, true, md.wino0, md.w0w));
+      FD_TRY(conv(hr, nullptr, (size_t)-1, nullptr, nullptr, md.w0, md.bias0_eff, nt, nullptr, 1.f, h1, 3, true, md.wino0, md.w0w, md.w0w4));
       tfree(hr);
     } else {
-      FD_TRY(conv(x0, x1, aff0, nullptr, nullptr, md.w0, md.bias0_eff, nt, nullptr, 1.f, h1, 3, true, md.wino0, md.w0w));
+      FD_TRY(conv(x0, x1, aff0, nullptr, nullptr, md.w0, md.bias0_eff, nt, nullptr, 1.f, h1, 3, true, md.wino0, md.w0w, md.w0w4));
     }
     arena.release(aff0);
     size_t aff1;
@@ -426,10 +433,10 @@ struct Fwd {
     if (!out_given) out = talloc(md.cout, OH, OW);
     else { out.C = md.cout; out.H = OH; out.W = OW; out.sums = (size_t)-1; }   // fd_resblock: the caller's output tensor
     if (md.has_c2) {  // Conv_1(act(GN1(h))) + Conv_2(x) in one launch (shortcut conv folded in as extra K steps)
-      if (md.up || md.down) FD_TRY(conv(h1, nullptr, aff1, &xr, nullptr, md.w1, md.b1, 1, nullptr, rs2, out, 3, true, md.wino1, md.w1w));
-      else FD_TRY(conv(h1, nullptr, aff1, &x0, x1, md.w1, md.b1, 1, nullptr, rs2, out, 3, true, md.wino1, md.w1w));
+      if (md.up || md.down) FD_TRY(conv(h1, nullptr, aff1, &xr, nullptr, md.w1, md.b1, 1, nullptr, rs2, out, 3, true, md.wino1, md.w1w, md.w1w4));
+      else FD_TRY(conv(h1, nullptr, aff1, &x0, x1, md.w1, md.b1, 1, nullptr, rs2, out, 3, true, md.wino1, md.w1w, md.w1w4));
     } else {
-      FD_TRY(conv(h1, nullptr, aff1, nullptr, nullptr, md.w1, md.b1, 1, &x0, rs2, out, 3, true, md.wino1, md.w1w));
+      FD_TRY(conv(h1, nullptr, aff1, nullptr, nullptr, md.w1, md.b1, 1, &x0, rs2, out, 3, true, md.wino1, md.w1w, md.w1w4));
     }
     if (md.up || md.down) tfree(xr);
     arena.release(aff1);
@@ -889,6 +896,12 @@ extern "C" int fd_model_finalize(fd_model* m, void* stream) {
         if (both && fd_conv_packed_bytes(md.cout, md.cout, 0, 3, md.has_c2 ? md.c0 : 0, md.has_c2 ? md.c1 : 0, m->dt | FD_WINOGRAD) > 0)
           FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, md.has_c2 ? p + "Conv_2.weight" : std::string(), md.has_c2 ? md.c0 : 0,
                            md.has_c2 ? md.c1 : 0, &md.w1w, st, FD_WINOGRAD));
+        const bool both4 = (m->cfg.act_dtype & FD_WINOGRAD_AUTO) != 0;
+        if (both4 && fd_conv_packed_bytes(md.cout, md.c0, md.c1, 3, 0, 0, m->dt | FD_WINOGRAD4) > 0)
+          FD_TRY(pack_conv(m, p + "Conv_0.weight", md.cout, md.c0, md.c1, 3, "", 0, 0, &md.w0w4, st, FD_WINOGRAD4));
+        if (both4 && fd_conv_packed_bytes(md.cout, md.cout, 0, 3, md.has_c2 ? md.c0 : 0, md.has_c2 ? md.c1 : 0, m->dt | FD_WINOGRAD4) > 0)
+          FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, md.has_c2 ? p + "Conv_2.weight" : std::string(), md.has_c2 ? md.c0 : 0,
+                           md.has_c2 ? md.c1 : 0, &md.w1w4, st, FD_WINOGRAD4));
         FD_TRY(pack_conv(m, p + "Conv_0.weight", md.cout, md.c0, md.c1, 3, "", 0, 0, &md.w0, st, md.wino0 ? FD_WINOGRAD : 0));
         if (md.has_c2) {  // fold the 1x1 shortcut into Conv_1's K loop; biases add
           FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, p + "Conv_2.weight", md.c0, md.c1, &md.w1, st, md.wino1 ? FD_WINOGRAD : 0));

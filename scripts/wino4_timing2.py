@@ -27,4 +27,4 @@ for name, C0, C1, aff, skip in [("plain 256", 256, 0, 0, 0), ("cat aff 512", 256
         pro, loop, epi = [d[:, k].mean().item() for k in range(3)]
         tot = pro + loop + epi
         print(f"{name:14s} {'wino4 ' if algo else 'direct'} {ms:.3f} ms | per workgroup ticks: prologue {pro:7.0f} ({100*pro/tot:4.1f}%)  loop {loop:8.0f} ({100*loop/tot:4.1f}%)  "
-              f"epilogue {epi:7.0f} ({100*epi/tot:4.1f}%)  total {tot:8.0f}", flush=True)
+              f"epilogue {epi:7.0f} ({100*epi/tot:4.1f}%)  total {tot:8.0f}" + (f" | round 0: transform+send {d[:, 3].mean():.0f} recv+combine {d[:, 4].mean():.0f} stage {d[:, 5].mean():.0f} sweep {d[:, 6].mean():.0f}, before {d[:, 7].mean():.0f}" if algo else ""), flush=True)
