@@ -65,10 +65,14 @@ constexpr int RAW_BYTES = 2 * NTH * 16;
 constexpr int MAIN_BYTES = RAW_OFF + RAW_BYTES;     // 152704
 // epilogue: exchange buffer [wave][plane][4][64 lanes x 16 B] = the staging of one round (128 pixels x 128 couts f32, padded rows)
 // in the same bytes (a barrier apart), two residual buffers (one round each: 4 passes x 512 threads x 16 B), bias, statistics
+constexpr int X_BYTES = 8 * 8192;                   // exchange buffer (two of them: one barrier per round)
 constexpr int S_PITCH = 128 * 4 + 16;
-constexpr int S_BYTES = 128 * S_PITCH;              // 67584 >= 8 x 8192
+constexpr int S_BYTES = 128 * S_PITCH;              // 67584; two staging buffers unless the residual buffers are in use
 constexpr int SK_OFF = S_BYTES, SK_BYTES = 4 * NTH * 16;
-constexpr int BIAS_OFF = SK_OFF + 2 * SK_BYTES;     // [256] f32
+constexpr int SCK = 2;                              // shortcut GEMM: MFMA K steps (16 channels) per stage
+constexpr int XS_OFF = 8 * 2 * SCK * 2048, XS_BYTES = SCK * 8192;   // weight rings [8 waves][2 stages x SCK x 2 KiB] below, two x stages here
+constexpr int BIAS_OFF = 2 * S_BYTES;               /* = 135168 */               // [256] f32; above everything the three phases use (2 X, rings + x stages, S + 2 SK)
+static_assert(BIAS_OFF >= 2 * X_BYTES && BIAS_OFF >= XS_OFF + 2 * XS_BYTES && BIAS_OFF >= SK_OFF + 2 * SK_BYTES, "epilogue LDS map");
 constexpr int STAT_OFF = BIAS_OFF + 1024;           // [2][8 waves][16 octets][16] f32 = 16 KiB
 constexpr int LDS_BYTES = cmax(MAIN_BYTES, STAT_OFF + 16384);
 constexpr int NSLOT = HH * HW * 2;                  // 648 halo slots of 16 B (8 channels) per chunk
@@ -95,8 +99,9 @@ __device__ __forceinline__ void glds16s_x2(const void* sbase, unsigned voff, uns
                : "memory");
 }
 
-template <bool ACT, bool SKIP>
+template <bool ACT, bool SKIP, bool SC>
 __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
+  static_assert(!(SKIP && SC), "residual input and folded shortcut exclude each other in this kernel");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef FD_TIMING2
   const unsigned long long t2_entry = __builtin_amdgcn_s_memtime();
@@ -133,8 +138,9 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   const size_t img_elems = (size_t)H * W;
   // the (at most two) concat segments in scalar registers: no kernel-argument loads inside the K loop
   const bf16* const sb0 = reinterpret_cast<const bf16*>(p.seg[0].src) + (size_t)b * img_elems * p.seg[0].C;
-  const bf16* const sb1 = p.nseg > 1 ? reinterpret_cast<const bf16*>(p.seg[1].src) + (size_t)b * img_elems * p.seg[1].C : sb0;
-  const int sC0 = p.seg[0].C, sC1 = p.nseg > 1 ? p.seg[1].C : 0;
+  const bool two3 = p.nseg > 1 && p.seg[1].taps == 9;   // (segments with taps == 1 are the folded shortcut: epilogue phase E2)
+  const bf16* const sb1 = two3 ? reinterpret_cast<const bf16*>(p.seg[1].src) + (size_t)b * img_elems * p.seg[1].C : sb0;
+  const int sC0 = p.seg[0].C, sC1 = two3 ? p.seg[1].C : 0;
   const int nch0 = sC0 / CK, n3 = nch0 + sC1 / CK;
   const int hq = wave & 1;
   const bool pass1 = wave < 4;       // (the other waves request a duplicate in pass 1 -- every wave has the same number of
@@ -390,11 +396,18 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
 
   // ---- epilogue -------------------------------------------------------------------------------------------------------
   // Lane (l31, lh) of wave (cq, xt) holds, for cout block ct and tile block nt, acc[x][ct][nt][e]: cout ct * 128 + cq * 32 + 8 (e >> 2)
-  // + 4 lh + (e & 3) of tile nt * 32 + l31 (row nt * 8 + (l31 >> 2), pixels 4 (l31 & 3) .. + 3), position 3 xt + x.
-  //   xt = 0:  a0 = M0 + M1 + M2   a1 = M1 - M2   a2 = M1 + M2          y0 = a0 + b0   y1 = a1 + b1
-  //   xt = 1:  b0 = M3 + M4   b1 = 2 (M3 - M4)   b2 = 4 (M3 + M4)   b3 = 8 (M3 - M4) + M5     y2 = a2 + b2   y3 = a1 + b3
-  // xt = 0 finishes y0, y1 (receives b0, b1), xt = 1 finishes y2, y3 (receives a2, a1).  Four rounds (ct, nt): swap through LDS,
-  // stage the round's 128 pixels x 128 couts as [pixel plane j][tile][cout] f32, sweep with 8 couts (16 B of bf16) per lane.
+  // + 4 lh + (e & 3) of tile nt * 32 + l31 (row nt * 8 + (l31 >> 2), pixels 4 (l31 & 3) .. + 3); x = 0, 1, 2 are the positions
+  // 0, 1, 2 (xt = 0) or 5, 3, 4 (xt = 1).
+  //   E1  output transform.  Per (ct, nt): both wave groups run the same code with wave-uniform coefficients (a branch costs spilled
+  //       accumulator tiles):  s = m1 + m2, d = m1 - m2;  send0 = s, send1 = ke d;  ya = ka m0 + ks s + recv0,  yb = kb m0 + kd d + recv1
+  //         xt = 0 (m = M0, M1, M2): sends a2 = s, a1 = d;   y0 = M0 + s + b0,  y1 = d + b1             (ka ks kb kd ke = 1 1 0 1 1)
+  //         xt = 1 (m = M5, M3, M4): sends b0 = s, b1 = 2 d;  y2 = 4 s + a2,     y3 = M5 + 8 d + a1      (ka ks kb kd ke = 0 4 1 8 2)
+  //       the two waves of a cout block swap two planes through LDS (double-buffered: one barrier per round); afterwards wave (cq, xt)
+  //       holds the pixel planes j = 2 xt (in m0) and 2 xt + 1 (in m1) of its couts and all 64 tiles.
+  //   E2  (SC) the folded 1x1 shortcut conv Conv_2 (layerspp.py:278-279) as a bf16 GEMM straight into those planes: y[cout][pixel] +=
+  //       W[cout][k] x[k][pixel], v_mfma_f32_32x32x16_bf16 on the RAW residual stream (no fp16 conversion: the direct kernel's numerics).
+  //   E3  per (ct, nt): stage the round's 128 pixels x 128 couts as [pixel plane j][tile][cout] f32, sweep with 8 couts (16 B of bf16)
+  //       per lane: bias / residual / scale / statistics / store.
   bf16* const out = reinterpret_cast<bf16*>(p.out) + (size_t)b * img_elems * p.Cout;
   const bf16* const skip = SKIP ? reinterpret_cast<const bf16*>(p.skip) + (size_t)b * img_elems * p.Cout : nullptr;
   float* const biast = reinterpret_cast<float*>(smem + BIAS_OFF);      // [256] f32 (zeros without a bias)
@@ -417,74 +430,65 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
     }
   };
   skip_dma(0);
-  const float ka = xt ? 0.f : 1.f, ks = xt ? 4.f : 1.f, kb = xt ? 1.f : 0.f, kd = xt ? 8.f : 1.f, kq = xt ? 0.25f : 1.f;
-  float ssum[8], ssq[8];
+  skip_dma(1);
 #ifdef FD_TIMING2
   unsigned long long t2_r[5] = {0, 0, 0, 0, 0};
-#define W4_STAMP(i) if (rd_ == 0) t2_r[i] = __builtin_amdgcn_s_memtime();
-#else
-#define W4_STAMP(i)
+  t2_r[0] = __builtin_amdgcn_s_memtime();
 #endif
-#pragma unroll
-  for (int rd_ = 0; rd_ < 4; ++rd_) {
+
+  const float ka = xt ? 0.f : 1.f, ks = xt ? 4.f : 1.f, kb = xt ? 1.f : 0.f, kd = xt ? 8.f : 1.f, kq = xt ? 0.25f : 1.f;
+  // E1 of one round: partial transform, send, barrier, receive + combine (ya -> m0, yb -> m1); xoff = byte offset of the exchange buffer
+  auto e1_round = [&](int rd_, int xoff) {
     const int ct = rd_ >> 1, nt = rd_ & 1;
     f32x16 &m0 = acc[0][ct][nt], &m1 = acc[1][ct][nt], &m2 = acc[2][ct][nt];
+    const f32x2 kd2 = {kd, kd}, kq2 = {kq, kq}, ka2 = {ka, ka}, ks2 = {ks, ks}, kb2 = {kb, kb};
+    char* const xmine = smem + xoff + wave * 8192 + lane * 16;
+    const char* const xpeer = smem + xoff + (wave ^ 4) * 8192 + lane * 16;
+    // (two channels per instruction: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 on consecutive accumulator registers)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x2 snd[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = 4 * g + 2 * h;
+        const f32x2 a1 = {m1[e], m1[e + 1]}, a2 = {m2[e], m2[e + 1]};
+        const f32x2 s_ = a1 + a2, d_ = (a1 - a2) * kd2;
+        m2[e] = s_[0]; m2[e + 1] = s_[1];
+        m1[e] = d_[0]; m1[e + 1] = d_[1];
+        snd[h] = d_ * kq2;                                     // ke d = (ke / kd) kd d
+      }
+      *reinterpret_cast<f32x4*>(xmine + g * 1024) = f32x4{m2[4 * g], m2[4 * g + 1], m2[4 * g + 2], m2[4 * g + 3]};
+      *reinterpret_cast<f32x4*>(xmine + 4096 + g * 1024) = f32x4{snd[0][0], snd[0][1], snd[1][0], snd[1][1]};
+    }
+    lds_wait();
+    barrier();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 r0 = *reinterpret_cast<const f32x4*>(xpeer + g * 1024), r1 = *reinterpret_cast<const f32x4*>(xpeer + 4096 + g * 1024);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = 4 * g + 2 * h;
+        const f32x2 mm = {m0[e], m0[e + 1]}, ss = {m2[e], m2[e + 1]}, dd = {m1[e], m1[e + 1]};
+        const f32x2 q0 = {r0[2 * h], r0[2 * h + 1]}, q1 = {r1[2 * h], r1[2 * h + 1]};
+        const f32x2 ya = __builtin_elementwise_fma(ka2, mm, __builtin_elementwise_fma(ks2, ss, q0));
+        const f32x2 yb = __builtin_elementwise_fma(kb2, mm, dd + q1);
+        m0[e] = ya[0]; m0[e + 1] = ya[1];
+        m1[e] = yb[0]; m1[e + 1] = yb[1];
+      }
+    }
+  };
+  // E3 of one round: stage into sbuf (byte offset soff), barrier, sweep
+  float ssum[8], ssq[8];
+  auto e3_round = [&](int rd_, int soff) {
+    const int ct = rd_ >> 1, nt = rd_ & 1;
+    f32x16 &m0 = acc[0][ct][nt], &m1 = acc[1][ct][nt];
+    char* const sbuf = smem + soff;
     if (nt == 0) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) ssum[j] = ssq[j] = 0.f;
     }
-    W4_STAMP(0)
-    if (rd_ < 3) skip_dma(rd_ + 1);
-    // (a) partial output transform in place, (b) send two planes, (c) receive two planes and finish in place (ya -> m0, yb -> m1).
-    // Both wave groups run the same code with wave-uniform coefficients (a branch here costs two spilled accumulator tiles):
-    //   s = m1 + m2, d = m1 - m2;   send0 = s, send1 = ke d;   ya = ka m0 + ks s + recv0,  yb = kb m0 + kd d + recv1
-    //   xt = 0 (m = M0, M1, M2): sends a2 = s, a1 = d;   y0 = M0 + s + b0,  y1 = d + b1             (ka ks kb kd ke = 1 1 0 1 1)
-    //   xt = 1 (m = M5, M3, M4): sends b0 = s, b1 = 2 d;  y2 = 4 s + a2,     y3 = M5 + 8 d + a1      (ka ks kb kd ke = 0 4 1 8 2)
-    {   // (two channels per instruction: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 on consecutive accumulator registers)
-      char* const xmine = smem + wave * 8192 + lane * 16;
-      const f32x2 kd2 = {kd, kd}, kq2 = {kq, kq};
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x2 snd[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int e = 4 * g + 2 * h;
-          const f32x2 a1 = {m1[e], m1[e + 1]}, a2 = {m2[e], m2[e + 1]};
-          const f32x2 s_ = a1 + a2, d_ = (a1 - a2) * kd2;
-          m2[e] = s_[0]; m2[e + 1] = s_[1];
-          m1[e] = d_[0]; m1[e + 1] = d_[1];
-          snd[h] = d_ * kq2;                                     // ke d = (ke / kd) kd d
-        }
-        *reinterpret_cast<f32x4*>(xmine + g * 1024) = f32x4{m2[4 * g], m2[4 * g + 1], m2[4 * g + 2], m2[4 * g + 3]};
-        *reinterpret_cast<f32x4*>(xmine + 4096 + g * 1024) = f32x4{snd[0][0], snd[0][1], snd[1][0], snd[1][1]};
-      }
-    }
-    lds_wait();
-    barrier();
-    W4_STAMP(1)
     {
-      const char* const xpeer = smem + (wave ^ 4) * 8192 + lane * 16;
-      const f32x2 ka2 = {ka, ka}, ks2 = {ks, ks}, kb2 = {kb, kb};
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 r0 = *reinterpret_cast<const f32x4*>(xpeer + g * 1024), r1 = *reinterpret_cast<const f32x4*>(xpeer + 4096 + g * 1024);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int e = 4 * g + 2 * h;
-          const f32x2 mm = {m0[e], m0[e + 1]}, ss = {m2[e], m2[e + 1]}, dd = {m1[e], m1[e + 1]};
-          const f32x2 q0 = {r0[2 * h], r0[2 * h + 1]}, q1 = {r1[2 * h], r1[2 * h + 1]};
-          const f32x2 ya = __builtin_elementwise_fma(ka2, mm, __builtin_elementwise_fma(ks2, ss, q0));
-          const f32x2 yb = __builtin_elementwise_fma(kb2, mm, dd + q1);
-          m0[e] = ya[0]; m0[e + 1] = ya[1];
-          m1[e] = yb[0]; m1[e + 1] = yb[1];
-        }
-      }
-    }
-    lds_wait();
-    barrier();   // every wave has read its peer's planes: the exchange buffer becomes the staging buffer
-    W4_STAMP(2)
-    {
-      char* const sbase = smem + ((2 * xt) * 32 + l31) * S_PITCH + (cq * 32 + 4 * lh) * 4;
+      char* const sbase = sbuf + ((2 * xt) * 32 + l31) * S_PITCH + (cq * 32 + 4 * lh) * 4;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         *reinterpret_cast<f32x4*>(sbase + g * 32) = f32x4{m0[4 * g], m0[4 * g + 1], m0[4 * g + 2], m0[4 * g + 3]};
@@ -493,14 +497,12 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
     }
     lds_wait();
     barrier();
-    W4_STAMP(3)
     __builtin_amdgcn_sched_barrier(0);
     // sweep in two batches of two passes: computed into registers first, stores back to back afterwards.  The residual of this round
-    // is in SK[rd_ & 1]: older than the stores of the previous round and the DMA of the next one (8 operations may stay in flight).
+    // is in SK[rd_ & 1]; younger than its DMA are the stores of the previous round and the DMA issued after them.
     if constexpr (SKIP) {
-      if (rd_ == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (rd_ < 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (rd_ == 0 || rd_ == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     }
     {
       const int tt = opaque(t);
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
         for (int q = 0; q < 2; ++q) {
           const int ps = 2 * bt + q;
           ooff[q] = out_off(tt, ct, nt, ps);
-          const float* sp = reinterpret_cast<const float*>(smem + (pp + ps * 32) * S_PITCH) + oct * 8;
+          const float* sp = reinterpret_cast<const float*>(sbuf + (pp + ps * 32) * S_PITCH) + oct * 8;
           const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
           float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
           if constexpr (SKIP) {
@@ -560,13 +562,118 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
         for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(rec + 4 * j) = f32x4{ssum[2 * j], ssq[2 * j], ssum[2 * j + 1], ssq[2 * j + 1]};
       }
     }
+  };
+
+  if constexpr (SC) {
+    // ---- E1 for all rounds (exchange buffers alternate: one barrier per round; the buffer of round r is written again in round r + 2,
+    // and every wave has read it before it passes the barrier of round r + 1)
+#pragma unroll
+    for (int rd_ = 0; rd_ < 4; ++rd_) {
+      e1_round(rd_, (rd_ & 1) * X_BYTES);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     lds_wait();
-    barrier();   // the staging buffer is the next round's exchange buffer
-    W4_STAMP(4)
-    __builtin_amdgcn_sched_barrier(0);
+    barrier();   // all exchange reads done: the LDS below is reused
+#ifdef FD_TIMING2
+    t2_r[1] = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- E2: folded shortcut ----
+    {
+      // K = the S0 + S1 channels of the (at most two) shortcut segments, in stages of SCK MFMA K steps (16 channels each).  A stage of x
+      // is [K step][pixel plane j][tile][32 B] (row r = j * 64 + tile, halves swizzled by (r >> 3) & 1 like the V planes), filled by DMA:
+      // lane l of wave w fetches the 16 bytes that belong at (w * 64 + l) * 16 of a K step's 8 KiB -- the pixel order is made by the
+      // SOURCE addresses.  Weights [K step][cq][ct][32 couts][32 B] bf16 go to a private double buffer per wave (the two 1-KiB pieces
+      // ct = 0, 1 of a K step are consecutive).  One barrier per stage; everything for stage s + 1 is requested right after the barrier
+      // of stage s and awaited (vmcnt(0): nothing younger) before the next one.
+      const int nsc = p.nseg - (sC1 ? 2 : 1);   // shortcut segments follow the 3x3 segments
+      const Seg q0 = p.seg[p.nseg - nsc], q1 = p.seg[p.nseg - 1];
+      const int S0 = q0.C, Stot = S0 + (nsc > 1 ? q1.C : 0);
+      const int nstage = Stot / (16 * SCK);
+      const bf16* const xb0 = reinterpret_cast<const bf16*>(q0.src) + (size_t)b * img_elems * q0.C;
+      const bf16* const xb1 = reinterpret_cast<const bf16*>(q1.src) + (size_t)b * img_elems * q1.C;
+      const char* const wsc = reinterpret_cast<const char*>(p.w) + (size_t)(n3 + 1) * 18 * SLAB + cq * 2048;
+      // per-lane source of the stage DMA: row r = (w * 64 + lane) >> 1, position (lane & 1) holds channel half (lane & 1) ^ ((r >> 3) & 1)
+      const int xr = (wave * 64 + lane) >> 1;
+      const int xtile = xr & 63, xj = xr >> 6;
+      const int xpix = (h0 + (xtile >> 2)) * W + w0 + 4 * (xtile & 3) + xj;
+      const int xhalf16 = (((lane & 1) ^ ((xr >> 3) & 1)) * 16);
+      const unsigned lane16e = (unsigned)(lane * 16);
+      auto stage_dma = [&](int st) {   // x of stage st -> XS[st & 1], weights of stage st -> this wave's buffer st & 1
+        const int c0 = st * 16 * SCK;
+        const bool first = c0 < S0;
+        const bf16* const xb = first ? xb0 : xb1;
+        const int Cs = first ? S0 : Stot - S0, cc = first ? c0 : c0 - S0;
+        const unsigned voff = (unsigned)((xpix * Cs + cc) * 2 + xhalf16);
+  #pragma unroll
+        for (int kk = 0; kk < SCK; ++kk)
+          glds16s(xb, voff + kk * 32, (unsigned)(XS_OFF + (st & 1) * XS_BYTES + kk * 8192 + wave * 1024));
+  #pragma unroll
+        for (int kk = 0; kk < SCK; ++kk)
+          glds16s_x2(wsc + (size_t)(st * SCK + kk) * SLAB, lane16e, (unsigned)(wave * (2 * SCK * 2048) + ((st & 1) * SCK + kk) * 2048));
+      };
+      const int wa_sc = wave * (2 * SCK * 2048) + l31 * 32 + ((lh ^ ((l31 >> 3) & 1)) * 16);
+      const int xb_sc = XS_OFF + (2 * xt) * 2048 + l31 * 32 + ((lh ^ ((l31 >> 3) & 1)) * 16);
+      stage_dma(0);
+      for (int st = 0; st < nstage; ++st) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_wait();
+        barrier();
+        if (st + 1 < nstage) stage_dma(st + 1);
+        const int par = st & 1;
+  #pragma unroll
+        for (int kk = 0; kk < SCK; ++kk) {
+          const u32x4 a0 = rd(wa_sc + (par * SCK + kk) * 2048), a1 = rd(wa_sc + (par * SCK + kk) * 2048 + 1024);
+          u32x4 bq[2][2];   // [plane][nt]
+  #pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+  #pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bq[pl][nt] = rd(xb_sc + par * XS_BYTES + kk * 8192 + pl * 2048 + nt * 1024);
+  #pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+  #pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              acc[pl][0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bq[pl][nt]), acc[pl][0][nt], 0, 0, 0);
+              acc[pl][1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bq[pl][nt]), acc[pl][1][nt], 0, 0, 0);
+            }
+        }
+      }
+      lds_wait();
+      barrier();   // all fragment reads done: the staging buffers overlap the weight rings and the x stages
+    }
+#ifdef FD_TIMING2
+    t2_r[2] = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- E3 for all rounds (two staging buffers: one barrier per round)
+#pragma unroll
+    for (int rd_ = 0; rd_ < 4; ++rd_) {
+      e3_round(rd_, (rd_ & 1) * S_BYTES);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    // ---- rounds of E1 + E3.  Without a residual input the exchange buffer [0, 64 KiB) and the staging buffer behind it are separate:
+    // two barriers per round (the next round's exchange stores follow this round's staging barrier, its staging stores the next
+    // exchange barrier, which every wave reaches only after its sweep).  With one, the two residual buffers take that room: exchange
+    // and staging share the bytes, four barriers per round.
+#pragma unroll
+    for (int rd_ = 0; rd_ < 4; ++rd_) {
+      e1_round(rd_, 0);
+      if constexpr (SKIP) { lds_wait(); barrier(); }
+      e3_round(rd_, SKIP ? 0 : X_BYTES);
+      if constexpr (SKIP) {
+        lds_wait();
+        barrier();
+        if (rd_ < 2) skip_dma(rd_ + 2);   // SK[rd_ & 1] is free again
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
+#ifdef FD_TIMING2
+  t2_r[3] = __builtin_amdgcn_s_memtime();
+#endif
   if (p.stats) {
-    // o = 2 * channel + which = t;  channel = ct * 128 + oct * 8 + j  (the records were published by the last round's barrier)
+    lds_wait();
+    barrier();
+    // o = 2 * channel + which = t;  channel = ct * 128 + oct * 8 + j
     const int ch = t >> 1, which = t & 1;
     const int ct = ch >> 7, oc = (ch >> 3) & 15, j = ch & 7;
     const float* src = statt + (ct * 8 * 16 + oc) * 16 + 2 * j + which;
@@ -581,7 +688,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
     const unsigned long long t2_end = __builtin_amdgcn_s_memtime();
     unsigned long long* d = p.dbg + (size_t)bid * 8;
     d[0] = t2_first - t2_entry; d[1] = t2_loop - t2_first; d[2] = t2_end - t2_loop;
-    d[3] = t2_r[1] - t2_r[0]; d[4] = t2_r[2] - t2_r[1]; d[5] = t2_r[3] - t2_r[2]; d[6] = t2_r[4] - t2_r[3]; d[7] = t2_r[0] - t2_loop;
+    d[3] = t2_r[1] - t2_r[0]; d[4] = t2_r[2] - t2_r[1]; d[5] = t2_r[3] - t2_r[2]; d[6] = t2_end - t2_r[3]; d[7] = t2_r[0] - t2_loop;
   }
 #endif
 }
@@ -619,37 +726,76 @@ __global__ void wino4_pack_kernel(const float* __restrict__ w, f16* __restrict__
   }
 }
 
+// shortcut weights [Cout][S] f32 -> [K step of 16 channels][slab row n = [cq][ct][32]][32 B] bf16, halves swizzled by (n >> 3) & 1
+__global__ void wino4_pack_sc_kernel(const float* __restrict__ w, bf16* __restrict__ dst, int Cout, int S) {
+  const long long total = (long long)(S / CK) * BN * CK;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % CK);
+    long long r = i / CK;
+    const int n = (int)(r % BN);
+    const int ks = (int)(r / BN);
+    const int co = ((n >> 5) & 1) * 128 + (n >> 6) * 32 + (n & 31);
+    const float v = co < Cout ? w[(size_t)co * S + ks * CK + k] : 0.f;
+    const int half = (k >> 3) ^ ((n >> 3) & 1);
+    dst[(i - k) + half * 8 + (k & 7)] = (bf16)v;
+  }
+}
+
 }  // namespace
 
 bool fd_wino4_supported(int Cout, int C0, int C1, int S0, int S1, int ksize) {
-  return ksize == 3 && Cout == BN && C0 > 0 && C0 % 32 == 0 && C1 % 32 == 0 && S0 == 0 && S1 == 0 && (C0 + C1) * 8 <= AFF_BYTES;
+  return ksize == 3 && Cout == BN && C0 > 0 && C0 % 32 == 0 && C1 % 32 == 0 && S0 % 32 == 0 && S1 % 32 == 0 && (S1 == 0 || S0 > 0) &&
+         (C0 + C1) * 8 <= AFF_BYTES;
 }
 bool fd_wino4_shape_ok(int H, int W) { return H % TH == 0 && W % TW == 0; }
 
 long long fd_wino4_packed_bytes(int Cout, int C0, int C1, int S0, int S1) {
-  (void)Cout; (void)S0; (void)S1;
-  return (long long)((C0 + C1) / CK + 1) * 18 * SLAB + 16 * 1024;   // + one chunk: the weight stream runs a ring length past the last step
+  (void)Cout;
+  // 3x3 part + one chunk (the weight stream runs a ring length past the last step), then the shortcut K steps
+  return (long long)((C0 + C1) / CK + 1) * 18 * SLAB + (long long)((S0 + S1) / CK) * SLAB + 16 * 1024;
 }
 
 int fd_wino4_pack_weights(const float* w, const float* w_sc, void* packed, int Cout, int C0, int C1, int S0, int S1, hipStream_t st) {
-  (void)w_sc; (void)S0; (void)S1;
   const long long total = (long long)((C0 + C1) / CK) * 18 * BN * CK;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(wino4_pack_kernel, dim3(blocks), dim3(256), 0, st, w, (f16*)packed, Cout, C0, C1);
+  if (w_sc) {
+    const long long tsc = (long long)((S0 + S1) / CK) * BN * CK;
+    const int bsc = (int)((tsc + 255) / 256 > 4096 ? 4096 : (tsc + 255) / 256);
+    hipLaunchKernelGGL(wino4_pack_sc_kernel, dim3(bsc), dim3(256), 0, st, w_sc,
+                       reinterpret_cast<bf16*>(reinterpret_cast<char*>(packed) + (size_t)((C0 + C1) / CK + 1) * 18 * SLAB), Cout, S0 + S1);
+  }
   FD_LAUNCH_CHECK();
   return FD_OK;
 }
 
+namespace {
+template <bool ACT>
+int set_attr4() {
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<ACT, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<ACT, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<ACT, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  return FD_OK;
+}
+template <bool ACT>
+void launch4(const ConvArgs& a, bool sc, dim3 grid, dim3 block, hipStream_t st) {
+  if (sc) hipLaunchKernelGGL((conv_wino4_kernel<ACT, false, true>), grid, block, LDS_BYTES, st, a);
+  else if (a.skip) hipLaunchKernelGGL((conv_wino4_kernel<ACT, true, false>), grid, block, LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((conv_wino4_kernel<ACT, false, false>), grid, block, LDS_BYTES, st, a);
+}
+}  // namespace
+
 int fd_wino4_init_attributes() {
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  FD_TRY(set_attr4<false>());
+  FD_TRY(set_attr4<true>());
   return FD_OK;
 }
 
 int fd_wino4_launch(ConvArgs a, hipStream_t st) {
   FD_REQUIRE(fd_wino4_shape_ok(a.H, a.W), "fd_conv2d: FD_WINOGRAD4 needs H %% 16 == 0 and W %% 16 == 0 (got %d x %d)", a.H, a.W);
+  bool sc = false;
+  for (int s = 0; s < a.nseg; ++s) sc = sc || a.seg[s].taps == 1;
+  FD_REQUIRE(!(sc && a.skip), "fd_conv2d: FD_WINOGRAD4 takes a folded shortcut or a residual input, not both");
   a.tiles_h = a.H / TH;
   a.tiles_w = a.W / TW;
   a.tiles_n = 1;
@@ -657,13 +803,8 @@ int fd_wino4_launch(ConvArgs a, hipStream_t st) {
   const long long nblk = (long long)a.B * a.tiles_h * a.tiles_w;
   FD_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
   const dim3 grid((unsigned)nblk), block(NTH);
-  if (a.affine) {
-    if (a.skip) hipLaunchKernelGGL((conv_wino4_kernel<true, true>), grid, block, LDS_BYTES, st, a);
-    else hipLaunchKernelGGL((conv_wino4_kernel<true, false>), grid, block, LDS_BYTES, st, a);
-  } else {
-    if (a.skip) hipLaunchKernelGGL((conv_wino4_kernel<false, true>), grid, block, LDS_BYTES, st, a);
-    else hipLaunchKernelGGL((conv_wino4_kernel<false, false>), grid, block, LDS_BYTES, st, a);
-  }
+  if (a.affine) launch4<true>(a, sc, grid, block, st);
+  else launch4<false>(a, sc, grid, block, st);
   FD_LAUNCH_CHECK();
   return FD_OK;
 }
