@@ -59,7 +59,10 @@ constexpr int VXI = HH * 4 * 32;                    // one position plane: [18 h
 constexpr int V_BYTES = 6 * VXI;                    // 13824
 constexpr int V_OFF = RING_BYTES;
 constexpr int Z_OFF = V_OFF + 2 * V_BYTES;
-constexpr int Z_BYTES = HH * HW * 32;               // activated halo, [18][18][32 B]
+constexpr int ZROW = HW + 4;                        // z row: halo column c at position c + (c >> 2) (one pad slot per four columns), 22 slots
+constexpr int ZPLANE = HH * ZROW * 16;              // 6336 = 64 (mod 128): the two channel-half planes are 16 banks apart
+constexpr int Z_BYTES = 2 * ZPLANE;                 // activated halo, [channel half 2][18 rows][22 slots][16 B]: conflict-free for the
+                                                    // wave-uniform-half stores of the conversion AND the word-wise reads of the transform
 constexpr int RAW_OFF = Z_OFF + Z_BYTES;            // raw halo (bf16) as the DMA delivers it: slot s at s * 16, padded to 1024 slots
 constexpr int RAW_BYTES = 2 * NTH * 16;
 constexpr int MAIN_BYTES = RAW_OFF + RAW_BYTES;     // 152704
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
     const int gh = h0 - 1 + hr, gw = w0 - 1 + hc;
     const bool ok = gh >= 0 && gh < H && gw >= 0 && gw < W;
     hpix[i] = ok ? gh * W + gw : 0;
-    zadr[i] = (has ? i * 8192 : 0) + t * 16 + ((hp * 32 + hq * 16) << 16);   // low half: RAW slot offset, high half: z offset
+    zadr[i] = (has ? i * 8192 : 0) + t * 16 + ((hq * ZPLANE + (hr * ZROW + hc + (hc >> 2)) * 16) << 16);   // low half: RAW slot offset, high half: z offset
     if (ok) hvalid |= 1u << i;
   }
   // state of the chunk whose halo is in flight / being converted (wave-uniform)
@@ -191,7 +194,8 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   };
   // one slot: RAW (bf16) -> [silu(a x + d)] -> fp16 -> z, zero padding AFTER the activation (an AND: no branch)
   auto conv_slot = [&](int i) {
-    const u32x4 raw = *reinterpret_cast<const u32x4*>(smem + RAW_OFF + (zadr[i] & 0xffff));
+    const int za = opaque(zadr[i]);
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(smem + RAW_OFF + (za & 0xffff));
     const unsigned vm = ((hvalid >> i) & 1u) ? 0xffffffffu : 0u;
     u32x4 o;
 #pragma unroll
@@ -204,26 +208,29 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
         r = pack_f16(__builtin_amdgcn_fmed3f(x0, -RAW_MAX, RAW_MAX), __builtin_amdgcn_fmed3f(x1, -RAW_MAX, RAW_MAX));
       o[j] = r & vm;
     }
-    *reinterpret_cast<u32x4*>(smem + Z_OFF + ((unsigned)zadr[i] >> 16)) = o;
+    *reinterpret_cast<u32x4*>(smem + Z_OFF + ((unsigned)za >> 16)) = o;
   };
 
-  // ---- input transform z -> V planes.  Item = (halo row, tile, 4-channel group): 288 of them; wave group xt transforms channel pair
-  // k = xt of every item (two channels: 6 words in, 6 words out): its 256 threads take item t & 255, and one wave of the group the
-  // 32 items 256 .. 287 a step later
-  auto item_z = [&](int item, int k) { return Z_OFF + ((item >> 4) * HW + 4 * ((item >> 2) & 3)) * 32 + (item & 3) * 8 + k * 4; };
-  auto item_v = [&](int item, int k) {
-    const int tg = item & 3, tidx = (item >> 4) * 4 + ((item >> 2) & 3);
-    return V_OFF + tidx * 32 + (((tg >> 1) ^ ((tidx >> 3) & 1)) * 16) + (tg & 1) * 8 + k * 4;
+  // ---- input transform z -> V planes, two channels (one 32-bit word) per lane: 6 words in, 6 words out.  Lane l of a 32-lane group
+  // takes word l & 7 (channel pair) of tile l >> 3 of ONE halo row: the group's reads cover four 16-byte slots per channel half that
+  // the z layout keeps in distinct banks, its stores 128 contiguous bytes of a V plane -- no bank conflicts (the first version's
+  // item order cost 430 LDS cycles per chunk in conflicts, SQ_LDS_BANK_CONFLICT).  Halo rows 0..15 = the sixteen 32-lane groups of
+  // the workgroup (rows 0..7 wave group 0, rows 8..15 wave group 1), rows 16, 17 = the two halves of wave 1 one step later.
+  auto item_z = [&](int hrow, int wt, int word) { return Z_OFF + (word >> 2) * ZPLANE + (hrow * ZROW + 5 * wt) * 16 + (word & 3) * 4; };
+  auto item_v = [&](int hrow, int wt, int word) {
+    const int tidx = hrow * 4 + wt;
+    return V_OFF + tidx * 32 + (((word >> 2) ^ ((tidx >> 3) & 1)) * 16) + (word & 3) * 4;
   };
-  const int tz0 = item_z(t & 255, xt), tv0 = item_v(t & 255, xt);
+  const int tz0 = item_z(t >> 5, (t >> 3) & 3, t & 7), tv0 = item_v(t >> 5, (t >> 3) & 3, t & 7);
   auto transform_at = [&](int za, int va, int vbuf) {
-    const char* const zp = smem + za;
-    char* const vb = smem + va + vbuf * V_BYTES;
+    // (opaque: hipcc otherwise hoists one address register per plane and buffer out of the K loop -- twelve registers it does not have)
+    const char* const zp = smem + opaque(za);
+    char* const vb = smem + opaque(va) + vbuf * V_BYTES;
     const f16x2 c4 = {(f16)4.f, (f16)4.f}, cm4 = {(f16)-4.f, (f16)-4.f}, cm5 = {(f16)-5.f, (f16)-5.f}, c2 = {(f16)2.f, (f16)2.f},
                 cm2 = {(f16)-2.f, (f16)-2.f};
     unsigned w_[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) w_[j] = *reinterpret_cast<const unsigned*>(zp + j * 32);
+    for (int j = 0; j < 6; ++j) w_[j] = *reinterpret_cast<const unsigned*>(zp + (j + (j >> 2)) * 16);   // halo column 4 wt + j
     const f16x2 z0 = h2(w_[0]), z1 = h2(w_[1]), z2 = h2(w_[2]), z3 = h2(w_[3]), z4 = h2(w_[4]), z5 = h2(w_[5]);
     const f16x2 t1 = __builtin_elementwise_fma(z2, cm4, z4);   // z4 - 4 z2
     const f16x2 t2 = __builtin_elementwise_fma(z1, cm4, z3);   // z3 - 4 z1
@@ -236,10 +243,9 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
     *reinterpret_cast<unsigned*>(vb + 5 * VXI) = u2(__builtin_elementwise_fma(t4, cm2, t3));                                      // xi = 4
     *reinterpret_cast<unsigned*>(vb + 3 * VXI) = u2(__builtin_elementwise_fma(z1, c4, __builtin_elementwise_fma(z3, cm5, z5)));   // xi = 5
   };
-  // the wave of each group that takes the 32 extra items: wave 1 (group 0, SIMD 2) and wave 6 (group 1, SIMD 1), lanes 0..31
-  const bool extra_wave = wave == 1 || wave == 6;
+  const bool extra_wave = wave == 1;
   auto transform_extra = [&](int vbuf) {
-    if (extra_wave && lane < 32) transform_at(item_z(256 + lane, xt), item_v(256 + lane, xt), vbuf);
+    if (extra_wave) transform_at(item_z(16 + (lane >> 5), (lane >> 3) & 3, lane & 7), item_v(16 + (lane >> 5), (lane >> 3) & 3, lane & 7), vbuf);
   };
 
   // ---- weight stream: this wave's 2 KiB (cout blocks ct = 0, 1: two consecutive 1-KiB pieces) of its step f -> ring slot f % NRING.
@@ -326,8 +332,8 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   // the previous chunk have read it) and the barrier of step 3; the transforms run between the barrier of step 3 and that of step 8.
   // The two waves of a SIMD (groups xt = 0 / 1) do this vector work in DIFFERENT steps:
   //   group 0: pass 0 converted in step 8 (of the previous chunk), pass 1 in step 0, next halo + affine requested in step 1,
-  //            transform in step 4 (channel pair 0), the 32 extra items in step 5 (wave 1)
-  //   group 1: conversions in steps 1 and 2, request in step 3, transform in step 5 (channel pair 1), extra items in step 6 (wave 6)
+  //            transform of halo rows 0..7 in step 4, of rows 16, 17 in step 5 (wave 1)
+  //   group 1: conversions in steps 1 and 2, request in step 3, transform of halo rows 8..15 in step 5
   // A step starts with a counted wait for the weights of the NEXT step (its first fragments are requested right away); in flight on
   // this wave's vector-memory counter at that wait, oldest first: the weight pieces of steps s + 1 .. s + 5 (2 each) and, in the five
   // steps after the halo request, its two pieces: vmcnt(8 / 10).  The weights of step s + 6 are requested after the third MFMA of step
@@ -380,7 +386,6 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
 #ifndef W4_EXP_NO_TRANS
       if (s == 4) { if (xg == 0) transform_at(tz0, tv0, vn); }
       if (s == 5) { if (xg == 1) transform_at(tz0, tv0, vn); else transform_extra(vn); }
-      if (s == 6) { if (xg == 1) transform_extra(vn); }
 #endif
 #endif
       __builtin_amdgcn_sched_barrier(0);
