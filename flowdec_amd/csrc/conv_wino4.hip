@@ -148,25 +148,35 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   const int hq = wave & 1;
   const bool pass1 = wave < 4;       // (the other waves request a duplicate in pass 1 -- every wave has the same number of
                                      //  vector-memory operations in flight -- and skip its conversion)
-  // per-lane halo constants: pixel index inside the image (0 when outside: the load is harmless, the value is masked), validity,
-  // z address.  Lanes without a pixel in pass 1 redo pass 0 (same load, same bytes to the same z address).
+  // per-lane halo constants.  REQUEST side: lane l of wave w fetches slot s = t (+ 512 in pass 1) = (pixel s >> 1, half s & 1): two
+  // adjacent lanes share a pixel's 32 bytes (one memory request instead of two), the slot lands at RAW + s * 16.  CONVERSION side: the
+  // wave converts half hq of the pixels hp(i): RAW slot (hp * 2 + hq), written by another lane -- hence the ordering "request after
+  // the barrier of step 3 (every conversion of the previous halo is done), landed before the barrier of step 8 (every wave waits for
+  // its own requests first), converted after it".  Pixels outside the image: the request reads pixel 0 (harmless), the conversion
+  // masks the value.  Lanes without a pixel in pass 1 redo pass 0 (same bytes to the same z address).
   int hpix[2], zadr[2];
   unsigned hvalid = 0;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    {   // request side
+      const int sl = t + i * NTH;
+      const int hp = sl < NSLOT ? sl >> 1 : 0;
+      const int hr = hp / HW, hc = hp - hr * HW;
+      const int gh = h0 - 1 + hr, gw = w0 - 1 + hc;
+      hpix[i] = (gh >= 0 && gh < H && gw >= 0 && gw < W) ? gh * W + gw : 0;
+    }
     const int base = ((t >> 7) << 6) + lane;
     const bool has = i == 0 || base + 256 < HH * HW;
     const int hp = has ? base + i * 256 : base;
     const int hr = hp / HW, hc = hp - hr * HW;
     const int gh = h0 - 1 + hr, gw = w0 - 1 + hc;
     const bool ok = gh >= 0 && gh < H && gw >= 0 && gw < W;
-    hpix[i] = ok ? gh * W + gw : 0;
-    zadr[i] = (has ? i * 8192 : 0) + t * 16 + ((hq * ZPLANE + (hr * ZROW + hc + (hc >> 2)) * 16) << 16);   // low half: RAW slot offset, high half: z offset
+    zadr[i] = (hp * 2 + hq) * 16 + ((hq * ZPLANE + (hr * ZROW + hc + (hc >> 2)) * 16) << 16);   // low half: RAW slot offset, high half: z offset
     if (ok) hvalid |= 1u << i;
   }
   // state of the chunk whose halo is in flight / being converted (wave-uniform)
   const bf16* nbase = sb0;
-  int nC2 = 0, ncb = 0;              // bytes per pixel, byte offset of this wave's 8 channels inside a pixel
+  int nC2 = 0, ncb = 0;              // bytes per pixel, byte offset of the chunk's 16 channels inside a pixel
   int cnext = 0;                     // index of the next chunk to request
   f32x16 aff;                        // (a, d) x 8 channels of the chunk being converted (scalar registers)
   const float* const affp = ACT ? p.affine + ((size_t)b * p.affC + hq * 8) * 2 : nullptr;
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
       const int cch = first ? cnext : cnext - nch0;
       nbase = first ? sb0 : sb1;
       nC2 = (first ? sC0 : sC1) * 2;
-      ncb = (cch * CK + hq * 8) * 2;
+      ncb = cch * CK * 2;
       if constexpr (ACT)             // affine table = [C0 + C1] pairs in concat order (fd_conv2d: aff_off = 0 / C0)
         asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(aff) : "s"(affp + (size_t)cnext * CK * 2) : "memory");
     }
@@ -189,8 +199,9 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   const unsigned rawdst = (unsigned)(RAW_OFF + wave * 1024);
   auto load_halo = [&]() {
     const int on = cnext <= n3 ? 1 : 0;   // (next_chunk has already counted this request)
-    glds16s(nbase, (unsigned)((hpix[0] * nC2 + ncb) * on), rawdst);
-    glds16s(nbase, (unsigned)((hpix[1] * nC2 + ncb) * on), rawdst + 8192);
+    const int h16 = (opaque(t) & 1) * 16;
+    glds16s(nbase, (unsigned)((hpix[0] * nC2 + ncb + h16) * on), rawdst);
+    glds16s(nbase, (unsigned)((hpix[1] * nC2 + ncb + h16) * on), rawdst + 8192);
   };
   // one slot: RAW (bf16) -> [silu(a x + d)] -> fp16 -> z, zero padding AFTER the activation (an AND: no branch)
   auto conv_slot = [&](int i) {
@@ -309,12 +320,13 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   for (int k = 0; k < NRING; ++k) dma_step(k, k);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   aff_wait();
+  barrier();                // every lane's halo slots have landed
   conv_slot(0);
   if (pass1) conv_slot(1);
   next_chunk();
   lds_wait();
-  load_halo();              // halo of chunk 1: this lane's RAW slots are free again
-  barrier();
+  barrier();                // z complete; every conversion has read its RAW slots
+  load_halo();              // halo of chunk 1
   transform_at(tz0, tv0, 0);
   transform_extra(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -331,9 +343,10 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   // into V[(c + 1) & 1], and the halo of chunk c + 2 is requested.  z may be written between the barrier of step 8 (all transforms of
   // the previous chunk have read it) and the barrier of step 3; the transforms run between the barrier of step 3 and that of step 8.
   // The two waves of a SIMD (groups xt = 0 / 1) do this vector work in DIFFERENT steps:
-  //   group 0: pass 0 converted in step 8 (of the previous chunk), pass 1 in step 0, next halo + affine requested in step 1,
-  //            transform of halo rows 0..7 in step 4, of rows 16, 17 in step 5 (wave 1)
-  //   group 1: conversions in steps 1 and 2, request in step 3, transform of halo rows 8..15 in step 5
+  //   group 0: pass 0 converted in step 8 (of the previous chunk), pass 1 in step 0, transform of halo rows 0..7 in step 4, of rows
+  //            16, 17 in step 5 (wave 1)
+  //   group 1: conversions in steps 1 and 2, transform of halo rows 8..15 in step 5
+  //   both:    next halo + affine requested in step 3
   // A step starts with a counted wait for the weights of the NEXT step (its first fragments are requested right away); in flight on
   // this wave's vector-memory counter at that wait, oldest first: the weight pieces of steps s + 1 .. s + 5 (2 each) and, in the five
   // steps after the halo request, its two pieces: vmcnt(8 / 10).  The weights of step s + 6 are requested after the third MFMA of step
@@ -351,10 +364,9 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
       const int xl = s / 3;
       u32x4 &A0 = qa[(2 * k) % 3], &A1 = qa[(2 * k + 1) % 3], &A2 = qa[(2 * k + 2) % 3];
       u32x4 &B0 = qb[(2 * k) % 3], &B1 = qb[(2 * k + 1) % 3], &B2 = qb[(2 * k + 2) % 3];
-      // halo request in step h: its pieces are younger than the awaited weights in steps h + 1 .. h + 5
-      if (s >= 2 && s <= 3) { if (xg == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW + 2) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory"); }
-      else if (s >= 4 && s <= 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW + 2) : "memory");
-      else if (s >= 7) { if (xg == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW + 2) : "memory"); }
+      // the halo request of step 3 (issued BEFORE that step's weight request) is younger than the awaited weights in steps 4 .. 7 and
+      // older than those of step 8: that wait also covers it, and the barrier behind it publishes the RAW slots
+      if (s >= 4 && s <= 7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW + 2) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
       if (s == 3 || s == 8) { lds_wait(); barrier(); }   // s == 3: z complete;  s == 8: V[vn] complete, every wave has its last V[vc] fragments
       A2 = rd(a_off(k + 1, 0));
@@ -367,12 +379,12 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
       mma(xl, 1, 0, A1, B0);
       __builtin_amdgcn_sched_barrier(0);
       B0 = rd(b_off(k + 1, 1));
-      dma_step(k + NRING, k % NRING);              // step s + 6 into the slot whose fragments have both arrived
 #ifndef W4_EXP_NO_PROD
 #ifndef W4_EXP_NO_HALO
-      if ((s == 1 && xg == 0) || (s == 3 && xg == 1)) { next_chunk(); load_halo(); }
+      if (s == 3) { next_chunk(); load_halo(); }   // (after the barrier of this step: every conversion of the previous halo is done)
 #endif
 #endif
+      dma_step(k + NRING, k % NRING);              // step s + 6 into the slot whose fragments have both arrived
       mma(xl, 1, 1, A1, B1);
       __builtin_amdgcn_sched_barrier(0);
       // the chunk's vector work, while the quads A1 / B1 are dead
