@@ -368,10 +368,15 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
       // older than those of step 8: that wait also covers it, and the barrier behind it publishes the RAW slots
       if (s >= 4 && s <= 7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW + 2) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
+#ifndef W4_EXP_NO_BAR
       if (s == 3 || s == 8) { lds_wait(); barrier(); }   // s == 3: z complete;  s == 8: V[vn] complete, every wave has its last V[vc] fragments
+#endif
       A2 = rd(a_off(k + 1, 0));
       B2 = rd(b_off(k + 1, 0));
       __builtin_amdgcn_sched_barrier(0);
+#ifdef W4_EXP_PRIO
+      __builtin_amdgcn_s_setprio(2);
+#endif
       mma(xl, 0, 0, A0, B0);
       mma(xl, 0, 1, A0, B1);
       __builtin_amdgcn_sched_barrier(0);
@@ -386,6 +391,9 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
 #endif
       dma_step(k + NRING, k % NRING);              // step s + 6 into the slot whose fragments have both arrived
       mma(xl, 1, 1, A1, B1);
+#ifdef W4_EXP_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       __builtin_amdgcn_sched_barrier(0);
       // the chunk's vector work, while the quads A1 / B1 are dead
 #ifndef W4_EXP_NO_PROD

@@ -35,12 +35,22 @@ def _world(group=None):
     return 1, 0
 
 
+def _needs_host_staging(group=None) -> bool:
+    """True when the group's collectives cannot take device tensors (gloo).  Composite backend strings such as
+    'cpu:gloo,cuda:nccl' carry a device backend: only a plain 'gloo' group has none."""
+    import torch.distributed as dist
+    b = str(dist.get_backend(group)).lower()
+    return "nccl" not in b and "cuda:" not in b
+
+
 def all_gather_shards(local: torch.Tensor, n_items: int, group=None) -> torch.Tensor:
     """Rank r holds items shard_range(n_items, r, world) of a [n_items, ...] tensor -> the whole tensor on every rank.
     One `all_gather_into_tensor` into a [world, max_shard, ...] buffer; with an even split the result is a view of that
     buffer (no further copy), with an uneven one the padding rows are dropped by one index_select.  Runs the collective
     even at world size 1 when a process group exists (that is how the RCCL path is exercised on a 1-GPU box)."""
     import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("all_gather_shards needs an initialised process group (torch.distributed.init_process_group)")
     world, rank = _world(group)
     sizes = shard_sizes(n_items, world)
     assert local.shape[0] == sizes[rank], f"rank {rank}: local shard has {local.shape[0]} items, expected {sizes[rank]}"
@@ -50,7 +60,7 @@ def all_gather_shards(local: torch.Tensor, n_items: int, group=None) -> torch.Te
     else:
         send = local.new_zeros((pad,) + tail)
         send[: local.shape[0]] = local
-    if send.is_cuda and dist.get_backend(group) == "gloo":   # gloo moves host memory: stage device tensors through the host
+    if send.is_cuda and _needs_host_staging(group):   # gloo moves host memory: stage device tensors through the host
         out = send.new_empty((world * pad,) + tail, device="cpu")
         dist.all_gather_into_tensor(out, send.cpu(), group=group)
         out = out.to(send.device)
@@ -122,13 +132,19 @@ def sharded_enhance(model, y: torch.Tensor, N: int = 50, solver: str = "euler", 
             n_freq, T = cfg["n_fft"] // 2 + 1, 1 + Lw // cfg["hop"]      # fd_num_frames / fd_padded_frames (pad_spec: multiple of 64)
             Tp = 64 * ((T + 63) // 64)
             if generator is not None:
-                nz = torch.randn((B, 1, n_freq, Tp), dtype=torch.complex64, device=dev, generator=generator)[lo:hi]
+                nz = _full_draw(generator, B, n_freq, Tp, dev)[lo:hi]
             else:
                 if seed is None:
                     seed = _shared_seed(dev, group)
                 nz = torch.stack([clip_noise(seed, i, (1, n_freq, Tp), dev) for i in range(lo, hi)])
         local = model.enhance(yl, N=N, solver=solver, noise=nz, **enhance_kwargs)
-    elif noise is None and generator is None and seed is None:
+    elif noise is None and generator is not None:
+        # idle rank (fewer clips than ranks): draw and discard the full noise, so that the generators of all ranks stay identical for
+        # the next call -- the contract of `generator=`
+        cfg = model.feature_extractor._cfg()
+        T = 1 + Lw // cfg["hop"]
+        _full_draw(generator, B, cfg["n_fft"] // 2 + 1, 64 * ((T + 63) // 64), dev)
+    elif noise is None and seed is None:
         _shared_seed(dev, group)   # idle rank: still takes part in the seed broadcast
     if stats is not None:
         if dev.type == "cuda":
@@ -138,6 +154,9 @@ def sharded_enhance(model, y: torch.Tensor, N: int = 50, solver: str = "euler", 
     if world == 1 and not always_gather:
         out = local
     else:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("sharded_enhance(always_gather=True) needs an initialised process group")
         if local is None:
             local = torch.empty((0, 1, Lw), dtype=torch.float32, device=dev)
         out = all_gather_shards(local, B, group)
@@ -150,13 +169,17 @@ def sharded_enhance(model, y: torch.Tensor, N: int = 50, solver: str = "euler", 
     return out
 
 
+def _full_draw(generator: torch.Generator, B: int, n_freq: int, Tp: int, dev) -> torch.Tensor:
+    """The [B, 1, F, T_pad] complex64 noise of the whole global batch from `generator` (on the generator's device)."""
+    return torch.randn((B, 1, n_freq, Tp), dtype=torch.complex64, device=generator.device, generator=generator).to(dev)
+
+
 def _shared_seed(dev, group=None) -> int:
     """A fresh seed that every rank agrees on (rank 0 draws, one 8-byte broadcast)."""
     import torch.distributed as dist
     world, rank = _world(group)
     s = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
     if world > 1:
-        backend = dist.get_backend(group)
-        s = s.to(dev) if backend == "nccl" else s
+        s = s if _needs_host_staging(group) else s.to(dev)
         dist.broadcast(s, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     return int(s.item())

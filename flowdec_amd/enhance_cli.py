@@ -56,7 +56,14 @@ class FileList:
         return self.clean is not None
 
 
-_PAIR_SEP = re.compile(r" ---> |,")
+def _split_pair(entry: str) -> List[str]:
+    """`clean ---> coded` if the arrow is present, else `clean,coded` if a comma is (the reference's precedence, enhance.py:153-158:
+    a path with commas in an arrow line is not cut at the comma)."""
+    if " ---> " in entry:
+        return entry.split(" ---> ")
+    if "," in entry:
+        return entry.split(",")
+    return [entry]
 
 
 def read_list(listfile: str) -> FileList:
@@ -69,8 +76,10 @@ def read_list(listfile: str) -> FileList:
             entry = raw.strip()
             if not entry:
                 continue
-            parts = _PAIR_SEP.split(entry)
-            if len(parts) >= 2:
+            parts = _split_pair(entry)
+            if len(parts) > 2:
+                raise ValueError(f"{listfile}:{lineno}: {len(parts)} fields in a pair line (expected `clean ---> coded` or `clean,coded`)")
+            if len(parts) == 2:
                 if out.clean is None:
                     if out.inputs:
                         raise ValueError(f"{listfile}:{lineno}: pair line after plain paths -- inconsistent file list format")
@@ -256,7 +265,30 @@ def collect_files(files: str, single_file: bool) -> Tuple[List[str], Optional[Li
     return sorted(glob.glob(f"{files}/*.wav")), None
 
 
+@dataclass
+class RunResult:
+    """What a CLI run did: files enhanced, files skipped because they exceed the length limit of the chosen precision (but not the
+    reference's 30 s), files skipped as too long for the reference as well."""
+    n_done: int = 0
+    n_over_precision_limit: int = 0
+    n_too_long: int = 0
+
+    @property
+    def exit_code(self) -> int:
+        return 3 if self.n_over_precision_limit else 0
+
+
 def main(argv=None, model: Optional[FlowModel] = None) -> int:
+    """Runs the CLI and returns the number of files enhanced (the detailed result: `run()`)."""
+    return run(argv, model).n_done
+
+
+def cli(argv=None) -> int:
+    """Console entry point: exit status 0, or 3 when files were skipped only because of the chosen precision's length limit."""
+    return run(argv).exit_code
+
+
+def run(argv=None, model: Optional[FlowModel] = None) -> RunResult:
     args = build_parser().parse_args(argv)
     os.makedirs(args.outdir, exist_ok=True)
     if model is None:
@@ -274,7 +306,7 @@ def main(argv=None, model: Optional[FlowModel] = None) -> int:
     gen = None
     if args.seed is not None:
         gen = torch.Generator(device=model.device).manual_seed(args.seed)
-    n_done = n_over_precision_limit = 0
+    res = RunResult()
     # one image must stay below 2 GiB (32-bit buffer offsets of the conv kernel): ~43 s in bf16, ~21 s with f32 storage
     max_seconds = MAX_SECONDS if args.precision == "bf16" else min(MAX_SECONDS, 20.0)
     print(f"flowdec_amd: precision={args.precision} ({PRECISION_NOTE[args.precision]}), solver={args.solver}, N={args.N}")
@@ -306,19 +338,18 @@ def main(argv=None, model: Optional[FlowModel] = None) -> int:
                         print(runtime, filetime, "-> rtf =", runtime / filetime)
                         print(f"{out_path},{runtime:.5f},{filetime:.5f},{runtime / filetime:.5f}", file=rtf_f)
                     save_wav(out_path, x_hat.cpu(), sr)
-                    n_done += 1
+                    res.n_done += 1
                 elif y.shape[-1] / sr <= MAX_SECONDS:
-                    n_over_precision_limit += 1
+                    res.n_over_precision_limit += 1
                     print(f"Skipping file: {y.shape[-1] / sr:.1f} s exceeds the {max_seconds:g} s limit of precision={args.precision} "
                           f"(the reference's limit is {MAX_SECONDS:g} s; use --precision bf16 for files up to it):", path)
                 else:
+                    res.n_too_long += 1
                     print("Skipping file due to length:", path)
             if trf is not None:
                 print(f"{clean[i]} ---> {noisy[i]} ---> {out_path}", file=trf)
-    main.skipped_over_precision_limit = n_over_precision_limit
-    return n_done
+    return res
 
 
 if __name__ == "__main__":
-    main()
-    sys.exit(3 if getattr(main, "skipped_over_precision_limit", 0) else 0)
+    sys.exit(cli())

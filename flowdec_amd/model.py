@@ -63,6 +63,12 @@ class Combine(nn.Module):
 DEFAULT_OUTPUTLAYER_KWARGS = dict(kernel_size=3, bias=False, padding="same", padding_mode="zeros")
 # 3x3 convolution algorithm of the bf16 mode: direct MFMA implicit GEMM, Winograd F(2,3) wherever the shape allows it, or
 # Winograd only at the low-resolution levels, or chosen per launch by grid fill ('auto'; include/flowdec_hip.h: FD_WINOGRAD*)
+# Tolerances of the adaptive solvers when enhance() gets none: the reference builds `NeuralODE(node_fn, solver=solver, sensitivity=
+# 'adjoint')` WITHOUT tolerances (flowdec/model.py:503-515), i.e. it runs on torchdyn's NeuralODE defaults -- atol = rtol = 1e-3 in
+# torchdyn 1.0.6 (1e-4 are the adjoint's / ODEProblem's).  torchdyn is not installable offline: scripts/pin_third_party.py checks this
+# value against the real package the first time it runs online (oracle/flowdec_oracle.py, section f4).
+ADAPTIVE_DEFAULT_TOL = 1e-3
+
 CONV_ALGOS = {"direct": 0, "winograd": L.FD_WINOGRAD, "winograd_lowres": L.FD_WINOGRAD_LOWRES, "auto": L.FD_WINOGRAD_AUTO,
               "latency": L.FD_LOW_LATENCY}   # one short clip on the whole chip (FD_LOW_LATENCY)
 
@@ -587,7 +593,7 @@ class FlowModel(nn.Module):
             with torch.cuda.stream(side):
                 if adaptive:
                     res = self._enhance_adaptive(lib, h, cfg, io, B, Lw, F, T, Tp, N, sigma_fac, return_traj, squeeze_dims, dev,
-                                                 float(kwargs.get("atol", 1e-4)), float(kwargs.get("rtol", 1e-4)), L.ADAPTIVE_SOLVERS[solver])
+                                                 float(kwargs.get("atol", ADAPTIVE_DEFAULT_TOL)), float(kwargs.get("rtol", ADAPTIVE_DEFAULT_TOL)), L.ADAPTIVE_SOLVERS[solver])
                 else:
                     res = self._enhance_native(lib, h, cfg, io, B, Lw, F, T, Tp, N, solver, sigma_fac, return_traj,
                                                return_preprocess_info, squeeze_dims, use_graph, dev)

@@ -792,9 +792,11 @@ def score_ode_enhance(net: NCSNppOracle, y: np.ndarray, prior_noise: np.ndarray,
 #   checkpoints                  `_adaptive_odeint` without interpolator: when t + dt would pass t_span[i] the step is shortened to land
 #                                on it exactly ("save old dt, raise checkpoint flag"), and dt_old - dt is restored before `adapt_step`
 #   tolerances                   `NeuralODE.__init__` (core/neuralde.py) forwards its own atol / rtol.  SURVEY section 8(c) records them as
-#                                1e-4; the builder's recollection of 1.0.6 is atol = rtol = 1e-3 for NeuralODE (1e-4 being `ODEProblem`'s
-#                                and the adjoint's).  Neither can be checked offline: `enhance(..., solver='dopri5', atol=, rtol=)` takes them
-#                                as arguments (default 1e-4, the tighter of the two) and profiles/r03_bench_cfg5_dopri5*.json has both.
+#                                1e-4; the builder's and the round-3 advisor's recollection of 1.0.6 is atol = rtol = 1e-3 for NeuralODE
+#                                (1e-4 being `ODEProblem`'s and the adjoint's).  Neither can be checked offline: `enhance(..., solver=
+#                                'dopri5', atol=, rtol=)` takes them as arguments, default flowdec_amd.model.ADAPTIVE_DEFAULT_TOL = 1e-3 since
+#                                round 4 (1e-4 before); scripts/pin_third_party.py compares it with the installed package;
+#                                profiles/r03_bench_cfg5_dopri5*.json has both settings.
 #   t, dt                        float32 tensors (t_span = torch.linspace(0, 1, N + 1), model.py:513); the state keeps its dtype
 # What IS checked offline: the tableau / controller integrate test problems to tolerance and agree with scipy's RK45
 # (tests/test_oracle_golden.py::test_dopri5_driver_against_scipy); the HIP driver follows this restatement (fixture g16).

@@ -40,6 +40,14 @@ def test_read_list_formats(tmp_path):
         bad = tmp_path / name; bad.write_text(text)
         with pytest.raises(ValueError, match=r":2: .*inconsistent"):     # the reference asserts (enhance.py:162)
             read_list(str(bad))
+    # the arrow wins over commas (reference precedence, enhance.py:153-158): a path with a comma in an arrow line is not cut
+    c = tmp_path / "comma.txt"; c.write_text("c/a,1.wav ---> n/a,1.wav\n")
+    fl = read_list(str(c))
+    assert fl.clean == ["c/a,1.wav"] and fl.inputs == ["n/a,1.wav"]
+    for name, text in (("bad3.txt", "a.wav,b.wav,c.wav\n"), ("bad4.txt", "a ---> b ---> c\n")):
+        bad = tmp_path / name; bad.write_text(text)
+        with pytest.raises(ValueError, match=r":1: 3 fields"):
+            read_list(str(bad))
     (tmp_path / "d").mkdir()
     for n in ("b.wav", "a.wav", "c.txt"):
         (tmp_path / "d" / n).write_bytes(b"")

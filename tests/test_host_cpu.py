@@ -156,6 +156,13 @@ assert torch.equal(sharded_enhance(m, y, N=2, generator=g2), ref), "generator= m
 a = sharded_enhance(m, y, N=2); b = sharded_enhance(m, y, N=2)      # nothing given: rank 0's seed is broadcast
 ga = [torch.empty_like(a) for _ in range(2)]; dist.all_gather(ga, a)
 assert torch.equal(ga[0], ga[1]) and not torch.equal(a, b), "default: all ranks agree on a fresh seed per call"
+# generator= with an idle rank (one clip, two ranks): the idle rank draws and discards, so both generators stay identical and the
+# NEXT call still equals the single-process sequence of draws
+g1 = torch.Generator().manual_seed(9); g2 = torch.Generator().manual_seed(9)
+r1 = m.enhance(y[:1], N=2, noise=torch.randn((1, 1, 16, 64), dtype=torch.complex64, generator=g1))
+r2 = m.enhance(y, N=2, noise=torch.randn((5, 1, 16, 64), dtype=torch.complex64, generator=g1))
+assert torch.equal(sharded_enhance(m, y[:1], N=2, generator=g2), r1)
+assert torch.equal(sharded_enhance(m, y, N=2, generator=g2), r2), "generator= after a call with an idle rank"
 one = sharded_enhance(m, y[:1], N=2, seed=1)      # one clip, two ranks: rank 1 idles but still gathers
 assert one.shape == (1, 1, 100) and torch.equal(one, m.enhance(y[:1], N=2, noise=clip_noise(1, 0, (1, 16, 64), "cpu")[None]))
 dist.barrier(); dist.destroy_process_group()
@@ -170,6 +177,72 @@ def test_batch_sharding_gloo_world2(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(2)]
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert all("ok" in o for o in outs)
+
+
+def test_gather_without_process_group_is_a_clear_error():
+    from flowdec_amd.dist import all_gather_shards, sharded_apply, sharded_enhance
+    x = torch.zeros(2, 1, 8)
+    with pytest.raises(RuntimeError, match="process group"):
+        all_gather_shards(x, 2)
+    with pytest.raises(RuntimeError, match="process group"):
+        sharded_apply(lambda v: v, x, always_gather=True)
+
+    class FE:
+        def _cfg(self):
+            return dict(n_fft=30, hop=8)
+
+    class Stub:
+        device = torch.device("cpu"); feature_extractor = FE()
+
+        def enhance(self, yb, N=50, solver="euler", noise=None, **kw):
+            return yb
+
+    with pytest.raises(RuntimeError, match="process group"):
+        sharded_enhance(Stub(), x, N=1, seed=0, always_gather=True)
+    assert torch.equal(sharded_enhance(Stub(), x, N=1, seed=0), x)      # world 1 without a group: plain call
+
+
+_WORKER8 = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from flowdec_amd.dist import clip_noise, shard_range, sharded_enhance
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+class FE:
+    def _cfg(self): return dict(n_fft=30, hop=8)
+class Stub:   # the FlowModel surface sharded_enhance uses; records the shard sizes it was called with
+    device = torch.device("cpu"); feature_extractor = FE()
+    def __init__(self): self.calls = []
+    def enhance(self, yb, N=50, solver="euler", noise=None, **kw):
+        self.calls.append(yb.shape[0])
+        return yb * N + noise.real.mean(dim=(1, 2, 3)).reshape(-1, 1, 1)
+# BASELINE cfg 4 (256 clips) and cfg 5 (64 clips) over the 8 ranks of one node, plus an uneven global batch: every rank gets its
+# contiguous slice, the gathered result equals the single-process call bit for bit, noise belongs to the GLOBAL clip index
+for B, per in ((256, 32), (64, 8), (20, None)):
+    torch.manual_seed(B)
+    y = torch.randn(B, 1, 40)
+    m = Stub()
+    out = sharded_enhance(m, y, N=3, solver="midpoint", seed=11)
+    lo, hi = shard_range(B, rank, world)
+    assert m.calls == [hi - lo] and (per is None or hi - lo == per), (m.calls, lo, hi)
+    ref = Stub().enhance(y, N=3, noise=torch.stack([clip_noise(11, i, (1, 16, 64), "cpu") for i in range(B)]))
+    assert out.shape == (B, 1, 40) and torch.equal(out, ref), B
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_batch_sharding_gloo_world8_cfg4_cfg5(tmp_path):
+    """The 8-rank splits of BASELINE cfg 4 (256 x 2 s -> 32 clips per GPU) and cfg 5 (64 x 4 s -> 8 per GPU) through
+    `sharded_enhance` on the CPU (gloo, stand-in model): shard sizes, gather order, noise by global clip index."""
+    script = tmp_path / "worker8.py"
+    script.write_text(_WORKER8)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="8", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(8)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert all("ok" in o for o in outs)
 
@@ -244,3 +317,28 @@ def test_c_abi_from_plain_c(tmp_path):
     r = subprocess.run([exe, _lib.LIB_PATH], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "c abi ok" in r.stdout
+
+
+def test_wino4_kernel_owns_m0():
+    """conv_wino4.hip writes M0 from inline asm without saving it (the LDS-DMA destination): nothing else in its ISA may use M0, and
+    the kernels must not spill (a scratch access inside the K loop would break the hand-counted s_waitcnt vmcnt)."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "w4.s")
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-I" + os.path.join(root, "include"),
+                            "-I" + os.path.join(root, "flowdec_amd", "csrc"), "-Wno-unused-result", "-S", "--cuda-device-only",
+                            os.path.join(root, "flowdec_amd", "csrc", "conv_wino4.hip"), "-o", out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        asm = open(out).read()
+    code = [l.split(";")[0] for l in asm.splitlines()]
+    foreign = [l for l in code if "m0" in l.split() or ", m0" in l or " m0," in l]
+    foreign = [l for l in foreign if not l.strip().startswith("s_mov_b32 m0,")]
+    assert not foreign, foreign[:5]
+    assert sum("v_mfma_f32_32x32x16_f16" in l for l in code) == 6 * 72   # six instantiations, 18 steps x 4 MFMAs each
+    assert not any("scratch_" in l for l in code), "conv_wino4 kernels spill"
