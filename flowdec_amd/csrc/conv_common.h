@@ -4,6 +4,14 @@
 #include "common.h"
 #include "internal.h"
 
+// Per-workgroup phase timing (s_memtime stamps written to the buffer of fd_debug_buffer) exists in -DFD_TIMING2 builds only
+// (scripts/build_t2.sh): FD_T2(...) keeps its argument there and drops it otherwise.
+#ifdef FD_TIMING2
+#define FD_T2(...) __VA_ARGS__
+#else
+#define FD_T2(...)
+#endif
+
 namespace fdconv {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));

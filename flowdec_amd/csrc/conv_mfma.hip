@@ -215,9 +215,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   char* const wbuf = smem + G::NHB * G::HALO_BYTES;
   char* const afftab = wbuf + G::NWBUF * G::W_LDS;
 
-#ifdef FD_TIMING2   // light phase timing (3 timestamps per wave, no waits added inside the loop)
-  const unsigned long long t2_entry = __builtin_amdgcn_s_memtime();
-#endif
+  FD_T2(const unsigned long long t2_entry = __builtin_amdgcn_s_memtime();)
   // ---- tile decode with XCD-aware remap: consecutive logical tiles share an XCD's L2 ------------------------
   const int bid = blockIdx.x, nblk = gridDim.x;
   int lid;
@@ -301,14 +299,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     nc = nchan_ok ? c : 0;
     naff = sg.aff_off >= 0 ? (sg.aff_off + nc) * 8 + (RE ? (lb & 1) * AFF_BYTES : 0) : -1;  // byte offset of this slot's (a,d) pairs in the LDS table (RE: one table per image parity)
   };
-#ifndef FD_HALO_AUX
-#define FD_HALO_AUX 0
-#endif
   int npix_on = 1;   // 0: the prefetch target is unused (last chunk of the K loop) -> every lane re-reads pixel 0 (one cache line, no HBM traffic)
   auto load_halo_slot = [&](int i) {
     const int off = (pixl[i] * npix_on * nC + nc) * (int)sizeof(TS);
-    hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(nsrd, off, 0, FD_HALO_AUX);
-    if constexpr (MIXED) hreg_hi[i] = __builtin_amdgcn_raw_buffer_load_b128(nsrd, off + 16, 0, FD_HALO_AUX);
+    hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(nsrd, off, 0, 0);
+    if constexpr (MIXED) hreg_hi[i] = __builtin_amdgcn_raw_buffer_load_b128(nsrd, off + 16, 0, 0);
   };
   // the LDS image of slot i, in place: silu(a*x+d) (or the storage -> operand conversion), zero padding AFTER the activation
   auto convert_slot = [&](int i) {
@@ -423,18 +418,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   // instruction-group hints ask the scheduler to spread that work BETWEEN the MFMAs (a few instructions per gap run under
   // the 32-cycle MFMA issue interval) instead of as a serial block while the matrix pipe idles.
   auto mma_all = [&](const u32x4 (&wf)[NT], const u32x4 (&pf)[MT]) {
-#ifdef FD_SETPRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
     for (int nj = 0; nj < NT; ++nj)
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) Math<T>::mma(acc[mi][nj], wf[nj], pf[mi]);
-#ifdef FD_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     constexpr int NM = MT * NT * (sizeof(T) == 2 ? 1 : 4);
-#ifndef FD_NO_SGB
 #pragma unroll
     for (int i = 0; i < NM; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
@@ -444,7 +432,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
       __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
     }
-#endif
   };
   // SPLIT schedule of one step (sets: wfA = w_hi, pfA = p_hi, wfB = w_lo, pfB = p_lo, wfC = next w_hi):
   //   phase A: read p_lo(s)                              || w_hi*p_hi, w_lo*p_hi     (p_hi and w_lo are dead afterwards)
@@ -550,9 +537,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
 #pragma unroll
   for (int i = 0; i < G::HITER; ++i) store_halo_slot(i, 0);
   block_sync();
-#ifdef FD_TIMING2
-  const unsigned long long t2_first = __builtin_amdgcn_s_memtime();
-#endif
+  FD_T2(const unsigned long long t2_first = __builtin_amdgcn_s_memtime();)
   read_frags(wfA, pfA, hbuf, wbuf, n9 > 0 ? 0 : CENTER, 0);  // (the k-half ks = 1 is addressed by passing hb + 32 / wb + 32)
   if constexpr (SPLIT) read_w(wfB, wbuf, 1);
 
@@ -576,9 +561,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     cs = 0; cch = 0;
     next_chunk(0, 0);
   };
-#ifdef FD_TIMING2
-  unsigned long long re_t0 = RE ? __builtin_amdgcn_s_memtime() : 0ull, re_loop = 0, re_epi = 0, re_stat = 0, re_tiles = 0;
-#endif
+  FD_T2(unsigned long long re_t0 = RE ? __builtin_amdgcn_s_memtime() : 0ull, re_loop = 0, re_epi = 0, re_stat = 0, re_tiles = 0;)
   for (;;) {   // tile loop: a single pass unless RE
   if constexpr (CW) {
     // Low-latency K loop.  With few MFMAs per phase the two-set pipeline above is a pure latency chain (the MFMAs of phase p + 1
@@ -756,9 +739,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     ++step; hcur ^= 1;
   }
   if constexpr (RE) {
-#ifdef FD_TIMING2
-    const unsigned long long re_t1 = __builtin_amdgcn_s_memtime();
-#endif
+    FD_T2(const unsigned long long re_t1 = __builtin_amdgcn_s_memtime();)
     // ---- register epilogue (see the file header).  Lane (l31, lh) of wave (wm, wn) holds, for M-tile mi and N-tile nj, the
     // couts 8 qd + 4 lh + e (qd, e = 0..3) of pixel l31 of patch wm * MT + mi.
     const auto kp = KP();
@@ -828,9 +809,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       }
     }
     pend_st = RE_NST;
-#ifdef FD_TIMING2
-    const unsigned long long re_t2 = __builtin_amdgcn_s_memtime();
-#endif
+    FD_T2(const unsigned long long re_t2 = __builtin_amdgcn_s_memtime();)
     if (want_stats) {
       lds_barrier();
       // (through a buffer resource: uniform base + tile offset in scalar registers, the per-thread part is 4 * o -- a 64-bit per-thread
@@ -846,7 +825,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
       }
       if (__builtin_amdgcn_readfirstlane(t) < 2 * G::BN) pend_st = RE_NST + 1;
     }
-#ifdef FD_TIMING2
+    FD_T2(
     {   // per-workgroup sums over its tiles: K loop | register epilogue (math + stores + lane reduction) | statistics barrier + combine
       const unsigned long long re_t3 = __builtin_amdgcn_s_memtime();
       re_loop += re_t1 - re_t0; re_epi += re_t2 - re_t1; re_stat += re_t3 - re_t2; ++re_tiles;
@@ -855,7 +834,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         d[0] = t2_first - t2_entry; d[1] = re_loop; d[2] = re_epi; d[3] = re_stat; d[4] = re_tiles; d[5] = re_t3 - t2_entry;
       }
     }
-#endif
+    )
     if (--tiles_left <= 0) break;
     {   // on to the next tile: its first halo is published, its first weight slabs are in the ring
       const int ob = b;
@@ -874,17 +853,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     wfetch = wfetch0 + 4 * slab_stride;
     asm volatile("" : "+s"(wfetch));
     read_frags(wfA, pfA, hbuf + hcur * G::HALO_BYTES, smem + WOFF + (step & 3) * G::W_LDS, 0, 0);
-#ifdef FD_TIMING2
+    FD_T2(
     re_t0 = __builtin_amdgcn_s_memtime();   // (transition -- tile decode, accumulator reset -- is counted with the total only)
-#endif
+    )
     continue;
   } else {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // all fragment reads / DMA done before the epilogue reuses the LDS
 
-#ifdef FD_TIMING2
-  const unsigned long long t2_loop = __builtin_amdgcn_s_memtime();
-#endif
+  FD_T2(const unsigned long long t2_loop = __builtin_amdgcn_s_memtime();)
   // ---- epilogue ------------------------------------------------------------------------------------------------------
   // MT rounds; in round mi every wave stages its acc[mi][*] (32 pixels x NT*32 couts, f32) to LDS as
   // [pixel (wm*32 + l31)][cout], then all threads sweep the WM*32 pixels with 8 couts (16/32 B) per lane.
@@ -907,9 +884,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   for (int j = 0; j < 8; ++j) ssum[j] = ssq[j] = 0.f;
   const bool interior = h0 + G::TH <= H && w0 + G::TW <= W && n0 + G::BN <= p.Cout;   // workgroup-uniform
 
-#ifdef FD_TIMING2
-  unsigned long long t2_e1 = 0, t2_e2 = 0, t2_e3 = 0;
-#endif
+  FD_T2(unsigned long long t2_e1 = 0, t2_e2 = 0, t2_e3 = 0;)
   // MT rounds, staging double-buffered (one barrier per round: the writes of round r+1 go to the other buffer, and
   // every wave has finished reading round r-1 from it before it arrived at barrier r).  The skip values of a round are
   // prefetched into registers BEFORE the staging of that round so that their latency hides behind the LDS round trip.
@@ -950,9 +925,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         }
     }
     lds_barrier();
-#ifdef FD_TIMING2
-    if (mi == 0) t2_e1 = __builtin_amdgcn_s_memtime();
-#endif
+    FD_T2(if (mi == 0) t2_e1 = __builtin_amdgcn_s_memtime();)
     // (c) sweep: 8 couts (16 / 32 B) per lane, fully coalesced.  All passes of the round are computed into registers
     // first and their stores are issued back to back afterwards: vmcnt counts loads AND stores, so any wait between two
     // stores (hipcc puts a vmcnt(0) in front of the first use of a residual value) would drain the previous store at full
@@ -1037,10 +1010,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     };
     if (interior) sweep(std::true_type{});
     else sweep(std::false_type{});
-#ifdef FD_TIMING2
+    FD_T2(
     if (mi == 0) t2_e2 = __builtin_amdgcn_s_memtime();
     if (mi == MT - 1) t2_e3 = __builtin_amdgcn_s_memtime();
-#endif
+    )
   }
   lds_barrier();
 
@@ -1064,7 +1037,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
         p.stats[(((size_t)b * p.tiles_h * p.tiles_w + tile) * p.CoutPad + n0) * 2 + o] = a;
     }
   }
-#ifdef FD_TIMING2
+  FD_T2(
   if (p.dbg && t == 0 && bid < 8192) {   // per-workgroup record, no atomics (they would perturb the epilogue being measured)
     const unsigned long long t2_end = __builtin_amdgcn_s_memtime();
     unsigned long long* d = p.dbg + (size_t)bid * 8;
@@ -1076,7 +1049,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
     d[5] = t2_e3 - t2_e2;         // rounds 1..MT-1
     d[6] = t2_end - t2_e3;        // final barrier + statistics
   }
-#endif
+  )
   break;
   }   // !RE
   }   // tile loop
@@ -1145,9 +1118,9 @@ inline int pad_to(int x, int a) { return (x + a - 1) / a * a; }
 inline int cout_pad(int Cout) { return Cout <= 32 ? 32 : (Cout <= 128 ? 128 : pad_to(Cout, 256)); }
 inline int n_steps(int C0, int C1, int taps, int CK) { return (fd_cdiv(C0, CK) + fd_cdiv(C1, CK)) * taps; }
 
-#ifdef FD_TIMING2
+FD_T2(
 unsigned long long* g_dbg = nullptr;  // instrumented builds only: device buffer of 8 counters per workgroup (fd_debug_buffer)
-#endif
+)
 
 template <typename T, int WM, int WN, int MT, int NT, bool CW = false, int MIXED = 0, bool SH = false>
 int set_attr() {
@@ -1269,9 +1242,7 @@ int fd_conv_init_attributes() {
   return FD_OK;
 }
 
-#ifdef FD_TIMING2
-extern "C" int fd_debug_buffer(void* p) { g_dbg = reinterpret_cast<unsigned long long*>(p); return FD_OK; }
-#endif
+FD_T2(extern "C" int fd_debug_buffer(void* p) { g_dbg = reinterpret_cast<unsigned long long*>(p); return FD_OK; })
 
 extern "C" int fd_conv_cout_pad(int Cout) { return cout_pad(Cout); }
 extern "C" int fd_conv_stats_tiles(int H, int W) { return fd_cdiv(H, 16) * fd_cdiv(W, 16); }
@@ -1372,18 +1343,14 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   a.w = packed_w; a.w_bytes = fd_conv_packed_bytes(Cout, C0, C1, ksize, S0, S1, dtype | (wino ? FD_WINOGRAD : 0) | (wino4 ? FD_WINOGRAD4 : 0) | (mixed ? FD_BF16_OPERANDS : 0) | (split ? FD_BF16X3_OPERANDS : 0));
   a.bias = bias; a.bias_rows = bias_rows; a.skip = skip; a.scale = scale; a.out = out; a.Cout = Cout; a.CoutPad = cout_pad(Cout);
   a.stats = stats; a.B = B; a.H = H; a.W = W;
-#ifdef FD_TIMING2
-  a.dbg = g_dbg;
-#endif
+  FD_T2(a.dbg = g_dbg;)
   FD_REQUIRE(a.w_bytes < (1ll << 31), "fd_conv2d: packed weights exceed 2 GiB");
   FD_REQUIRE(affine == nullptr || (C0 + C1) * 8 <= AFF_BYTES, "fd_conv2d: at most %d activated input channels", AFF_BYTES / 8);
   if (wino4) return fd_wino4_launch(a, fd_stream(stream));
   if (wino) return fd_wino_launch(a, fd_stream(stream));
   if (mixed) return dispatch_conv_mixed(a, fd_stream(stream));
   if (split) return dispatch_conv_split(a, fd_stream(stream));
-#ifndef FD_NO_HEAD_KERNEL
   if (bn_hint == 0 && fd_head_supported(a, ksize, dtype)) return fd_head_launch(a, fd_stream(stream));
-#endif
   if (dtype == FD_BF16) return dispatch_conv<bf16>(a, fd_stream(stream), bn_hint, tile == FD_TILE_BN64_CHUNK || tile == FD_TILE_BN32_CHUNK, tile == FD_TILE_PERSIST);
   return dispatch_conv<float>(a, fd_stream(stream), bn_hint, false);
 }

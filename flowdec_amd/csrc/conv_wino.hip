@@ -161,9 +161,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const hbuf = smem + HALO_OFF;
   char* const afftab = smem + AFF_OFF;
-#ifdef FD_TIMING2
-  const unsigned long long t2_entry = __builtin_amdgcn_s_memtime();
-#endif
+  FD_T2(const unsigned long long t2_entry = __builtin_amdgcn_s_memtime();)
 
   // ---- tile decode with XCD-aware remap (as conv_mfma.hip) ------------------------------------------------------------
   const int bid = blockIdx.x, nblk = gridDim.x;
@@ -378,9 +376,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino_kernel(ConvArgs p) {
   next_chunk();
   load_halo();
   step_barrier(K7{});   // steps 0 and 1 landed (step 2 and the halo loads may still fly); halo 0 published
-#ifdef FD_TIMING2
-  const unsigned long long t2_first = __builtin_amdgcn_s_memtime();
-#endif
+  FD_T2(const unsigned long long t2_first = __builtin_amdgcn_s_memtime();)
   read_cluster<0, 0>(wfA, raA, rbA, wb0, pa0, pb0);
 
   int step = 0, hcur = 0;
@@ -443,9 +439,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino_kernel(ConvArgs p) {
   const int nmain = n1 > 0 ? n3 - 1 : n3;
   for (int i = 0; i < nmain; ++i) chunk_body(TACT{}, false);
   for (int i = nmain; i < n3; ++i) chunk_body(TRAW{}, true);   // last 3x3 chunk in front of the shortcut: the halo it converts is raw
-#ifdef FD_TIMING2
-  const unsigned long long t2_sc = __builtin_amdgcn_s_memtime();
-#endif
+  FD_T2(const unsigned long long t2_sc = __builtin_amdgcn_s_memtime();)
   // ---- folded 1x1 shortcut: one step per chunk, half a K step (8 MFMAs) per wave.  Same pipeline with short steps: the halo
   // of the next chunk is in registers, converted and stored before the barrier; the loads of the chunk after it follow.
   for (int i = 0; i < n1; ++i) {
@@ -467,9 +461,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino_kernel(ConvArgs p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // all fragment reads / DMA done before the epilogue reuses the LDS
-#ifdef FD_TIMING2
-  const unsigned long long t2_loop = __builtin_amdgcn_s_memtime();
-#endif
+  FD_T2(const unsigned long long t2_loop = __builtin_amdgcn_s_memtime();)
 
   // ---- epilogue -------------------------------------------------------------------------------------------------------
   // 4 rounds (mi, nh): every wave stages acc[mi][2nh..2nh+1] (32 tiles x 64 couts of its position) as
@@ -581,14 +573,14 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino_kernel(ConvArgs p) {
       if (n0 + c < p.CoutPad) p.stats[(((size_t)b * p.tiles_h * p.tiles_w + tile) * p.CoutPad + n0) * 2 + t] = a;
     }
   }
-#ifdef FD_TIMING2
+  FD_T2(
   if (p.dbg && t == 0 && bid < 8192) {
     const unsigned long long t2_end = __builtin_amdgcn_s_memtime();
     unsigned long long* d = p.dbg + (size_t)bid * 8;
     d[0] = t2_first - t2_entry; d[1] = t2_loop - t2_first; d[2] = t2_end - t2_loop; d[3] = t2_sc - t2_first; d[4] = t2_loop - t2_sc;
     d[5] = 0; d[6] = 0;
   }
-#endif
+  )
 }
 
 // ---- weight packing: [Cout][Cin][3][3] f32 -> [step = (segment, chunk, dy)][xi][CoutPad][64 B] fp16 ---------------------

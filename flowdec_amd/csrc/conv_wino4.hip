@@ -106,9 +106,7 @@ template <bool ACT, bool SKIP, bool SC>
 __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   static_assert(!(SKIP && SC), "residual input and folded shortcut exclude each other in this kernel");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef FD_TIMING2
-  const unsigned long long t2_entry = __builtin_amdgcn_s_memtime();
-#endif
+  FD_T2(const unsigned long long t2_entry = __builtin_amdgcn_s_memtime();)
 
   // ---- tile decode with XCD-aware remap (as conv_mfma.hip) ------------------------------------------------------------
   const int bid = blockIdx.x, nblk = gridDim.x;
@@ -334,9 +332,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   barrier();
   aff_wait();
   if (xt == 0) conv_slot(0);   // wave group 0 is one step ahead with its conversions (see below)
-#ifdef FD_TIMING2
-  const unsigned long long t2_first = __builtin_amdgcn_s_memtime();
-#endif
+  FD_T2(const unsigned long long t2_first = __builtin_amdgcn_s_memtime();)
   qa[0] = rd(a_off(0, 0)); qb[0] = rd(b_off(0, 0)); qb[1] = rd(b_off(0, 1)); qa[1] = rd(a_off(0, 1));
 
   // ---- K loop.  Chunk c multiplies V[c & 1]; meanwhile the halo of chunk c + 1 (in RAW) is activated and stored into z, transformed
@@ -415,9 +411,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // all fragment reads / DMA done before the epilogue reuses the LDS
-#ifdef FD_TIMING2
-  const unsigned long long t2_loop = __builtin_amdgcn_s_memtime();
-#endif
+  FD_T2(const unsigned long long t2_loop = __builtin_amdgcn_s_memtime();)
 
   // ---- epilogue -------------------------------------------------------------------------------------------------------
   // Lane (l31, lh) of wave (cq, xt) holds, for cout block ct and tile block nt, acc[x][ct][nt][e]: cout ct * 128 + cq * 32 + 8 (e >> 2)
@@ -456,10 +450,10 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   };
   skip_dma(0);
   skip_dma(1);
-#ifdef FD_TIMING2
+  FD_T2(
   unsigned long long t2_r[5] = {0, 0, 0, 0, 0};
   t2_r[0] = __builtin_amdgcn_s_memtime();
-#endif
+  )
 
   const float ka = xt ? 0.f : 1.f, ks = xt ? 4.f : 1.f, kb = xt ? 1.f : 0.f, kd = xt ? 8.f : 1.f, kq = xt ? 0.25f : 1.f;
   // E1 of one round: partial transform, send, barrier, receive + combine (ya -> m0, yb -> m1); xoff = byte offset of the exchange buffer
@@ -599,9 +593,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
     }
     lds_wait();
     barrier();   // all exchange reads done: the LDS below is reused
-#ifdef FD_TIMING2
-    t2_r[1] = __builtin_amdgcn_s_memtime();
-#endif
+    FD_T2(t2_r[1] = __builtin_amdgcn_s_memtime();)
     // ---- E2: folded shortcut ----
     {
       // K = the S0 + S1 channels of the (at most two) shortcut segments, in stages of SCK MFMA K steps (16 channels each).  A stage of x
@@ -665,9 +657,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
       lds_wait();
       barrier();   // all fragment reads done: the staging buffers overlap the weight rings and the x stages
     }
-#ifdef FD_TIMING2
-    t2_r[2] = __builtin_amdgcn_s_memtime();
-#endif
+    FD_T2(t2_r[2] = __builtin_amdgcn_s_memtime();)
     // ---- E3 for all rounds (two staging buffers: one barrier per round)
 #pragma unroll
     for (int rd_ = 0; rd_ < 4; ++rd_) {
@@ -692,9 +682,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-#ifdef FD_TIMING2
-  t2_r[3] = __builtin_amdgcn_s_memtime();
-#endif
+  FD_T2(t2_r[3] = __builtin_amdgcn_s_memtime();)
   if (p.stats) {
     lds_wait();
     barrier();
@@ -708,14 +696,14 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
     const int tile = th_i * p.tiles_w + tw_i;
     p.stats[((size_t)b * p.tiles_h * p.tiles_w + tile) * p.CoutPad * 2 + t] = a;
   }
-#ifdef FD_TIMING2
+  FD_T2(
   if (p.dbg && t == 0 && bid < 8192) {
     const unsigned long long t2_end = __builtin_amdgcn_s_memtime();
     unsigned long long* d = p.dbg + (size_t)bid * 8;
     d[0] = t2_first - t2_entry; d[1] = t2_loop - t2_first; d[2] = t2_end - t2_loop;
     d[3] = t2_r[1] - t2_r[0]; d[4] = t2_r[2] - t2_r[1]; d[5] = t2_r[3] - t2_r[2]; d[6] = t2_end - t2_r[3]; d[7] = t2_r[0] - t2_loop;
   }
-#endif
+  )
 }
 
 // ---- weight packing: [Cout][Cin][3][3] f32 -> [chunk][xt][xi][dy][256 couts][32 B] fp16 ------------------------------------
