@@ -437,11 +437,16 @@ class NCSNppOracle:
     GaussianFourierProjection (:42-51)."""
 
     def __init__(self, state_dict: Dict[str, np.ndarray], nf=64, ch_mult=(4, 4, 4, 2), num_res_blocks=1,
-                 num_channels=4, prefix="backbone.", dtype=np.float32, operand_round=None):
+                 num_channels=4, prefix="backbone.", dtype=np.float32, operand_round=None, storage_round=None):
+        """operand_round='bf16': every convolution rounds its two operands to bf16 (f32 accumulation).  storage_round='bf16': every
+        tensor the HIP bf16 mode keeps in memory between kernels is rounded to bf16 where that mode stores it (conv / FIR / Combine
+        outputs, block outputs, the pyramids) -- together the two model the bf16 mode's arithmetic; tests/test_hip_model.py derives its
+        tolerance from this prediction (tests/golden/make_golden_bf16_prediction.py)."""
         self.cfg = dict(nf=nf, ch_mult=tuple(ch_mult), num_res_blocks=num_res_blocks, num_channels=num_channels)
         self.specs = build_module_specs(**self.cfg)
         self.dtype = dtype
         self.operand_round = operand_round
+        self._st = (lambda a: round_bf16(np.asarray(a, np.float32)).astype(dtype)) if storage_round == "bf16" else (lambda a: a)
         self.p = {k[len(prefix):] if k.startswith(prefix) else k: np.asarray(v).astype(dtype)
                   for k, v in state_dict.items()}
         self.taps: Dict[str, np.ndarray] = {}
@@ -463,18 +468,19 @@ class NCSNppOracle:
         """layerspp.py:252-284."""
         ci, co = s["cin"], s["cout"]
         h = silu(group_norm(x, gn_groups(ci), self._w(i, "GroupNorm_0.weight"), self._w(i, "GroupNorm_0.bias")))
+        st = self._st
         if s["up"]:
-            h = upsample_2d(h); x = upsample_2d(x)
+            h = st(upsample_2d(h)); x = st(upsample_2d(x))
         elif s["down"]:
-            h = downsample_2d(h); x = downsample_2d(x)
+            h = st(downsample_2d(h)); x = st(downsample_2d(x))
         h = conv2d(h, self._w(i, "Conv_0.weight"), self._w(i, "Conv_0.bias"), self.operand_round)
         tb = linear(silu(temb), self._w(i, "Dense_0.weight"), self._w(i, "Dense_0.bias"))  # [Bt, co]
-        h = h + tb[:, :, None, None]
+        h = st(h + tb[:, :, None, None])
         h = silu(group_norm(h, gn_groups(co), self._w(i, "GroupNorm_1.weight"), self._w(i, "GroupNorm_1.bias")))
         h = conv2d(h, self._w(i, "Conv_1.weight"), self._w(i, "Conv_1.bias"), self.operand_round)
         if ci != co or s["up"] or s["down"]:
             x = conv2d(x, self._w(i, "Conv_2.weight"), self._w(i, "Conv_2.bias"), self.operand_round)
-        return ((x + h) / np.sqrt(2.0)).astype(self.dtype)
+        return st(((x + h) / np.sqrt(2.0)).astype(self.dtype))
 
     # -- forward ------------------------------------------------------------------------
     def forward(self, x: np.ndarray, y: np.ndarray, t: np.ndarray, tap: bool = False) -> np.ndarray:
@@ -487,7 +493,8 @@ class NCSNppOracle:
         nrb = self.cfg["num_res_blocks"]
         m = 3
         input_pyramid = h
-        hs = [conv2d(h, self._w(m, "weight"), self._w(m, "bias"), self.operand_round)]
+        st = self._st
+        hs = [st(conv2d(h, self._w(m, "weight"), self._w(m, "bias"), self.operand_round))]
         m += 1
         taps = {}
         for lvl in range(R):
@@ -496,8 +503,8 @@ class NCSNppOracle:
                 hs.append(h)
             if lvl != R - 1:
                 h = self.resblock(m, specs[m], hs[-1], temb); m += 1
-                input_pyramid = downsample_2d(input_pyramid)
-                h = conv2d(input_pyramid, self._w(m, "Conv_0.weight"), self._w(m, "Conv_0.bias"), self.operand_round) + h
+                input_pyramid = st(downsample_2d(input_pyramid))
+                h = st(conv2d(input_pyramid, self._w(m, "Conv_0.weight"), self._w(m, "Conv_0.bias"), self.operand_round) + h)
                 m += 1
                 hs.append(h)
         h = hs[-1]
@@ -512,7 +519,7 @@ class NCSNppOracle:
             c = specs[m]["c"]
             ph = silu(group_norm(h, gn_groups(c), self._w(m, "weight"), self._w(m, "bias"))); m += 1
             ph = conv2d(ph, self._w(m, "weight"), self._w(m, "bias"), self.operand_round); m += 1
-            pyramid = ph if pyramid is None else upsample_2d(pyramid) + ph
+            pyramid = st(ph if pyramid is None else st(upsample_2d(pyramid)) + ph)
             if lvl != 0:
                 h = self.resblock(m, specs[m], h, temb); m += 1
         assert not hs and m == len(specs)

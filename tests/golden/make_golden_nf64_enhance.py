@@ -4,7 +4,9 @@ headline solver settings (Euler N=6, midpoint N=3 = NFE 6).  Runs only in the bu
 through the stub recipe of make_golden.py); only the arrays travel.  Weights are re-derived in the tests from
 `oracle.flowdec_oracle.random_state_dict(seed=64, nf=64)`.
 
-    python tests/golden/make_golden_nf64_enhance.py      # ~1-2 min of CPU, writes tests/golden/g17_enhance_nf64.npz
+    python tests/golden/make_golden_nf64_enhance.py          # ~1-2 min of CPU, writes tests/golden/g17_enhance_nf64.npz
+    python tests/golden/make_golden_nf64_enhance.py --cfg1   # G18: BASELINE config 1 EXACTLY -- one 1 s clip, 6-step Euler, fp32 -- ~2 min,
+                                                             # writes tests/golden/g18_enhance_nf64_cfg1.npz
 """
 import os
 import sys
@@ -40,21 +42,23 @@ def main():
                    sampling_rate=48000, lr=1e-4, full_config={}).eval()
     sd = O.random_state_dict(seed=64, nf=64)
     fm.backbone.load_state_dict(MG.to_t(MG.strip(sd, "backbone.")))
-    rng = np.random.default_rng(1764)
-    L = 24000
+    cfg1 = "--cfg1" in sys.argv
+    rng = np.random.default_rng(1801 if cfg1 else 1764)
+    L = 48000 if cfg1 else 24000
     y = (0.1 * rng.standard_normal((1, 1, L))).astype(np.float32)
     Tp = O.padded_frames(O.num_frames(L))
     noise = MG.crandn(rng, (1, 1, 768, Tp))
     noise_t = torch.from_numpy(noise)
     fm._get_noise = lambda x, sigma: (sigma * noise_t[:x.shape[0]]).type(x.dtype)  # same arithmetic as model.py:536
     g = dict(y=y, noise=noise, sigma_y=sig.numpy(), seed=np.int64(64))
-    for solver, N in (("euler", 6), ("midpoint", 3)):
+    for solver, N in ((("euler", 6),) if cfg1 else (("euler", 6), ("midpoint", 3))):
         t0 = time.time()
         xh = fm.enhance(torch.from_numpy(y), N=N, solver=solver)
         print(f"{solver} N={N}: {time.time() - t0:.1f} s on {torch.get_num_threads()} threads", flush=True)
         g[f"{solver}_N{N}"] = xh.numpy()
-    np.savez_compressed(os.path.join(HERE, "g17_enhance_nf64.npz"), **g)
-    print("g17_enhance_nf64.npz", os.path.getsize(os.path.join(HERE, "g17_enhance_nf64.npz")) // 1024, "KiB")
+    name = "g18_enhance_nf64_cfg1.npz" if cfg1 else "g17_enhance_nf64.npz"
+    np.savez_compressed(os.path.join(HERE, name), **g)
+    print(name, os.path.getsize(os.path.join(HERE, name)) // 1024, "KiB")
 
 
 if __name__ == "__main__":

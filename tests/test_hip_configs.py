@@ -7,7 +7,7 @@ import torch
 
 from conftest import load_golden, rel_err
 from oracle import flowdec_oracle as O
-from test_hip_model import TOL_FWD, TOL_WAVE, TOL_WAVE_FULL, cu, make_model
+from test_hip_model import TOL_FWD, TOL_FWD_FULL, TOL_WAVE, TOL_WAVE_FULL, cu, make_model
 from test_hip_ops import DT, check, dev, from_nhwc, nhwc, report
 
 pytestmark = pytest.mark.gpu
@@ -81,6 +81,13 @@ def test_cfg3_flowdec_25s_b32_full_width():
     """BASELINE config 3: FlowDec-25s, batch = 32 x 2 s, midpoint (N = 3 -> NFE 6), bf16, full width."""
     m, _ = _preset_model("flowdec_25s", 64, 64, "bf16")
     _size_properties(m, 32, 2.0, 3, "midpoint", "cfg3_b32_midpoint")
+
+
+def test_cfg3_flowdec_25s_b32_midpoint_N6_full_width():
+    """BASELINE config 3's second reading ("6-step midpoint" = enhance(N=6, 'midpoint') = 12 evaluations, the reference's
+    docstring model.py:487 "midpoint has NFE=2*N"): same properties at full size."""
+    m, _ = _preset_model("flowdec_25s", 64, 64, "bf16")
+    _size_properties(m, 32, 2.0, 6, "midpoint", "cfg3_b32_midpoint_N6")
 
 
 def test_cfg2_flowdec_75m_b8_euler6_full_width():
@@ -492,8 +499,8 @@ def test_auto_keeps_residual_stream_out_of_fp16():
         outs[prec, algo] = m(cu(g["x"]) * 3e5, cu(g["y"]) * 3e5, torch.tensor([0.5], device="cuda")).cpu().numpy()
         assert np.isfinite(outs[prec, algo]).all()
         del m
-    check("ncsnpp_nf64_x3e5[bf16,direct]", outs["bf16", "direct"], outs["fp32", "direct"], TOL_FWD["bf16"])
-    check("ncsnpp_nf64_x3e5[bf16,auto]", outs["bf16", "auto"], outs["fp32", "direct"], TOL_FWD["bf16"])
+    check("ncsnpp_nf64_x3e5[bf16,direct]", outs["bf16", "direct"], outs["fp32", "direct"], TOL_FWD_FULL["bf16"])
+    check("ncsnpp_nf64_x3e5[bf16,auto]", outs["bf16", "auto"], outs["fp32", "direct"], TOL_FWD_FULL["bf16"])
 
 
 def test_model_create_rejects_flag_combinations():
@@ -590,7 +597,7 @@ def test_model_winograd_parity(algo):
     m.load_state_dict({k: torch.from_numpy(v) for k, v in O.random_state_dict(seed=int(g["seed"]), nf=64).items()}, strict=False)
     m = m.cuda()
     out = m(cu(g["x"]), cu(g["y"]), torch.tensor([0.5], device="cuda"))
-    check(f"ncsnpp_nf64[bf16,{algo}]", out.cpu().numpy(), g["out"], TOL_FWD["bf16"])
+    check(f"ncsnpp_nf64[bf16,{algo}]", out.cpu().numpy(), g["out"], TOL_FWD_FULL["bf16"])
     g17 = load_golden("g17_enhance_nf64.npz")
     x = m.enhance(torch.from_numpy(g17["y"]), N=6, solver="euler", noise=torch.from_numpy(g17["noise"]))
     check(f"enhance_nf64[euler,N=6,bf16,{algo}]", x.numpy(), g17["euler_N6"], TOL_WAVE_FULL["bf16"])
