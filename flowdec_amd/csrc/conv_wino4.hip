@@ -72,10 +72,11 @@ constexpr int X_BYTES = 8 * 8192;                   // exchange buffer (two of t
 constexpr int S_PITCH = 128 * 4 + 16;
 constexpr int S_BYTES = 128 * S_PITCH;              // 67584; two staging buffers unless the residual buffers are in use
 constexpr int SK_OFF = S_BYTES, SK_BYTES = 4 * NTH * 16;
-constexpr int SCK = 2;                              // shortcut GEMM: MFMA K steps (16 channels) per stage
-constexpr int XS_OFF = 8 * 2 * SCK * 2048, XS_BYTES = SCK * 8192;   // weight rings [8 waves][2 stages x SCK x 2 KiB] below, two x stages here
-constexpr int BIAS_OFF = 2 * S_BYTES;               /* = 135168 */               // [256] f32; above everything the three phases use (2 X, rings + x stages, S + 2 SK)
-static_assert(BIAS_OFF >= 2 * X_BYTES && BIAS_OFF >= XS_OFF + 2 * XS_BYTES && BIAS_OFF >= SK_OFF + 2 * SK_BYTES, "epilogue LDS map");
+constexpr int SCK = 2, SCD = 3;                     // shortcut GEMM: MFMA K steps (16 channels) per stage, stages resident (SCD - 1 in flight)
+constexpr int XS_OFF = 8 * SCD * SCK * 2048, XS_BYTES = SCK * 8192;   // weight buffers [8 waves][SCD stages x SCK x 2 KiB] below, SCD x stages here
+constexpr int BIAS_OFF = 2 * S_BYTES;               // = 135168: [256] f32; above what E1 (2 X) and E3 (2 S, or S + 2 SK) use.  E2 (shortcut:
+                                                    // buffers up to XS_OFF + SCD * XS_BYTES) overlaps it: the table is written after E2
+static_assert(BIAS_OFF >= 2 * X_BYTES && BIAS_OFF >= SK_OFF + 2 * SK_BYTES && XS_OFF + SCD * XS_BYTES <= 160 * 1024, "epilogue LDS map");
 constexpr int STAT_OFF = BIAS_OFF + 1024;           // [2][8 waves][16 octets][16] f32 = 16 KiB
 constexpr int LDS_BYTES = cmax(MAIN_BYTES, STAT_OFF + 16384);
 constexpr int NSLOT = HH * HW * 2;                  // 648 halo slots of 16 B (8 channels) per chunk
@@ -431,7 +432,8 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   const bf16* const skip = SKIP ? reinterpret_cast<const bf16*>(p.skip) + (size_t)b * img_elems * p.Cout : nullptr;
   float* const biast = reinterpret_cast<float*>(smem + BIAS_OFF);      // [256] f32 (zeros without a bias)
   float* const statt = reinterpret_cast<float*>(smem + STAT_OFF);      // [ct][wave][oct 16][16] f32 partial sums
-  if (t < BN) biast[t] = p.bias ? p.bias[(size_t)(p.bias_rows > 1 ? b : 0) * p.Cout + t] : 0.f;
+  auto load_bias_table = [&]() { if (t < BN) biast[t] = p.bias ? p.bias[(size_t)(p.bias_rows > 1 ? b : 0) * p.Cout + t] : 0.f; };
+  if constexpr (!SC) load_bias_table();   // (published by the barriers of the first round; with a shortcut: after E2, whose buffers overlap it)
   // element offset of pass ps of round (ct, nt) for this thread: staged pixel pp + 32 ps = plane ps of tile pp, cout octet oct
   auto out_off = [&](int tt, int ct, int nt, int ps) {
     const int oct = tt & 15, pp = tt >> 4;
@@ -597,11 +599,11 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
     // ---- E2: folded shortcut ----
     {
       // K = the S0 + S1 channels of the (at most two) shortcut segments, in stages of SCK MFMA K steps (16 channels each).  A stage of x
-      // is [K step][pixel plane j][tile][32 B] (row r = j * 64 + tile, halves swizzled by (r >> 3) & 1 like the V planes), filled by DMA:
-      // lane l of wave w fetches the 16 bytes that belong at (w * 64 + l) * 16 of a K step's 8 KiB -- the pixel order is made by the
-      // SOURCE addresses.  Weights [K step][cq][ct][32 couts][32 B] bf16 go to a private double buffer per wave (the two 1-KiB pieces
-      // ct = 0, 1 of a K step are consecutive).  One barrier per stage; everything for stage s + 1 is requested right after the barrier
-      // of stage s and awaited (vmcnt(0): nothing younger) before the next one.
+      // is [pixel plane j][tile][64 B] (row r = j * 64 + tile = one pixel's 32 channels), filled by DMA -- the pixel order is made by
+      // the SOURCE addresses.  Weights [K step][cq][ct][32 couts][32 B] bf16 go to private buffers per wave (the two 1-KiB pieces ct = 0, 1
+      // of a K step are consecutive).  SCD stages are resident: while stage s is multiplied, stages s + 1 and s + 2 are in flight (one
+      // stage in flight left the phase at a quarter of the matrix rate: a stage is ~600 cycles of MFMAs, a DMA round trip ~2000).  One
+      // barrier per stage, behind a counted wait: only the requests of the NEXT stage (3 SCK instructions) may still be in flight.
       const int nsc = p.nseg - (sC1 ? 2 : 1);   // shortcut segments follow the 3x3 segments
       const Seg q0 = p.seg[p.nseg - nsc], q1 = p.seg[p.nseg - 1];
       const int S0 = q0.C, Stot = S0 + (nsc > 1 ? q1.C : 0);
@@ -609,53 +611,72 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
       const bf16* const xb0 = reinterpret_cast<const bf16*>(q0.src) + (size_t)b * img_elems * q0.C;
       const bf16* const xb1 = reinterpret_cast<const bf16*>(q1.src) + (size_t)b * img_elems * q1.C;
       const char* const wsc = reinterpret_cast<const char*>(p.w) + (size_t)(n3 + 1) * 18 * SLAB + cq * 2048;
-      // per-lane source of the stage DMA: row r = (w * 64 + lane) >> 1, position (lane & 1) holds channel half (lane & 1) ^ ((r >> 3) & 1)
-      const int xr = (wave * 64 + lane) >> 1;
-      const int xtile = xr & 63, xj = xr >> 6;
-      const int xpix = (h0 + (xtile >> 2)) * W + w0 + 4 * (xtile & 3) + xj;
-      const int xhalf16 = (((lane & 1) ^ ((xr >> 3) & 1)) * 16);
+      // per-lane source of the stage DMA.  A stage row is one pixel's 64 bytes (SCK = 2 K steps x 2 channel halves): FOUR adjacent
+      // lanes fetch one pixel's contiguous 64 B (one memory request), lane l of DMA instruction i of wave w fills the 16 bytes at
+      // ((i * 8 + w) * 64 + l) * 16: row r = that >> 2, 16-byte position q = l & 3, which holds piece (kk * 2 + half) = q ^ ((r >> 2) & 3)
+      // (the XOR keeps the 64-byte-stride fragment reads free of bank conflicts)
+      static_assert(SCK == 2, "a stage row = 2 K steps x 2 halves x 16 B");
+      int xsrc[2];   // per DMA instruction: (pixel index) << 8 | byte offset of the piece inside the pixel's 64 B
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = ((i * 8 + wave) * 64 + lane) >> 2;
+        const int xtile = r & 63, xj = r >> 6;
+        const int piece = (lane & 3) ^ ((r >> 2) & 3);
+        xsrc[i] = (((h0 + (xtile >> 2)) * W + w0 + 4 * (xtile & 3) + xj) << 8) | (piece * 16);
+      }
       const unsigned lane16e = (unsigned)(lane * 16);
-      auto stage_dma = [&](int st) {   // x of stage st -> XS[st & 1], weights of stage st -> this wave's buffer st & 1
-        const int c0 = st * 16 * SCK;
+      // x of stage st -> x buffer `slot`, weights of stage st -> this wave's buffer `slot`; past the last stage: a harmless re-read of
+      // stage 0 (every stage issues the same number of requests: the waits below count them)
+      auto stage_dma = [&](int st, int slot) {
+        const int ste = st < nstage ? st : 0;
+        const int c0 = ste * 16 * SCK;
         const bool first = c0 < S0;
         const bf16* const xb = first ? xb0 : xb1;
         const int Cs = first ? S0 : Stot - S0, cc = first ? c0 : c0 - S0;
-        const unsigned voff = (unsigned)((xpix * Cs + cc) * 2 + xhalf16);
-  #pragma unroll
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          glds16s(xb, (unsigned)(((xsrc[i] >> 8) * Cs + cc) * 2 + (xsrc[i] & 255)), (unsigned)(XS_OFF + slot * XS_BYTES + i * 8192 + wave * 1024));
+#pragma unroll
         for (int kk = 0; kk < SCK; ++kk)
-          glds16s(xb, voff + kk * 32, (unsigned)(XS_OFF + (st & 1) * XS_BYTES + kk * 8192 + wave * 1024));
-  #pragma unroll
-        for (int kk = 0; kk < SCK; ++kk)
-          glds16s_x2(wsc + (size_t)(st * SCK + kk) * SLAB, lane16e, (unsigned)(wave * (2 * SCK * 2048) + ((st & 1) * SCK + kk) * 2048));
+          glds16s_x2(wsc + (size_t)(ste * SCK + kk) * SLAB, lane16e, (unsigned)(wave * (SCD * SCK * 2048) + (slot * SCK + kk) * 2048));
       };
-      const int wa_sc = wave * (2 * SCK * 2048) + l31 * 32 + ((lh ^ ((l31 >> 3) & 1)) * 16);
-      const int xb_sc = XS_OFF + (2 * xt) * 2048 + l31 * 32 + ((lh ^ ((l31 >> 3) & 1)) * 16);
-      stage_dma(0);
+      const int wa_sc = wave * (SCD * SCK * 2048) + l31 * 32 + ((lh ^ ((l31 >> 3) & 1)) * 16);
+      // B fragment of (K step kk, plane pl, tile block nt): row r = (2 xt + pl) * 64 + nt * 32 + l31 at r * 64, piece kk * 2 + lh at
+      // position (kk * 2 + lh) ^ ((r >> 2) & 3) = ((kk * 2 + lh) ^ ((l31 >> 2) & 3))   (the row offsets are multiples of 16 rows)
+      const int xb_row = XS_OFF + ((2 * xt) * 64 + l31) * 64;
+      const int xb_sw = (l31 >> 2) & 3;
+#pragma unroll
+      for (int d = 0; d < SCD - 1; ++d) stage_dma(d, d);
+      int slot = 0;
       for (int st = 0; st < nstage; ++st) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * SCK * (SCD - 2)) : "memory");   // stage st has landed (this wave's part)
         lds_wait();
-        barrier();
-        if (st + 1 < nstage) stage_dma(st + 1);
-        const int par = st & 1;
-  #pragma unroll
+        barrier();                                                                  // ... everybody's; buffer (slot + SCD - 1) % SCD is free
+        const int nslot = slot == 0 ? SCD - 1 : slot - 1;                           // = (slot + SCD - 1) % SCD
+        stage_dma(st + SCD - 1, nslot);
+        const int wo = slot * SCK * 2048, xo = slot * XS_BYTES;
+#pragma unroll
         for (int kk = 0; kk < SCK; ++kk) {
-          const u32x4 a0 = rd(wa_sc + (par * SCK + kk) * 2048), a1 = rd(wa_sc + (par * SCK + kk) * 2048 + 1024);
+          const u32x4 a0 = rd(wa_sc + wo + kk * 2048), a1 = rd(wa_sc + wo + kk * 2048 + 1024);
           u32x4 bq[2][2];   // [plane][nt]
-  #pragma unroll
+#pragma unroll
           for (int pl = 0; pl < 2; ++pl)
-  #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) bq[pl][nt] = rd(xb_sc + par * XS_BYTES + kk * 8192 + pl * 2048 + nt * 1024);
-  #pragma unroll
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bq[pl][nt] = rd(xb_row + xo + (pl * 64 + nt * 32) * 64 + (((kk * 2 + lh) ^ xb_sw) * 16));
+#pragma unroll
           for (int pl = 0; pl < 2; ++pl)
-  #pragma unroll
+#pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
               acc[pl][0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bq[pl][nt]), acc[pl][0][nt], 0, 0, 0);
               acc[pl][1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bq[pl][nt]), acc[pl][1][nt], 0, 0, 0);
             }
         }
+        slot = slot + 1 == SCD ? 0 : slot + 1;
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-reads past the last stage
       lds_wait();
-      barrier();   // all fragment reads done: the staging buffers overlap the weight rings and the x stages
+      barrier();   // all fragment reads done: the staging buffers overlap the weight buffers and the x stages
+      load_bias_table();
     }
     FD_T2(t2_r[2] = __builtin_amdgcn_s_memtime();)
     // ---- E3 for all rounds (two staging buffers: one barrier per round)
