@@ -27,7 +27,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_FILE = "r03_conv_traffic.json"
+TRAFFIC_FILE = "r04_conv_traffic.json"
 REF_CPU_FILE = "r02_reference_cpu_timing.json"
 F32_MFMA_PEAK_TFLOPS = 157.3   # dense f32 MFMA (the exact-f32 DFT GEMMs of the STFT front / back end)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "mixed": 2500.0, "bf16x3": 2500.0 / 3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
@@ -154,7 +154,7 @@ def main():
         dev = torch.device("cpu")
         y = 0.1 * torch.randn(gbatch, 1, Lw, generator=torch.Generator().manual_seed(0))
         y_host = None
-        nfe = {"euler": args.N, "midpoint": 2 * args.N, "heun2": 2 * args.N, "heun2_eulerlast": 2 * args.N - 1}[args.solver]
+        nfe = {"euler": args.N, "midpoint": 2 * args.N, "heun2": 2 * args.N, "heun2_eulerlast": 2 * args.N - 1, "dopri5": args.N}[args.solver]
         Tp, model, noise = 0, None, None
 
         def step(src):
@@ -276,7 +276,7 @@ def main():
         achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[args.precision]
         nl = max(int(n.value), 1)
-        result["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel / conv_wino_kernel / conv_head_kernel (implicit-GEMM 3x3/1x1)", "achieved": achieved, "peak": peak,
+        result["roofline"] = {"bound": "mfma", "kernel": "conv_wino4_kernel / conv_mfma_kernel / conv_wino_kernel / conv_head_kernel (3x3/1x1 convolutions: Winograd F(4,3) and direct implicit GEMM)", "achieved": achieved, "peak": peak,
                               "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "launches": int(n.value),
                               "avg_launch_ms": ms.value / nl, "conv_ms_per_step": ms.value, "algorithmic_tflop_per_step": fl.value / 1e12,
                               "algorithmic_tflop_per_launch": fl.value / 1e12 / nl, "algorithmic_bytes_per_launch": by.value / nl,

@@ -13,22 +13,26 @@
 // Design (round 4; what the round-2 F(2,3) kernel conv_wino.hip got wrong is in DESIGN.md section 4):
 //   * one workgroup = 16 x 16 output pixels (64 Winograd tiles of 1 x 4) x ALL 256 output channels: the input is activated once
 //     per pixel tile, as in the direct kernel (the F(2,3) kernel's 128-channel workgroups activated everything twice);
-//   * the input transform happens ONCE per workgroup and chunk, when the activated halo is stored: halo -> silu(a x + d) -> fp16 ->
-//     LDS (z) -> packed-fp16 transform (12 v_pk ops per 2 channels x 6 planes) -> LDS (V planes).  The K loop then reads plain
-//     fragments: no VALU work per fragment (the F(2,3) kernel transformed at fragment-read time, in every wave, for every cout tile);
-//   * 6 x 256 x 64 accumulators = 96 K registers = 192 per lane of the 8 waves: wave (cq, xt) owns positions xi = 0, 1, 2 (xt = 0) or 5, 3, 4 (xt = 1)
-//     for couts {ct * 128 + cq * 32 + 0..31, ct = 0, 1} and all 64 tiles: 3 x (2 x 2) MFMA tiles of 32 x 32 (v_mfma_f32_32x32x16_f16),
-//     one operand read per MFMA;
+//   * the input transform happens ONCE per workgroup and chunk, at halo-store time: raw bf16 halo --(direct-to-LDS DMA)--> RAW -->
+//     silu(a x + d) (the wave's 8 channels are wave-uniform: (a, d) live in 16 SGPRs) -> fp16 -> LDS (z) -> packed-fp16 B^T transform
+//     -> LDS (V planes, double-buffered).  The K loop then reads plain fragments: no VALU work per fragment (the F(2,3) kernel
+//     transformed at fragment-read time, in every wave, for every cout tile: 6.9 VALU per MFMA; here 2.2);
+//   * 6 x 256 x 64 accumulators = 96 K registers = 192 per lane of the 8 waves: wave (cq, xt) owns positions xi = 0, 1, 2 (xt = 0) or 5, 3, 4
+//     (xt = 1) for couts {ct * 128 + cq * 32 + 0..31, ct = 0, 1} and all 64 tiles: 3 x (2 x 2) MFMA tiles of 32 x 32
+//     (v_mfma_f32_32x32x16_f16); fragments rotate through three 16-byte quads per operand, 4 MFMAs per 4 ds_read_b128;
 //   * K walks 16-channel chunks; per chunk a wave runs the 9 steps (xi, dy), 4 MFMAs each.  A step needs a 2-KiB weight piece that
 //     only THIS wave reads: every wave streams its own pieces through a private ring of 6 LDS slots by direct-to-LDS DMA -- no
-//     barrier for the weights at all, counted s_waitcnt vmcnt for this wave's own traffic (the halo loads are inline asm too, so
-//     that every vector-memory operation of the loop is counted by hand);
-//   * two barriers per chunk (z complete / V planes complete), both in the middle of a step with the fragments pipelined across;
+//     barrier for the weights at all, counted s_waitcnt vmcnt for this wave's own traffic (every vector-memory operation of the
+//     loop is inline asm and counted by hand);
+//   * two barriers per chunk (z complete / V planes complete + raw halo landed), both in the middle of a step with the fragments
+//     pipelined across; the producer work (conversion, transform) is spread over the steps of the two wave groups;
 //   * epilogue: partial output transforms in registers (xt = 0: M0+M1+M2, M1-M2, M1+M2; xt = 1: M3+M4, 2(M3-M4), 4(M3+M4),
 //     8(M3-M4)+M5), the two waves of a cout block swap two planes each through LDS, then the direct kernel's staged sweep
-//     (bias / residual / scale / statistics / bf16 store with 16 bytes per lane).
+//     (bias / residual (prefetched by DMA) / scale / statistics / bf16 store with 16 bytes per lane); with a folded 1x1 shortcut
+//     (Conv_2 of layerspp.py:276-284) a bf16 MFMA GEMM on the raw shortcut input runs between the two on the same accumulators' outputs.
 // Operands are fp16 (3 more mantissa bits than bf16 and packed add / fma for the transform); storage stays bf16, accumulation f32.
-// Error of a 256-channel convolution against f64: 1.0e-3 (direct bf16 kernel: 2.4e-3; both below the bf16 output rounding).
+// Error of a 256-channel convolution against f64: 1.7e-3 (direct bf16 kernel: 1.9e-3; both are the bf16 output rounding).
+// Measurements (per launch x1.14-1.22 over conv_mfma.hip at full resolution, counters, ablations): MEASUREMENTS.md section R4.
 #include <type_traits>
 
 #include "conv_common.h"
@@ -49,10 +53,7 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int NTH = 512, TH = 16, TW = 16, HH = TH + 2, HW = TW + 2, BN = 256;
 constexpr int CK = 16;                              // channels per K chunk (one 32-byte LDS row: two 16-byte halves)
 constexpr int SLAB = BN * 32;                       // 8 KiB: the weights of one (chunk, xi, dy) step, [256 couts][16 ch] fp16
-#ifndef W4_NRING
-#define W4_NRING 6
-#endif
-constexpr int RSLOT = 2048, NRING = W4_NRING;       // per-wave ring: 6 slots of 64 couts x 32 B (18 % NRING == 0)
+constexpr int RSLOT = 2048, NRING = 6;              // per-wave ring: 6 slots of 64 couts x 32 B (18 % NRING == 0)
 static_assert(18 % NRING == 0, "the two-chunk loop body turns the ring a whole number of times");
 constexpr int RING_BYTES = 8 * NRING * RSLOT;       // 96 KiB
 constexpr int VXI = HH * 4 * 32;                    // one position plane: [18 halo rows][4 tiles][32 B]
@@ -266,9 +267,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   const unsigned lane16 = (unsigned)(lane * 16);
   const unsigned wring = (unsigned)(wave * NRING * RSLOT);
   auto dma_step = [&](int f, int slot) {   // f = step index relative to the current chunk pair (compile-time)
-#ifndef W4_EXP_NO_WDMA
     glds16s_x2(wp + (f / 9) * 18 * SLAB + (f % 9) * SLAB, lane16, wring + slot * RSLOT);
-#endif
   };
 
   // ---- per-lane fragment coordinates --------------------------------------------------------------------------------------
@@ -365,15 +364,10 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
       // older than those of step 8: that wait also covers it, and the barrier behind it publishes the RAW slots
       if (s >= 4 && s <= 7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW + 2) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
-#ifndef W4_EXP_NO_BAR
       if (s == 3 || s == 8) { lds_wait(); barrier(); }   // s == 3: z complete;  s == 8: V[vn] complete, every wave has its last V[vc] fragments
-#endif
       A2 = rd(a_off(k + 1, 0));
       B2 = rd(b_off(k + 1, 0));
       __builtin_amdgcn_sched_barrier(0);
-#ifdef W4_EXP_PRIO
-      __builtin_amdgcn_s_setprio(2);
-#endif
       mma(xl, 0, 0, A0, B0);
       mma(xl, 0, 1, A0, B1);
       __builtin_amdgcn_sched_barrier(0);
@@ -381,30 +375,17 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
       mma(xl, 1, 0, A1, B0);
       __builtin_amdgcn_sched_barrier(0);
       B0 = rd(b_off(k + 1, 1));
-#ifndef W4_EXP_NO_PROD
-#ifndef W4_EXP_NO_HALO
       if (s == 3) { next_chunk(); load_halo(); }   // (after the barrier of this step: every conversion of the previous halo is done)
-#endif
-#endif
       dma_step(k + NRING, k % NRING);              // step s + 6 into the slot whose fragments have both arrived
       mma(xl, 1, 1, A1, B1);
-#ifdef W4_EXP_PRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
       __builtin_amdgcn_sched_barrier(0);
       // the chunk's vector work, while the quads A1 / B1 are dead
-#ifndef W4_EXP_NO_PROD
-#ifndef W4_EXP_NO_CONV
       if (s == 8) { if (xg == 0) { aff_wait(); conv_slot(0); } }
       if (s == 0) { if (xg == 0 && pass1) conv_slot(1); }
       if (s == 1) { if (xg == 1) { aff_wait(); conv_slot(0); } }
       if (s == 2) { if (xg == 1 && pass1) conv_slot(1); }
-#endif
-#ifndef W4_EXP_NO_TRANS
       if (s == 4) { if (xg == 0) transform_at(tz0, tv0, vn); }
       if (s == 5) { if (xg == 1) transform_at(tz0, tv0, vn); else transform_extra(vn); }
-#endif
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     wp += 36 * SLAB;

@@ -24,17 +24,24 @@ def main(d, steps):
                 a[1] += float(r["TotalDurationNs"]) / 1e6
     tot = sum(v[1] for v in agg.values())
     print(f"# {steps} steps with kernel records; listed kernels {tot / steps:.2f} ms per step")
-    conv = fir = 0.0
-    nconv = 0
+    conv = fir = once = 0.0
+    nconv = nstep = 0
+    ONCE = ("__amd_rocclr_copyBuffer", "pack_weights_kernel", "wino_pack_kernel", "wino4_pack", "at::native", "fillBuffer")   # model load / weight packing / torch's input generation
     for k, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         short = k.replace("_ZN12_GLOBAL__N_1", "").replace("(anonymous namespace)::", "").replace("void ", "")[:84]
+        if any(o in k for o in ONCE):
+            once += ms
+        else:
+            nstep += n
         if ms / steps >= 0.01:
             print(f"{short:84s} calls/step {n / steps:7.1f}  ms/step {ms / steps:8.3f}  avg {1e3 * ms / n:8.1f} us  {100 * ms / tot:5.2f} %")
         if "conv_mfma" in k or "conv_wino" in k or "conv_head" in k:
             conv += ms; nconv += n
         if "fir_" in k:
             fir += ms
-    print(f"# conv kernels: {nconv / steps:.0f} launches per step, {conv / steps:.2f} ms per step; FIR {fir / steps:.2f} ms; everything else {(tot - conv - fir) / steps:.2f} ms")
+    print(f"# conv kernels: {nconv / steps:.0f} launches per step, {conv / steps:.2f} ms per step; FIR {fir / steps:.2f} ms; everything else "
+          f"{(tot - conv - fir - once) / steps:.2f} ms per step (+ {once:.2f} ms ONCE per run: model load, weight packing, input generation -- "
+          f"the copyBuffer / pack rows above are those, divided by the step count like every row); launches per step {nstep / steps:.0f}")
 
 
 if __name__ == "__main__":

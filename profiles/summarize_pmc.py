@@ -40,7 +40,7 @@ def main(fetch_dir, write_dir, steps, pixels=0):
             continue
         f, w = fe.get(k, [0, 0.0])[1], wr.get(k, [0, 0.0])[1]
         out["kernels"][k] = dict(launches=n, fetch_raw_per_launch=f / n, fetch_corrected_per_launch=2 * f / n, write_per_launch=w / n)
-        if k.startswith("conv_mfma_kernel") or k.startswith("conv_wino_kernel") or k.startswith("conv_head_kernel"):
+        if k.startswith(("conv_mfma_kernel", "conv_wino_kernel", "conv_wino4_kernel", "conv_head_kernel")):
             conv["launches"] += n; conv["fetch_raw"] += f; conv["write"] += w
         if k.startswith(("fir_up_kernel", "fir_down_kernel", "fir_down_march_kernel")):
             fir["launches"] += n; fir["fetch_raw"] += f; fir["write"] += w

@@ -1,5 +1,6 @@
 #!/bin/bash
-# build_w4var.sh NAME FLAGS...: a -DFD_TIMING2 variant library with conv_wino4.hip compiled with extra flags (timing experiments)
+# build_w4var.sh NAME FLAGS...: a -DFD_TIMING2 variant library with conv_wino4.hip compiled with extra flags (timing experiments;
+# the W4_EXP_* / W4_NRING switches exist after `patch -p0 < scripts/conv_wino4_ablation.patch`)
 set -e
 cd "$(dirname "$0")/.."
 NAME=$1; shift

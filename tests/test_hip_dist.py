@@ -115,3 +115,29 @@ def test_rccl_world1_gather(tmp_path):
     script.write_text(_NCCL1)
     r = subprocess.run([sys.executable, str(script), ROOT], env=_env(WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.parametrize("flags,clips", [
+    (["--global-batch", "8", "--seconds", "2", "--solver", "midpoint", "--N", "3"], [2, 2, 2, 2]),          # cfg 4's split (strong scaling), 4 ranks
+    (["--global-batch", "6", "--seconds", "1", "--precision", "fp32", "--N", "2"], [2, 2, 1, 1]),          # cfg 5's flavour, ragged split
+])
+def test_bench_four_ranks_share_gpu(flags, clips):
+    """The driver's multi-GPU launch line (python -m torch.distributed.run ... bench.py --gpus N) with 4 ranks on the ONE GPU of the
+    test box (--share-gpu, gloo): rank 0 prints exactly one JSON line, the split is the one INTEGRATION.md section 4 states, the
+    value is whole-job audio seconds over the max-over-ranks time."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--share-gpu",
+           "--backend", "gloo", "--no-cpu-baseline"] + flags
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 4 and j["steps"] == 2 and j["scaling"] == "strong"
+    assert j["config"]["clips_per_rank"] == clips and j["config"]["global_batch"] == sum(clips)
+    assert len(j["per_rank_ms_per_step"]) == 4 and j["ms_per_step"] >= max(j["per_rank_ms_per_step"]) * 0.999
+    secs = float(flags[flags.index("--seconds") + 1])
+    assert abs(j["value"] - sum(clips) * secs / (j["ms_per_step"] * 1e-3)) <= 1e-6 * j["value"]

@@ -24,14 +24,21 @@ TOL_FWD = {"fp32": 2e-4, "bf16x3": 2e-4, "bf16": 3e-2, "mixed": 1.1e-2}
 TOL_WAVE = {"fp32": 5e-4, "bf16x3": 5e-4, "bf16": 1.3e-1, "mixed": 1.3e-1}
 # round 4: at FULL width the bf16 tolerances are DERIVED, not fitted: tests/golden/g19_bf16_prediction.json holds the error the
 # oracle makes on the same goldens when it rounds every conv operand AND every stored tensor to bf16 in float32 NumPy arithmetic
-# (make_golden_bf16_prediction.py: forward 1.008e-2 against G10, waveform 1.77e-2 / Euler-6 against G17); the HIP bf16 mode must
-# stay within 1.3 x that prediction (summation order, transcendental ulps; the fp16-operand Winograd launches round less).
+# (make_golden_bf16_prediction.py: forward 1.008e-2 against G10, waveform 1.77e-2 / Euler-6 against G17).  One forward of the HIP
+# bf16 mode must stay within 1.3 x that prediction (summation order, transcendental ulps; the fp16-operand Winograd launches round
+# less).  The WAVEFORM of enhance() is a different statistic: the random-weight field amplifies a perturbation by a factor that
+# depends on its direction, so on ONE (clip, noise) draw the error of any rounding model -- the oracle's included -- scatters by about
+# +-25 % around its mean (scripts/wino4_error_seeds.py, 8 draws x 4 convolution algorithms).  The contract is therefore
+#   mean over draws  <=  1.3 x mean prediction   and   every draw  <=  1.6 x its own prediction
+# over G17's draw plus the draws of g20_bf16_prediction_draws.npz (test_bf16_error_is_the_predicted_one); single-draw tests use 1.6.
+import importlib.util as _ilu
 import json as _json
 import os as _os
 from conftest import GOLDEN as _GOLDEN
 BF16_PRED = _json.load(open(_os.path.join(_GOLDEN, "g19_bf16_prediction.json")))
-TOL_FWD_FULL = {"fp32": 2e-4, "bf16x3": 2e-4, "bf16": 1.3 * BF16_PRED["forward_rel_l2"]["bf16_operands_and_storage"], "mixed": 1.1e-2}
-TOL_WAVE_FULL = {"fp32": 5e-4, "bf16x3": 5e-4, "bf16": 1.3 * max(BF16_PRED["enhance_rel_l2"].values()), "mixed": 1.7e-2}
+BF16_MEAN_FACTOR, BF16_DRAW_FACTOR = 1.3, 1.6
+TOL_FWD_FULL = {"fp32": 2e-4, "bf16x3": 2e-4, "bf16": BF16_MEAN_FACTOR * BF16_PRED["forward_rel_l2"]["bf16_operands_and_storage"], "mixed": 1.1e-2}
+TOL_WAVE_FULL = {"fp32": 5e-4, "bf16x3": 5e-4, "bf16": BF16_DRAW_FACTOR * max(BF16_PRED["enhance_rel_l2"].values()), "mixed": 1.7e-2}
 
 _cache = {}
 
@@ -76,22 +83,37 @@ def test_ncsnpp_full_width_golden(prec):
 
 def test_bf16_error_is_the_predicted_one():
     """The headline precision's contract as a derived assertion: the HIP bf16 mode's error against the REFERENCE (G10 forward, G17
-    enhance, both at full width) is at most 1.3 x the error of the oracle with bf16-rounded operands and storage on the same goldens
-    -- and not implausibly smaller either (a kernel that skipped work would not land inside [0.3, 1.3] x the model by accident)."""
+    enhance, both at full width; further draws against the float32 oracle) is at most 1.3 x the error of the oracle with bf16-rounded
+    operands and storage on the same inputs -- and not implausibly smaller either (a kernel that skipped work would not land inside
+    [0.3, 1.3] x the model by accident).  enhance: mean over the draws, and 1.6 x per draw (see the comment at TOL_WAVE_FULL)."""
     g = load_golden("g10_ncsnpp_nf64.npz")
     m = make_model(64, int(g["seed"]), "bf16")
     out = m(cu(g["x"]), cu(g["y"]), torch.tensor([0.5], device="cuda"))
     e = rel_err(out.cpu().numpy(), g["out"])
     pred = BF16_PRED["forward_rel_l2"]["bf16_operands_and_storage"]
-    report("bf16_forward_vs_prediction", e / pred, 1.3)
-    assert 0.3 * pred < e < 1.3 * pred, (e, pred)
+    report("bf16_forward_vs_prediction", e / pred, BF16_MEAN_FACTOR)
+    assert 0.3 * pred < e < BF16_MEAN_FACTOR * pred, (e, pred)
     g17 = load_golden("g17_enhance_nf64.npz")
+    errs, preds = [], []
     for solver, N in (("euler", 6), ("midpoint", 3)):
         x = m.enhance(torch.from_numpy(g17["y"]), N=N, solver=solver, noise=torch.from_numpy(g17["noise"]))
-        e = rel_err(x.numpy(), g17[f"{solver}_N{N}"])
-        pred = BF16_PRED["enhance_rel_l2"][f"{solver}_N{N}"]
-        report(f"bf16_enhance_vs_prediction[{solver}]", e / pred, 1.3)
-        assert 0.3 * pred < e < 1.3 * pred, (solver, e, pred)
+        errs.append(rel_err(x.numpy(), g17[f"{solver}_N{N}"]))
+        preds.append(BF16_PRED["enhance_rel_l2"][f"{solver}_N{N}"])
+    g20 = load_golden("g20_bf16_prediction_draws.npz")
+    assert int(g20["weights_seed"]) == int(g17["seed"])
+    spec = _ilu.spec_from_file_location("_draws", _os.path.join(_GOLDEN, "make_golden_bf16_prediction_draws.py"))
+    gen = _ilu.module_from_spec(spec); spec.loader.exec_module(gen)
+    for i, seed in enumerate(g20["seeds"]):
+        y, nz = gen.draw(int(seed))
+        x = m.enhance(torch.from_numpy(y), N=6, solver="euler", noise=torch.from_numpy(nz))
+        errs.append(rel_err(x.numpy(), g20[f"truth{i}"]))
+        preds.append(float(g20["predicted_rel_l2"][i]))
+    for i, (e, p) in enumerate(zip(errs, preds)):
+        report(f"bf16_enhance_vs_prediction[draw {i}]", e / p, BF16_DRAW_FACTOR)
+        assert 0.3 * p < e < BF16_DRAW_FACTOR * p, (i, e, p)
+    ratio = float(np.mean(errs) / np.mean(preds))
+    report("bf16_enhance_vs_prediction[mean over draws]", ratio, BF16_MEAN_FACTOR)
+    assert 0.3 < ratio < BF16_MEAN_FACTOR, (errs, preds)
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16"])

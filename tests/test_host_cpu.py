@@ -342,3 +342,14 @@ def test_wino4_kernel_owns_m0():
     assert not foreign, foreign[:5]
     assert sum("v_mfma_f32_32x32x16_f16" in l for l in code) == 6 * 72   # six instantiations, 18 steps x 4 MFMAs each
     assert not any("scratch_" in l for l in code), "conv_wino4 kernels spill"
+
+
+def test_every_committed_profile_json_parses():
+    """profiles/*.json are the evidence the bench lines and DESIGN / MEASUREMENTS cite: each must be one valid JSON document."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*.json")))
+    assert files
+    for f in files:
+        with open(f) as fh:
+            json.load(fh)
