@@ -25,7 +25,7 @@
 //     squares of the f32 result are reduced per tile for the consumer GroupNorm (deterministic, no atomics).
 //
 // One kernel template, several configurations (all of them run the same K order per output, so the convolution result is the same
-// bits whatever the workgroup shape; DESIGN.md section 4 has the measurements behind each):
+// bits whatever the workgroup shape; MEASUREMENTS.md "Direct kernel" / "Small grids" has the measurements behind each):
 //   <WM, WN, MT, NT>  wave grid and MFMA tiles per wave: 8 waves x (128 px x 64 cout) = BN 256 by default, narrower ones for few output
 //                     channels and for small grids (FD_TILE_*);
 //   CW                chunk-resident weight ring + fragments two phases ahead, one barrier per chunk (the low-latency configurations);

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino_kernel(ConvArgs p) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(afftab + naff + 16 * j);
       r = pack_f16(fd_silu(fmaf(x0, a[0], a[1])), fd_silu(fmaf(x1, a[2], a[3])));
     } else {   // raw input (activated / resampled upstream, or the shortcut input): saturate at HALF the fp16 range, so that the
-               // transform z[a] +- z[b] (packed fp16) cannot overflow to inf either.  Dynamic-range contract: DESIGN.md section 5.
+               // transform z[a] +- z[b] (packed fp16) cannot overflow to inf either.  Dynamic-range contract: MEASUREMENTS.md "Parity detail".
       r = pack_f16(__builtin_amdgcn_fmed3f(x0, -32752.f, 32752.f), __builtin_amdgcn_fmed3f(x1, -32752.f, 32752.f));
     }
     // zero padding AFTER the activation -- as an AND: a select around the SiLU becomes a divergent branch per word, and a branch

@@ -10,7 +10,7 @@
 //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
 // summed over the three kernel rows dy and all input channels in the accumulators of position xi = 0..5.
 //
-// Design (round 4; what the round-2 F(2,3) kernel conv_wino.hip got wrong is in DESIGN.md section 4):
+// Design (round 4; what the round-2 F(2,3) kernel conv_wino.hip got wrong: MEASUREMENTS.md, "conv_wino_kernel"):
 //   * one workgroup = 16 x 16 output pixels (64 Winograd tiles of 1 x 4) x ALL 256 output channels: the input is activated once
 //     per pixel tile, as in the direct kernel (the F(2,3) kernel's 128-channel workgroups activated everything twice);
 //   * the input transform happens ONCE per workgroup and chunk, at halo-store time: raw bf16 halo --(direct-to-LDS DMA)--> RAW -->

@@ -16,9 +16,9 @@ pytestmark = pytest.mark.gpu
 # measured floors on the nf=8 golden model: rounding ONLY the conv operands to bf16 in the oracle (everything else f32)
 # already gives 1.2e-2 on one forward and 6.4e-2 on the final waveform (|X|^(1/0.3) decompression amplifies 3.3x);
 # the HIP bf16 path measures 1.6e-2 / 8-10e-2, the f32 path 2e-6 / 1e-5.
-# round 2: the bf16 waveform tolerance is the measured error x 1.3 (DESIGN section 5 states it as the path's contract):
+# round 2: the nf = 8 bf16 waveform tolerance is the measured error x 1.3:
 #   nf = 8 toy model (random weights, very sensitive): 8.5-9.9e-2 measured -> 0.13
-#   full width (nf = 64) against the reference's own enhance() (golden G17): 1.8e-2 (Euler 6) / 2.3e-2 (midpoint 3) -> 0.031
+#   (full width: derived bounds, below)
 # precision="bf16x3" (split-bf16 operands) is held to the FP32 mode's tolerances; "mixed" (f32 residual stream, bf16 operands): measured x 1.3
 TOL_FWD = {"fp32": 2e-4, "bf16x3": 2e-4, "bf16": 3e-2, "mixed": 1.1e-2}
 TOL_WAVE = {"fp32": 5e-4, "bf16x3": 5e-4, "bf16": 1.3e-1, "mixed": 1.3e-1}
