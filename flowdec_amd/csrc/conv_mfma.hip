@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   auto next_chunk = [&](int s, int ch) {
     const Seg sg = p.seg[s];
     const TS* src = reinterpret_cast<const TS*>(sg.src) + (size_t)lb * img_elems * sg.C;
-    nsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<TS*>(src), 0, (int)(img_elems * sg.C * sizeof(TS)), 0x00020000);
+    nsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<TS*>(src), 0, (int)(unsigned)(img_elems * sg.C * sizeof(TS)), 0x00020000);   // num_records: unsigned 32 bits
     nC = sg.C;
     const int c = SPLIT ? ch * CK + (q & 1) * 8 : ch * CK + q * EPS;   // SPLIT: slots 0,1 = hi, 2,3 = lo of the same 16 channels
     nchan_ok = c < sg.C;
@@ -301,9 +301,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvArgs p) 
   };
   int npix_on = 1;   // 0: the prefetch target is unused (last chunk of the K loop) -> every lane re-reads pixel 0 (one cache line, no HBM traffic)
   auto load_halo_slot = [&](int i) {
-    const int off = (pixl[i] * npix_on * nC + nc) * (int)sizeof(TS);
-    hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(nsrd, off, 0, 0);
-    if constexpr (MIXED) hreg_hi[i] = __builtin_amdgcn_raw_buffer_load_b128(nsrd, off + 16, 0, 0);
+    // byte offset inside ONE image, unsigned 32 bits: an f32 image of a 30 s clip is 2.97 GB (the buffer resource's range is 4 GiB)
+    const unsigned off = ((unsigned)(pixl[i] * npix_on) * (unsigned)nC + (unsigned)nc) * (unsigned)sizeof(TS);
+    hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(nsrd, (int)off, 0, 0);
+    if constexpr (MIXED) hreg_hi[i] = __builtin_amdgcn_raw_buffer_load_b128(nsrd, (int)(off + 16u), 0, 0);
   };
   // the LDS image of slot i, in place: silu(a*x+d) (or the storage -> operand conversion), zero padding AFTER the activation
   auto convert_slot = [&](int i) {
@@ -1328,8 +1329,10 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   FD_REQUIRE(B > 0 && H > 0 && W > 0, "fd_conv2d: bad shape");
   FD_REQUIRE(bias == nullptr || bias_rows == 1 || bias_rows == B, "fd_conv2d: bias_rows must be 1 or B");
   int cm = C0; if (C1 > cm) cm = C1; if (S0 > cm) cm = S0; if (S1 > cm) cm = S1; if (Cout > cm) cm = Cout;
-  FD_REQUIRE((long long)H * W * cm * (dtype == FD_BF16 ? 2 : 4) < (1ll << 31),
-             "fd_conv2d: one image of %d x %d x %d elements exceeds 2 GiB (32-bit buffer offsets; ~43 s of audio in bf16, ~21 s in f32)", H, W, cm);
+  // 32-bit byte offsets inside one image: unsigned in the direct kernel (4 GiB: ~43 s of audio with f32 storage), the bf16-only kernels
+  // (Winograd, heads) keep the signed range (2 GiB: ~43 s in bf16 as well)
+  FD_REQUIRE((long long)H * W * cm * (dtype == FD_BF16 ? 2 : 4) < (dtype == FD_BF16 ? (1ll << 31) : (1ll << 32)),
+             "fd_conv2d: one image of %d x %d x %d elements exceeds %d GiB (32-bit buffer offsets; ~43 s of audio)", H, W, cm, dtype == FD_BF16 ? 2 : 4);
   FD_TRY(fd_conv_init_attributes());
   const int taps = ksize * ksize;
   ConvArgs a{};

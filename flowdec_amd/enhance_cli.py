@@ -14,9 +14,10 @@ selects the EMA weights exactly like `demo.ipynb` cell 2.
 Non-48 kHz input is resampled with a restatement of torchaudio.functional.resample(..., lowpass_filter_width=64)
 (enhance.py:118; torchaudio itself is not a dependency): `sinc_resample_kernel` / `resample` below.
 
-Length limit: the reference skips files longer than 30 s.  One image of the conv kernel must stay below 2 GiB (32-bit buffer
-offsets), which the f32-storage precisions (fp32 / mixed / bf16x3) reach at ~21 s: with those, files between 20 s and
-30 s are skipped WITH a message that says so and the exit status is 3 (the reference would have processed them).
+Length limit: the reference skips files longer than 30 s; so does this driver, in every precision (one image of the conv kernels
+must stay below 2 GiB in bf16 and below 4 GiB with f32 storage -- 32-bit byte offsets inside an image -- both ~43 s of audio).
+`PRECISION_MAX_SECONDS` is where a precision with a shorter reach would say so: such files are then skipped WITH a message and
+the exit status is 3 (the reference would have processed them).
 """
 import argparse
 import contextlib
@@ -34,6 +35,7 @@ import torch
 from .model import BACKBONE_FINAL_NO_ATTN, AmplitudeCompressedComplexSTFT, FlowModel, NCSNpp, from_preset
 
 MAX_SECONDS = 30.0  # enhance.py:115
+PRECISION_MAX_SECONDS = {}   # precision -> clip length it can take, if shorter than MAX_SECONDS (none since round 4: every mode reaches ~43 s)
 PRECISION_NOTE = {   # printed at start-up so that a log says which arithmetic produced the files
     "bf16": "bf16 storage and MFMA operands, f32 accumulation; ~2e-2 relative waveform error vs the fp32 reference on random weights",
     "mixed": "f32 residual stream, bf16 MFMA operands; ~1.3e-2",
@@ -307,8 +309,7 @@ def run(argv=None, model: Optional[FlowModel] = None) -> RunResult:
     if args.seed is not None:
         gen = torch.Generator(device=model.device).manual_seed(args.seed)
     res = RunResult()
-    # one image must stay below 2 GiB (32-bit buffer offsets of the conv kernel): ~43 s in bf16, ~21 s with f32 storage
-    max_seconds = MAX_SECONDS if args.precision == "bf16" else min(MAX_SECONDS, 20.0)
+    max_seconds = min(MAX_SECONDS, PRECISION_MAX_SECONDS.get(args.precision, MAX_SECONDS))
     print(f"flowdec_amd: precision={args.precision} ({PRECISION_NOTE[args.precision]}), solver={args.solver}, N={args.N}")
     with (open(triples_path, "w") if triples_path else contextlib.nullcontext()) as trf, \
             (open(rtf_path, "w") if rtf_path else contextlib.nullcontext()) as rtf_f:

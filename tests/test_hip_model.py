@@ -278,6 +278,29 @@ def test_longest_cli_clip_full_width():
     assert torch.equal(two[:1], one)
 
 
+def test_longest_cli_clip_f32_storage_modes():
+    """The same 30 s clip in the f32-storage modes (one activation tensor = 2.97 GB: byte offsets beyond 2^31 inside an image, which
+    the direct kernel addresses as UNSIGNED 32 bits): `bf16x3` and `fp32` agree to the fp32 tolerance over the whole clip AND over its
+    last two seconds (the highest addresses), and both agree with the bf16 mode (whose images stay below 2^31) to the bf16 tolerance."""
+    L = 30 * 48000
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    y = 0.1 * torch.randn(1, 1, L, device="cuda", generator=gen)
+    nz = torch.randn(1, 1, 768, 3776, dtype=torch.complex64, device="cuda", generator=gen)
+    outs = {}
+    for prec in ("bf16", "bf16x3", "fp32"):
+        m = make_model(64, 64, prec)
+        outs[prec] = m.enhance(y, N=1, solver="euler", noise=nz).cpu().numpy()
+        assert np.isfinite(outs[prec]).all() and np.abs(outs[prec]).max() > 0
+        _cache.pop((64, 64, prec), None) if prec != "bf16" else None      # free the f32 workspaces (tens of GB) before the next mode
+        del m
+        torch.cuda.empty_cache()
+    tail = slice(L - 2 * 48000, L)
+    check("longest_clip[bf16x3 vs fp32]", outs["bf16x3"], outs["fp32"], TOL_WAVE_FULL["bf16x3"])
+    check("longest_clip_tail[bf16x3 vs fp32]", outs["bf16x3"][..., tail], outs["fp32"][..., tail], TOL_WAVE_FULL["bf16x3"])
+    check("longest_clip[bf16 vs fp32]", outs["bf16"], outs["fp32"], TOL_WAVE_FULL["bf16"])
+    check("longest_clip_tail[bf16 vs fp32]", outs["bf16"][..., tail], outs["fp32"][..., tail], TOL_WAVE_FULL["bf16"])
+
+
 def test_many_clip_lengths_graph_cache():
     """A file-by-file driver sees many clip lengths: more distinct captured graphs than the cache holds (32) must keep
     working, and a length seen before gives the same waveform again."""
