@@ -337,9 +337,9 @@ struct Fwd {
   // the IMAGE only, never at the batch: a clip must give the same bits alone, in a batch, or in a shard of a batch (section 8(e)).
   bool auto_wino(const Tens& out) const { return fd_cdiv(out.H, 16) * fd_cdiv(out.W, 16) <= 96; }
   // FD_LOW_LATENCY (one short clip on the whole chip; profiles/r02_latency_tiles.txt): images of at most 24 tiles run the direct
-  // kernel with 32-channel workgroups and chunk-resident weights (8 x the workgroups, one barrier per chunk); the Winograd kernel
+  // kernel with 32-channel workgroups and chunk-resident weights (8 x the workgroups, one barrier per chunk); the F(2,3) kernel
   // (128-channel workgroups) takes everything else up to 512 tiles unless a 1x1 shortcut is folded in; those run the direct kernel with
-  // 128-channel workgroups up to 128 tiles.  By image size only.
+  // 128-channel workgroups up to 128 tiles and the F(4,3) kernel above, which also takes everything above 512 tiles.  By image size only.
   int conv(const Tens& a, const Tens* b, size_t aff, const Tens* s0, const Tens* s1, const void* w, const float* bias, int bias_rows,
            const Tens* skip, float scale, Tens& out, int ks, bool want_stats, bool wino = false, const void* w_wino = nullptr,
            const void* w_wino4 = nullptr) {
@@ -358,7 +358,10 @@ struct Fwd {
     // MFMAs of the direct kernel, 1.09-1.19x per launch (profiles/r04_wino4_vs_direct.txt); whole 16 x 16 tiles only
     // (not the 64-channel input of the first block: 0.93-1.0x there)
     // (a folded 1x1 shortcut runs as a bf16 GEMM on the raw residual stream in that kernel's epilogue: no fp16 range issue)
-    else if (autosel && w_wino4 && !(s0 && skip) && out.H % 16 == 0 && out.W % 16 == 0 && a.C + (b ? b->C : 0) >= 128) { w = w_wino4; wino4 = true; }
+    // (FD_LOW_LATENCY: the folded-shortcut launches above 128 tiles, which the F(2,3) rule leaves to the direct kernel, and everything
+    // above that rule's 512 tiles: one 1 s clip 60.0 -> 62.9x, one 2 s clip 79 -> 88x real time)
+    else if ((autosel || (latency && ((s0 && px_tiles > 128) || px_tiles > 512))) && w_wino4 && !(s0 && skip) && out.H % 16 == 0 && out.W % 16 == 0 &&
+             a.C + (b ? b->C : 0) >= 128) { w = w_wino4; wino4 = true; }
     // one clip, folded-shortcut convolutions of the 384 x 64 level (96 tiles): 96 workgroups of 256 channels leave 160 CUs idle; 128-channel
     // workgroups are 1.28-1.39x per launch there (scripts/ab_conv_b1.py with AB_H=384 AB_W=64), same bits
     else if (latency && px_tiles <= 128 && out.C >= 256 && out.C % 128 == 0) tile = FD_TILE_BN128;
@@ -897,7 +900,7 @@ extern "C" int fd_model_finalize(fd_model* m, void* stream) {
         if (both && fd_conv_packed_bytes(md.cout, md.cout, 0, 3, md.has_c2 ? md.c0 : 0, md.has_c2 ? md.c1 : 0, m->dt | FD_WINOGRAD) > 0)
           FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, md.has_c2 ? p + "Conv_2.weight" : std::string(), md.has_c2 ? md.c0 : 0,
                            md.has_c2 ? md.c1 : 0, &md.w1w, st, FD_WINOGRAD));
-        const bool both4 = (m->cfg.act_dtype & FD_WINOGRAD_AUTO) != 0;
+        const bool both4 = (m->cfg.act_dtype & (FD_WINOGRAD_AUTO | FD_LOW_LATENCY)) != 0;
         if (both4 && fd_conv_packed_bytes(md.cout, md.c0, md.c1, 3, 0, 0, m->dt | FD_WINOGRAD4) > 0)
           FD_TRY(pack_conv(m, p + "Conv_0.weight", md.cout, md.c0, md.c1, 3, "", 0, 0, &md.w0w4, st, FD_WINOGRAD4));
         if (both4 && fd_conv_packed_bytes(md.cout, md.cout, 0, 3, md.has_c2 ? md.c0 : 0, md.has_c2 ? md.c1 : 0, m->dt | FD_WINOGRAD4) > 0)
