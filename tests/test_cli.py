@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import flowdec_oracle as O
+from conftest import ROOT
 
 
 def synthetic_ckpt(nf=8, seed=8, with_hp=True):
@@ -193,3 +194,24 @@ def test_cli_end_to_end(tmp_path):
     ref_o = O.enhance(O.NCSNppOracle(sd, nf=8), y.numpy()[None], noise.cpu().numpy(), np.full((768, 1), 0.4), N=2, solver="midpoint")
     err = float(np.linalg.norm(a32.numpy() - ref_o[0]) / np.linalg.norm(ref_o[0]))
     assert err < 5e-4, f"CLI vs oracle: {err:.3e}"
+
+
+@pytest.mark.gpu
+def test_real_checkpoint_check_script(tmp_path):
+    """scripts/real_checkpoint_check.py (the first-run-on-a-real-checkpoint one-liner) on a synthetic Lightning checkpoint: the three
+    precisions run on the same noise, the report carries per-file errors, PASS / FAIL follows the thresholds."""
+    import importlib.util
+    from flowdec_amd import enhance_cli
+    spec = importlib.util.spec_from_file_location("rcc", os.path.join(ROOT, "scripts", "real_checkpoint_check.py"))
+    rcc = importlib.util.module_from_spec(spec); spec.loader.exec_module(rcc)
+    torch.save(synthetic_ckpt(), tmp_path / "m.ckpt")
+    ind = tmp_path / "in"; ind.mkdir()
+    rng = np.random.default_rng(1)
+    for name, n, sr in (("a.wav", 24000, 48000), ("b.wav", 12000, 16000)):
+        enhance_cli.save_wav(str(ind / name), torch.from_numpy((0.1 * rng.standard_normal(n)).astype(np.float32))[None], sr)
+    rep = rcc.run(["--ckpt", str(tmp_path / "m.ckpt"), "--files", str(ind), "--N", "2", "--solver", "midpoint", "--tol", "0.3",
+                   "--report", str(tmp_path / "r.json")])
+    assert rep["verdict"] == "PASS" and len(rep["files"]) == 2 and os.path.exists(tmp_path / "r.json")
+    assert all(r["bf16x3_rel_l2"] < 5e-4 and 1e-4 < r["bf16_rel_l2"] < 0.3 for r in rep["files"])   # (nf = 8 toy model: bf16 ~ 1e-1)
+    rep = rcc.run(["--ckpt", str(tmp_path / "m.ckpt"), "--files", str(ind), "--N", "2", "--solver", "midpoint", "--tol", "1e-4"])
+    assert rep["verdict"] == "FAIL"
