@@ -64,9 +64,10 @@ constexpr int ZROW = HW + 4;                        // z row: halo column c at p
 constexpr int ZPLANE = HH * ZROW * 16;              // 6336 = 64 (mod 128): the two channel-half planes are 16 banks apart
 constexpr int Z_BYTES = 2 * ZPLANE;                 // activated halo, [channel half 2][18 rows][22 slots][16 B]: conflict-free for the
                                                     // wave-uniform-half stores of the conversion AND the word-wise reads of the transform
-constexpr int RAW_OFF = Z_OFF + Z_BYTES;            // raw halo (bf16) as the DMA delivers it: slot s at s * 16, padded to 1024 slots
-constexpr int RAW_BYTES = 2 * NTH * 16;
-constexpr int MAIN_BYTES = RAW_OFF + RAW_BYTES;     // 152704
+constexpr int RAW_OFF = Z_OFF + Z_BYTES;            // raw halo (bf16) of a chunk PAIR as the DMA delivers it: 64 B per pixel = [chunk parity][half][16 B],
+constexpr int RAW_PASSES = 3;                       // piece s = 4 * pixel + 2 * parity + half at s * 16; 1296 pieces, padded to 3 passes of 512 lanes
+constexpr int RAW_BYTES = RAW_PASSES * NTH * 16;    // 24576
+constexpr int MAIN_BYTES = RAW_OFF + RAW_BYTES;     // 163200
 // epilogue: exchange buffer [wave][plane][4][64 lanes x 16 B] = the staging of one round (128 pixels x 128 couts f32, padded rows)
 // in the same bytes (a barrier apart), two residual buffers (one round each: 4 passes x 512 threads x 16 B), bias, statistics
 constexpr int X_BYTES = 8 * 8192;                   // exchange buffer (two of them: one barrier per round)
@@ -80,8 +81,8 @@ constexpr int BIAS_OFF = 2 * S_BYTES;               // = 135168: [256] f32; abov
 static_assert(BIAS_OFF >= 2 * X_BYTES && BIAS_OFF >= SK_OFF + 2 * SK_BYTES && XS_OFF + SCD * XS_BYTES <= 160 * 1024, "epilogue LDS map");
 constexpr int STAT_OFF = BIAS_OFF + 1024;           // [2][8 waves][16 octets][16] f32 = 16 KiB
 constexpr int LDS_BYTES = cmax(MAIN_BYTES, STAT_OFF + 16384);
-constexpr int NSLOT = HH * HW * 2;                  // 648 halo slots of 16 B (8 channels) per chunk
-static_assert(LDS_BYTES <= 160 * 1024 && NSLOT <= 2 * NTH, "LDS layout");
+constexpr int NPIECE = HH * HW * 4;                 // 1296 raw pieces of 16 B (8 channels) per chunk pair
+static_assert(LDS_BYTES <= 160 * 1024 && NPIECE <= RAW_PASSES * NTH && HH * HW <= 2 * 256, "LDS layout");
 constexpr float RAW_MAX = 6000.f;                   // raw (not activated) inputs saturate here: |V| <= 10 |z| stays finite in fp16
 
 __device__ __forceinline__ unsigned pack_f16(float a, float b) {
@@ -129,14 +130,15 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int cq = wave & 3, xt = wave >> 2;
 
-  // ---- halo loader.  A chunk's halo is 324 pixels x two 8-channel halves (16 B of bf16 each).  Wave w loads half hq = w & 1 of the
-  // pixels hp = i * 256 + (w >> 1) * 64 + lane in pass i = 0, 1 (pass 1: 68 pixels, waves 0..3 only) -- the half is WAVE-UNIFORM, so
-  // the GroupNorm affine (a, d) of the wave's 8 channels is 16 scalar registers (one s_load_dwordx16 per chunk: no LDS table, no LDS
-  // reads in the conversion).  The raw bf16 slots go straight to LDS by DMA (RAW buffer: pass i of wave w at (i * 8 + w) KiB, lane
-  // order); the lane that requested a slot later reads it back, activates it and stores it as fp16 into z -- nothing is held in
-  // registers while the load is in flight, nobody else touches a RAW slot (no barrier between the DMA and the read).
-  // The K loop is bound by vector-instruction issue as soon as the per-chunk work costs more than a few hundred instructions per wave
-  // (SQ counters, profiles/r04_wino4_*): everything a lane needs per chunk is computed ONCE here and kept in registers. ----------
+  // ---- halo loader.  The halo of a chunk PAIR (32 channels) is requested at once: 324 pixels x 64 contiguous bytes, FOUR adjacent
+  // lanes per pixel (one memory request per pixel and pair: the 32-byte gathers of a per-chunk request were a third of the vector L1's
+  // time), three passes of 512 lanes, straight to LDS by DMA (RAW: piece 4 pixel + 2 parity + half at 16 bytes each, pass i of wave w
+  // at (i * 8 + w) KiB in lane order).  CONVERSION, per chunk: wave w converts channel half hq = w & 1 of the pixels hp = i * 256 +
+  // (w >> 1) * 64 + lane in pass i = 0, 1 (pass 1: 68 pixels, waves 0..3 only) -- the half is WAVE-UNIFORM, so the GroupNorm affine
+  // (a, d) of the wave's 8 channels is 16 scalar registers (one s_load_dwordx16 per chunk: no LDS table); the lane reads the piece back
+  // (written by another lane's request), activates it and stores it as fp16 into z -- nothing is held in registers while the load is in
+  // flight.  The K loop is bound by vector-instruction issue as soon as the per-chunk work costs more than a few hundred instructions
+  // per wave (SQ counters, profiles/r04_wino4_*): everything a lane needs per chunk is computed ONCE here and kept in registers. -----
   auto opaque = [&](int v) { asm volatile("" : "+v"(v)); return v; };
   const size_t img_elems = (size_t)H * W;
   // the (at most two) concat segments in scalar registers: no kernel-argument loads inside the K loop
@@ -148,30 +150,29 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   const int hq = wave & 1;
   const bool pass1 = wave < 4;       // (the other waves request a duplicate in pass 1 -- every wave has the same number of
                                      //  vector-memory operations in flight -- and skip its conversion)
-  // per-lane halo constants.  REQUEST side: lane l of wave w fetches slot s = t (+ 512 in pass 1) = (pixel s >> 1, half s & 1): two
-  // adjacent lanes share a pixel's 32 bytes (one memory request instead of two), the slot lands at RAW + s * 16.  CONVERSION side: the
-  // wave converts half hq of the pixels hp(i): RAW slot (hp * 2 + hq), written by another lane -- hence the ordering "request after
-  // the barrier of step 3 (every conversion of the previous halo is done), landed before the barrier of step 8 (every wave waits for
-  // its own requests first), converted after it".  Pixels outside the image: the request reads pixel 0 (harmless), the conversion
-  // masks the value.  Lanes without a pixel in pass 1 redo pass 0 (same bytes to the same z address).
-  int hpix[2], zadr[2];
+  // per-lane halo constants.  Ordering between the request side (lane t, piece t + 512 i) and the conversion side (piece (hp * 4 + 2 e +
+  // hq), written by another lane): "request after the barrier of step 3 of an even chunk (every conversion of the previous pair is done),
+  // landed before the barrier of step 8 (every wave waits for its own requests first), converted after it".  Pixels outside the image:
+  // the request reads pixel 0 (harmless), the conversion masks the value.  Lanes without a pixel in pass 1 redo pass 0.
+  int hpix[RAW_PASSES], zadr[2];
   unsigned hvalid = 0;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    {   // request side
-      const int sl = t + i * NTH;
-      const int hp = sl < NSLOT ? sl >> 1 : 0;
-      const int hr = hp / HW, hc = hp - hr * HW;
-      const int gh = h0 - 1 + hr, gw = w0 - 1 + hc;
-      hpix[i] = (gh >= 0 && gh < H && gw >= 0 && gw < W) ? gh * W + gw : 0;
-    }
+  for (int i = 0; i < RAW_PASSES; ++i) {   // request side: piece sl = t + 512 i -> pixel sl >> 2 (four adjacent lanes share a pixel's 64 bytes)
+    const int sl = t + i * NTH;
+    const int hp = sl < NPIECE ? sl >> 2 : 0;
+    const int hr = hp / HW, hc = hp - hr * HW;
+    const int gh = h0 - 1 + hr, gw = w0 - 1 + hc;
+    hpix[i] = (gh >= 0 && gh < H && gw >= 0 && gw < W) ? gh * W + gw : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {            // conversion side
     const int base = ((t >> 7) << 6) + lane;
     const bool has = i == 0 || base + 256 < HH * HW;
     const int hp = has ? base + i * 256 : base;
     const int hr = hp / HW, hc = hp - hr * HW;
     const int gh = h0 - 1 + hr, gw = w0 - 1 + hc;
     const bool ok = gh >= 0 && gh < H && gw >= 0 && gw < W;
-    zadr[i] = (hp * 2 + hq) * 16 + ((hq * ZPLANE + (hr * ZROW + hc + (hc >> 2)) * 16) << 16);   // low half: RAW slot offset, high half: z offset
+    zadr[i] = (hp * 4 + hq) * 16 + ((hq * ZPLANE + (hr * ZROW + hc + (hc >> 2)) * 16) << 16);   // low half: RAW piece offset (parity 0), high half: z offset
     if (ok) hvalid |= 1u << i;
   }
   // state of the chunk whose halo is in flight / being converted (wave-uniform)
@@ -197,16 +198,16 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   };
   // past the end of the K loop every lane re-reads element 0 of the last tensor (one cache line; the data is never used)
   const unsigned rawdst = (unsigned)(RAW_OFF + wave * 1024);
-  auto load_halo = [&]() {
+  auto load_halo = [&]() {                // the 32 channels of the chunk pair that starts at the chunk next_chunk has just set up
     const int on = cnext <= n3 ? 1 : 0;   // (next_chunk has already counted this request)
-    const int h16 = (opaque(t) & 1) * 16;
-    glds16s(nbase, (unsigned)((hpix[0] * nC2 + ncb + h16) * on), rawdst);
-    glds16s(nbase, (unsigned)((hpix[1] * nC2 + ncb + h16) * on), rawdst + 8192);
+    const int h16 = (opaque(t) & 3) * 16;
+#pragma unroll
+    for (int i = 0; i < RAW_PASSES; ++i) glds16s(nbase, (unsigned)((hpix[i] * nC2 + ncb + h16) * on), rawdst + i * 8192);
   };
   // one slot: RAW (bf16) -> [silu(a x + d)] -> fp16 -> z, zero padding AFTER the activation (an AND: no branch)
-  auto conv_slot = [&](int i) {
+  auto conv_slot = [&](int i, int e) {   // e = parity of the chunk inside its pair (compile-time)
     const int za = opaque(zadr[i]);
-    const u32x4 raw = *reinterpret_cast<const u32x4*>(smem + RAW_OFF + (za & 0xffff));
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(smem + RAW_OFF + e * 32 + (za & 0xffff));
     const unsigned vm = ((hvalid >> i) & 1u) ? 0xffffffffu : 0u;
     u32x4 o;
 #pragma unroll
@@ -319,19 +320,18 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   aff_wait();
   barrier();                // every lane's halo slots have landed
-  conv_slot(0);
-  if (pass1) conv_slot(1);
-  next_chunk();
+  conv_slot(0, 0);
+  if (pass1) conv_slot(1, 0);
+  next_chunk();             // (chunk 1: its halo arrived with chunk 0's)
   lds_wait();
-  barrier();                // z complete; every conversion has read its RAW slots
-  load_halo();              // halo of chunk 1
+  barrier();                // z complete
   transform_at(tz0, tv0, 0);
   transform_extra(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_wait();
   barrier();
   aff_wait();
-  if (xt == 0) conv_slot(0);   // wave group 0 is one step ahead with its conversions (see below)
+  if (xt == 0) conv_slot(0, 1);   // wave group 0 is one step ahead with its conversions (see below)
   FD_T2(const unsigned long long t2_first = __builtin_amdgcn_s_memtime();)
   qa[0] = rd(a_off(0, 0)); qb[0] = rd(b_off(0, 0)); qb[1] = rd(b_off(0, 1)); qa[1] = rd(a_off(0, 1));
 
@@ -342,10 +342,10 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   //   group 0: pass 0 converted in step 8 (of the previous chunk), pass 1 in step 0, transform of halo rows 0..7 in step 4, of rows
   //            16, 17 in step 5 (wave 1)
   //   group 1: conversions in steps 1 and 2, transform of halo rows 8..15 in step 5
-  //   both:    next halo + affine requested in step 3
+  //   both:    next affine requested in step 3 of every chunk, the halo of the next chunk PAIR in step 3 of the even chunks
   // A step starts with a counted wait for the weights of the NEXT step (its first fragments are requested right away); in flight on
-  // this wave's vector-memory counter at that wait, oldest first: the weight pieces of steps s + 1 .. s + 5 (2 each) and, in the five
-  // steps after the halo request, its two pieces: vmcnt(8 / 10).  The weights of step s + 6 are requested after the third MFMA of step
+  // this wave's vector-memory counter at that wait, oldest first: the weight pieces of steps s + 1 .. s + 5 (2 each) and, in the four
+  // steps after a halo request, its three pieces: vmcnt(8 / 11).  The weights of step s + 6 are requested after the third MFMA of step
   // s: by then both weight fragments of step s have arrived and its ring slot is free.
   // Two chunks per iteration: 18 steps = three turns of the ring = six turns of the fragment quads, and the V buffers swap back, so
   // that every LDS offset is an immediate and the loop has ONE set of MFMA sites (two bodies in one loop double the accumulators).
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
       u32x4 &B0 = qb[(2 * k) % 3], &B1 = qb[(2 * k + 1) % 3], &B2 = qb[(2 * k + 2) % 3];
       // the halo request of step 3 (issued BEFORE that step's weight request) is younger than the awaited weights in steps 4 .. 7 and
       // older than those of step 8: that wait also covers it, and the barrier behind it publishes the RAW slots
-      if (s >= 4 && s <= 7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW + 2) : "memory");
+      if (s >= 4 && s <= 7 && half == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW + RAW_PASSES) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
       if (s == 3 || s == 8) { lds_wait(); barrier(); }   // s == 3: z complete;  s == 8: V[vn] complete, every wave has its last V[vc] fragments
       A2 = rd(a_off(k + 1, 0));
@@ -375,15 +375,16 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
       mma(xl, 1, 0, A1, B0);
       __builtin_amdgcn_sched_barrier(0);
       B0 = rd(b_off(k + 1, 1));
-      if (s == 3) { next_chunk(); load_halo(); }   // (after the barrier of this step: every conversion of the previous halo is done)
+      if (s == 3) { next_chunk(); if (half == 0) load_halo(); }   // (after the barrier of this step: every conversion of the previous pair is done)
       dma_step(k + NRING, k % NRING);              // step s + 6 into the slot whose fragments have both arrived
       mma(xl, 1, 1, A1, B1);
       __builtin_amdgcn_sched_barrier(0);
       // the chunk's vector work, while the quads A1 / B1 are dead
-      if (s == 8) { if (xg == 0) { aff_wait(); conv_slot(0); } }
-      if (s == 0) { if (xg == 0 && pass1) conv_slot(1); }
-      if (s == 1) { if (xg == 1) { aff_wait(); conv_slot(0); } }
-      if (s == 2) { if (xg == 1 && pass1) conv_slot(1); }
+      // (step 8 converts the chunk two ahead: same parity as the current one; steps 0 .. 2 the next chunk: the other parity)
+      if (s == 8) { if (xg == 0) { aff_wait(); conv_slot(0, half); } }
+      if (s == 0) { if (xg == 0 && pass1) conv_slot(1, half ^ 1); }
+      if (s == 1) { if (xg == 1) { aff_wait(); conv_slot(0, half ^ 1); } }
+      if (s == 2) { if (xg == 1 && pass1) conv_slot(1, half ^ 1); }
       if (s == 4) { if (xg == 0) transform_at(tz0, tv0, vn); }
       if (s == 5) { if (xg == 1) transform_at(tz0, tv0, vn); else transform_extra(vn); }
       __builtin_amdgcn_sched_barrier(0);

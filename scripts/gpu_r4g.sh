@@ -15,6 +15,6 @@ python profiles/summarize_kernel_stats.py $O/prof_stats 7 > $O/r4g_kernel_stats.
 BENCH1="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-e2e"
 (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $BENCH1 < /dev/null > $O/pmc_fetch.log 2>&1); echo "fetch rc=$?"
 (cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $BENCH1 < /dev/null > $O/pmc_write.log 2>&1); echo "write rc=$?"
-python profiles/summarize_pmc.py $O/pmc_fetch $O/pmc_write 2 > $O/r4g_conv_traffic.json; head -c 1500 $O/r4g_conv_traffic.json
+python profiles/summarize_pmc.py $O/pmc_fetch $O/pmc_write 2 1572864 > $O/r4g_conv_traffic.json; head -c 1500 $O/r4g_conv_traffic.json
 find $O/prof_stats $O/pmc_fetch $O/pmc_write -name '*.csv' -size +20M -delete
 du -sh $O/prof_stats $O/pmc_fetch $O/pmc_write 2>/dev/null
