@@ -75,7 +75,8 @@ constexpr int S_PITCH = 128 * 4 + 16;
 constexpr int S_BYTES = 128 * S_PITCH;              // 67584; two staging buffers unless the residual buffers are in use
 constexpr int SK_OFF = S_BYTES, SK_BYTES = 4 * NTH * 16;
 constexpr int SCK = 2, SCD = 3;                     // shortcut GEMM: MFMA K steps (16 channels) per stage, stages resident (SCD - 1 in flight)
-constexpr int XS_OFF = 8 * SCD * SCK * 2048, XS_BYTES = SCK * 8192;   // weight buffers [8 waves][SCD stages x SCK x 2 KiB] below, SCD x stages here
+constexpr int WS_BYTES = SCK * SLAB;                // shortcut weights of a stage: [K step][cq][ct][32 couts][32 B], shared by the workgroup
+constexpr int XS_OFF = SCD * WS_BYTES, XS_BYTES = SCK * 8192;   // SCD weight stages below, SCD x stages here
 constexpr int BIAS_OFF = 2 * S_BYTES;               // = 135168: [256] f32; above what E1 (2 X) and E3 (2 S, or S + 2 SK) use.  E2 (shortcut:
                                                     // buffers up to XS_OFF + SCD * XS_BYTES) overlaps it: the table is written after E2
 static_assert(BIAS_OFF >= 2 * X_BYTES && BIAS_OFF >= SK_OFF + 2 * SK_BYTES && XS_OFF + SCD * XS_BYTES <= 160 * 1024, "epilogue LDS map");
@@ -582,10 +583,11 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
     {
       // K = the S0 + S1 channels of the (at most two) shortcut segments, in stages of SCK MFMA K steps (16 channels each).  A stage of x
       // is [pixel plane j][tile][64 B] (row r = j * 64 + tile = one pixel's 32 channels), filled by DMA -- the pixel order is made by
-      // the SOURCE addresses.  Weights [K step][cq][ct][32 couts][32 B] bf16 go to private buffers per wave (the two 1-KiB pieces ct = 0, 1
-      // of a K step are consecutive).  SCD stages are resident: while stage s is multiplied, stages s + 1 and s + 2 are in flight (one
+      // the SOURCE addresses.  Weights [K step][cq][ct][32 couts][32 B] bf16: the two waves of a cout block (xt = 0, 1) multiply the SAME
+      // rows, so a stage's 16 KiB are loaded once -- wave (cq, xt) brings K step xt of its cout block (2 KiB), everybody reads both K
+      // steps after the stage's barrier (private buffers fetched every piece twice).  SCD stages are resident: while stage s is multiplied, stages s + 1 and s + 2 are in flight (one
       // stage in flight left the phase at a quarter of the matrix rate: a stage is ~600 cycles of MFMAs, a DMA round trip ~2000).  One
-      // barrier per stage, behind a counted wait: only the requests of the NEXT stage (3 SCK instructions) may still be in flight.
+      // barrier per stage, behind a counted wait: only the requests of the NEXT stage (4 instructions) may still be in flight.
       const int nsc = p.nseg - (sC1 ? 2 : 1);   // shortcut segments follow the 3x3 segments
       const Seg q0 = p.seg[p.nseg - nsc], q1 = p.seg[p.nseg - 1];
       const int S0 = q0.C, Stot = S0 + (nsc > 1 ? q1.C : 0);
@@ -597,7 +599,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
       // lanes fetch one pixel's contiguous 64 B (one memory request), lane l of DMA instruction i of wave w fills the 16 bytes at
       // ((i * 8 + w) * 64 + l) * 16: row r = that >> 2, 16-byte position q = l & 3, which holds piece (kk * 2 + half) = q ^ ((r >> 2) & 3)
       // (the XOR keeps the 64-byte-stride fragment reads free of bank conflicts)
-      static_assert(SCK == 2, "a stage row = 2 K steps x 2 halves x 16 B");
+      static_assert(SCK == 2, "a stage row = 2 K steps x 2 halves x 16 B; K step kk of the weights is loaded by wave group xt = kk");
       int xsrc[2];   // per DMA instruction: (pixel index) << 8 | byte offset of the piece inside the pixel's 64 B
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -618,11 +620,9 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
           glds16s(xb, (unsigned)(((xsrc[i] >> 8) * Cs + cc) * 2 + (xsrc[i] & 255)), (unsigned)(XS_OFF + slot * XS_BYTES + i * 8192 + wave * 1024));
-#pragma unroll
-        for (int kk = 0; kk < SCK; ++kk)
-          glds16s_x2(wsc + (size_t)(ste * SCK + kk) * SLAB, lane16e, (unsigned)(wave * (SCD * SCK * 2048) + (slot * SCK + kk) * 2048));
+        glds16s_x2(wsc + (size_t)(ste * SCK + xt) * SLAB, lane16e, (unsigned)(slot * WS_BYTES + xt * SLAB + cq * 2048));
       };
-      const int wa_sc = wave * (SCD * SCK * 2048) + l31 * 32 + ((lh ^ ((l31 >> 3) & 1)) * 16);
+      const int wa_sc = cq * 2048 + l31 * 32 + ((lh ^ ((l31 >> 3) & 1)) * 16);
       // B fragment of (K step kk, plane pl, tile block nt): row r = (2 xt + pl) * 64 + nt * 32 + l31 at r * 64, piece kk * 2 + lh at
       // position (kk * 2 + lh) ^ ((r >> 2) & 3) = ((kk * 2 + lh) ^ ((l31 >> 2) & 3))   (the row offsets are multiples of 16 rows)
       const int xb_row = XS_OFF + ((2 * xt) * 64 + l31) * 64;
@@ -631,15 +631,15 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
       for (int d = 0; d < SCD - 1; ++d) stage_dma(d, d);
       int slot = 0;
       for (int st = 0; st < nstage; ++st) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * SCK * (SCD - 2)) : "memory");   // stage st has landed (this wave's part)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (SCD - 2)) : "memory");   // stage st has landed (this wave's part)
         lds_wait();
         barrier();                                                                  // ... everybody's; buffer (slot + SCD - 1) % SCD is free
         const int nslot = slot == 0 ? SCD - 1 : slot - 1;                           // = (slot + SCD - 1) % SCD
         stage_dma(st + SCD - 1, nslot);
-        const int wo = slot * SCK * 2048, xo = slot * XS_BYTES;
+        const int wo = slot * WS_BYTES, xo = slot * XS_BYTES;
 #pragma unroll
         for (int kk = 0; kk < SCK; ++kk) {
-          const u32x4 a0 = rd(wa_sc + wo + kk * 2048), a1 = rd(wa_sc + wo + kk * 2048 + 1024);
+          const u32x4 a0 = rd(wa_sc + wo + kk * SLAB), a1 = rd(wa_sc + wo + kk * SLAB + 1024);
           u32x4 bq[2][2];   // [plane][nt]
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl)

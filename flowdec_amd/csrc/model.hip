@@ -356,12 +356,12 @@ struct Fwd {
     else if (w_wino && !s0 && (auto_wino(out) || (latency && px_tiles <= 512))) { w = w_wino; wino = true; }
     // images of more than 96 tiles (the two upper resolution levels of a 2 s clip): Winograd F(4,3) with 256-cout workgroups -- half the
     // MFMAs of the direct kernel, 1.09-1.19x per launch (profiles/r04_wino4_vs_direct.txt); whole 16 x 16 tiles only
-    // (not the 64-channel input of the first block: 0.93-1.0x there)
+    // (the 64-channel input of the first block included: 1.07x with the halo of a chunk pair per request)
     // (a folded 1x1 shortcut runs as a bf16 GEMM on the raw residual stream in that kernel's epilogue: no fp16 range issue)
     // (FD_LOW_LATENCY: the folded-shortcut launches above 128 tiles, which the F(2,3) rule leaves to the direct kernel, and everything
     // above that rule's 512 tiles: one 1 s clip 60.0 -> 62.9x, one 2 s clip 79 -> 88x real time)
     else if ((autosel || (latency && ((s0 && px_tiles > 128) || px_tiles > 512))) && w_wino4 && !(s0 && skip) && out.H % 16 == 0 && out.W % 16 == 0 &&
-             a.C + (b ? b->C : 0) >= 128) { w = w_wino4; wino4 = true; }
+             a.C + (b ? b->C : 0) >= 64) { w = w_wino4; wino4 = true; }
     // one clip, folded-shortcut convolutions of the 384 x 64 level (96 tiles): 96 workgroups of 256 channels leave 160 CUs idle; 128-channel
     // workgroups are 1.28-1.39x per launch there (scripts/ab_conv_b1.py with AB_H=384 AB_W=64), same bits
     else if (latency && px_tiles <= 128 && out.C >= 256 && out.C % 128 == 0) tile = FD_TILE_BN128;
