@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("FLOWDEC_HIP_LIB") or os.path.join(_HERE, "libflowdec_
 FD_F32, FD_BF16 = 0, 1
 FD_WINOGRAD = 0x100  # algorithm flag OR-ed into a dtype argument (include/flowdec_hip.h)
 FD_WINOGRAD4 = 0x80000  # Winograd F(4,3) along W, 256-cout workgroups (conv_wino4.hip)
+FD_TILE_REVERSED = 0x100000  # with FD_WINOGRAD4: tiles in descending order (same bits)
 FD_WINOGRAD_LOWRES = 0x200
 FD_WINOGRAD_AUTO = 0x400
 FD_LOW_LATENCY = 0x800

@@ -44,6 +44,7 @@ struct ConvArgs {
   unsigned long long* dbg;         // FD_TIMING2 builds only
   int B, H, W;
   int tiles_h, tiles_w, tiles_n;
+  int reversed;                    // FD_TILE_REVERSED: workgroup i takes tile (n - 1 - i)
 };
 
 

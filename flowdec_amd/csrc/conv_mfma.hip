@@ -1311,6 +1311,8 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   const bool mixed = (dtype & FD_BF16_OPERANDS) != 0, split = (dtype & FD_BF16X3_OPERANDS) != 0;
   FD_REQUIRE(!(mixed || split) || dtype == (FD_F32 | FD_BF16_OPERANDS) || dtype == (FD_F32 | FD_BF16X3_OPERANDS),
              "fd_conv2d: FD_BF16_OPERANDS / FD_BF16X3_OPERANDS go with FD_F32 storage and the default direct configuration only");
+  const bool reversed = (dtype & FD_TILE_REVERSED) != 0;
+  FD_REQUIRE(!reversed || wino4, "fd_conv2d: FD_TILE_REVERSED goes with FD_WINOGRAD4 only");
   const int tile = dtype & FD_TILE_MASK;
   const int bn_hint = tile == FD_TILE_DUO128 ? -128 : (tile == FD_TILE_BN32 || tile == FD_TILE_BN32_CHUNK) ? 32 : (tile == FD_TILE_BN64 || tile == FD_TILE_BN64_CHUNK) ? 64 : tile == FD_TILE_BN128 ? 128 : 0;
   FD_REQUIRE(tile == 0 || bn_hint != 0 || tile == FD_TILE_PERSIST, "fd_conv2d: bad FD_TILE_* flag");
@@ -1345,7 +1347,7 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   a.affine = affine; a.affC = C0 + C1;
   a.w = packed_w; a.w_bytes = fd_conv_packed_bytes(Cout, C0, C1, ksize, S0, S1, dtype | (wino ? FD_WINOGRAD : 0) | (wino4 ? FD_WINOGRAD4 : 0) | (mixed ? FD_BF16_OPERANDS : 0) | (split ? FD_BF16X3_OPERANDS : 0));
   a.bias = bias; a.bias_rows = bias_rows; a.skip = skip; a.scale = scale; a.out = out; a.Cout = Cout; a.CoutPad = cout_pad(Cout);
-  a.stats = stats; a.B = B; a.H = H; a.W = W;
+  a.stats = stats; a.B = B; a.H = H; a.W = W; a.reversed = reversed ? 1 : 0;
   FD_T2(a.dbg = g_dbg;)
   FD_REQUIRE(a.w_bytes < (1ll << 31), "fd_conv2d: packed weights exceed 2 GiB");
   FD_REQUIRE(affine == nullptr || (C0 + C1) * 8 <= AFF_BYTES, "fd_conv2d: at most %d activated input channels", AFF_BYTES / 8);

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
     const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
     lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   }
+  if (p.reversed) lid = nblk - 1 - lid;   // FD_TILE_REVERSED: start where the producing launch stopped (its last lines are still cached)
   int pt = lid;
   const int tw_i = pt % p.tiles_w; pt /= p.tiles_w;
   const int th_i = pt % p.tiles_h;

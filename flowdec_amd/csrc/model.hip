@@ -279,6 +279,7 @@ struct Fwd {
   Arena arena;
   hipStream_t st;
   int B, F, T, dt, esz;
+  int w4_launches = 0;   // F(4,3) launches so far in this walk (alternating tile order)
 
   void* ptr(size_t off) const { return dry ? nullptr : base + off; }
   // ---- side branch: work that the main chain does not need right away runs on m->side between fork() and back(), and the main
@@ -345,6 +346,7 @@ struct Fwd {
            const void* w_wino4 = nullptr) {
     int tile = 0;
     bool wino4 = false;
+    int order = 0;
     const int opflag = m ? (m->cfg.act_dtype & (FD_BF16_OPERANDS | FD_BF16X3_OPERANDS)) : 0;
     const int px_tiles = fd_cdiv(out.H, 16) * fd_cdiv(out.W, 16);
     const bool latency = m && (m->cfg.act_dtype & FD_LOW_LATENCY) && dt == FD_BF16;
@@ -361,7 +363,12 @@ struct Fwd {
     // (FD_LOW_LATENCY: the folded-shortcut launches above 128 tiles, which the F(2,3) rule leaves to the direct kernel, and everything
     // above that rule's 512 tiles: one 1 s clip 60.0 -> 62.9x, one 2 s clip 79 -> 88x real time)
     else if ((autosel || (latency && ((s0 && px_tiles > 128) || px_tiles > 512))) && w_wino4 && !(s0 && skip) && out.H % 16 == 0 && out.W % 16 == 0 &&
-             a.C + (b ? b->C : 0) >= 64) { w = w_wino4; wino4 = true; }
+             a.C + (b ? b->C : 0) >= 64) {
+      w = w_wino4; wino4 = true;
+      // every other F(4,3) launch of a forward walks its tiles backwards: a consumer then starts on the lines its producer wrote last,
+      // which the memory-side cache still holds (the position in the launch sequence decides, so every forward has the same schedule)
+      if ((w4_launches++ & 1) != 0) order = FD_TILE_REVERSED;
+    }
     // one clip, folded-shortcut convolutions of the 384 x 64 level (96 tiles): 96 workgroups of 256 channels leave 160 CUs idle; 128-channel
     // workgroups are 1.28-1.39x per launch there (scripts/ab_conv_b1.py with AB_H=384 AB_W=64), same bits
     else if (latency && px_tiles <= 128 && out.C >= 256 && out.C % 128 == 0) tile = FD_TILE_BN128;
@@ -382,7 +389,7 @@ struct Fwd {
     const int rc = fd_conv2d(ptr(a.off), a.C, b ? ptr(b->off) : nullptr, b ? b->C : 0, aff == (size_t)-1 ? nullptr : (const float*)ptr(aff),
                              s0 ? ptr(s0->off) : nullptr, s0 ? s0->C : 0, s1 ? ptr(s1->off) : nullptr, s1 ? s1->C : 0, w, bias, bias_rows,
                              skip ? ptr(skip->off) : nullptr, scale, ptr(out.off), out.C, want_stats ? (float*)ptr(out.sums) : nullptr, B,
-                             out.H, out.W, ks, dt | (wino ? FD_WINOGRAD : 0) | (wino4 ? FD_WINOGRAD4 : 0) | tile | opflag, st);
+                             out.H, out.W, ks, dt | (wino ? FD_WINOGRAD : 0) | (wino4 ? FD_WINOGRAD4 : 0) | order | tile | opflag, st);
     if (m && m->profiling) {
       FD_HIP(hipEventRecord(m->ev[m->ev_used].second, st));
       ++m->ev_used;

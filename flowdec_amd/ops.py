@@ -90,7 +90,7 @@ def pack_conv_weight(w, C0=None, dtype=torch.bfloat16, w_sc=None, S0=None, winog
 
 
 def conv2d(x0, packed_w, Cout, ksize, x1=None, affine=None, bias=None, skip=None, scale=1.0, sc0=None, sc1=None, want_stats=False,
-           winograd=False, tile_bn=0, bf16_operands=False):
+           winograd=False, tile_bn=0, bf16_operands=False, reversed_tiles=False):
     """Returns out, or (out, stats partials [B, tiles, CoutPad, 2]) with want_stats."""
     B, H, W, C0 = _nhwc(x0)
     lib = L.load()
@@ -102,7 +102,7 @@ def conv2d(x0, packed_w, Cout, ksize, x1=None, affine=None, bias=None, skip=None
     rows = 0 if bias is None else (1 if bias.ndim == 1 else bias.shape[0])
     L.check(lib.fd_conv2d(L.ptr(x0), C0, L.ptr(x1), C1, L.ptr(affine), L.ptr(sc0), S0, L.ptr(sc1), S1, L.ptr(packed_w), L.ptr(bias), rows,
                           L.ptr(skip), float(scale), L.ptr(out), Cout, L.ptr(stats), B, H, W, ksize,
-                          L.dtype_id(x0.dtype) | _WINO[winograd] | L.FD_TILE[tile_bn] | {False: 0, True: L.FD_BF16_OPERANDS, "x3": L.FD_BF16X3_OPERANDS}[bf16_operands],
+                          L.dtype_id(x0.dtype) | _WINO[winograd] | (L.FD_TILE_REVERSED if reversed_tiles else 0) | L.FD_TILE[tile_bn] | {False: 0, True: L.FD_BF16_OPERANDS, "x3": L.FD_BF16X3_OPERANDS}[bf16_operands],
                           L.stream()))
     return (out, stats) if want_stats else out
 

@@ -53,6 +53,10 @@ extern "C" {
  * transform done once per workgroup when the activated halo is stored (conv_wino4.hip).  bf16 storage, fp16 MFMA operands, f32
  * accumulation; raw (not activated) inputs saturate at +-6000.  Pack and launch with the same flag. */
 #define FD_WINOGRAD4 0x80000
+/* fd_conv2d with FD_WINOGRAD4 only: walk the pixel tiles in DESCENDING order.  Same result, bit for bit; a consumer that starts where
+ * its producer stopped finds the producer's last output lines still in the memory-side cache (the model alternates the direction from
+ * one F(4,3) launch to the next: 0.5 % of a cfg 2 step). */
+#define FD_TILE_REVERSED 0x100000
 /* fd_model_config.act_dtype only: Winograd for the blocks of resolution level >= 2 (small grids, where its 128-cout workgroups
  * fill the chip better), direct MFMA convolution elsewhere. */
 #define FD_WINOGRAD_LOWRES 0x200

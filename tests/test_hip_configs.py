@@ -400,6 +400,10 @@ def test_conv2d_winograd4(case):
     # deterministic (no atomics, fixed reduction order) ...
     out2, stats2 = run()
     assert torch.equal(out, out2) and torch.equal(stats, stats2)
+    # ... whatever the order the tiles are walked in (FD_TILE_REVERSED) ...
+    out3, stats3 = ops.conv2d(x0, pw, Cout, 3, x1=x1, affine=aff, bias=bias, skip=skip, scale=scale, sc0=sc0, sc1=sc1, want_stats=True, winograd=4,
+                              reversed_tiles=True)
+    assert torch.equal(out, out3) and torch.equal(stats, stats3)
     # ... and close to the direct MFMA kernel on the same inputs (both round their output to bf16)
     pd = ops.pack_conv_weight(dev(w), C0=C0, dtype=torch.bfloat16, w_sc=w_sc, S0=S0 if S0 else None)
     outd = ops.conv2d(x0, pd, Cout, 3, x1=x1, affine=aff, bias=bias, skip=skip, scale=scale, sc0=sc0, sc1=sc1)
@@ -424,6 +428,8 @@ def test_conv2d_winograd4_rejects_unsupported():
     z = lambda c: torch.zeros(1, 16, 16, c, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(RuntimeError):   # residual input AND folded shortcut
         ops.conv2d(z(32), pws, 256, 3, sc0=z(64), skip=z(256), winograd=4)
+    with pytest.raises(RuntimeError):   # the reversed order exists for the F(4,3) kernel only
+        ops.conv2d(z(32), ops.pack_conv_weight(w, dtype=torch.bfloat16), 256, 3, reversed_tiles=True)
 
 
 @pytest.mark.parametrize("mag", [1e4, 3e3])
