@@ -638,22 +638,30 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
         const int nslot = slot == 0 ? SCD - 1 : slot - 1;                           // = (slot + SCD - 1) % SCD
         stage_dma(st + SCD - 1, nslot);
         const int wo = slot * WS_BYTES, xo = slot * XS_BYTES;
+        // all twelve fragments of the stage first (the third accumulator plane is dead here: 48 registers are free), the MFMAs behind
+        // them with the waits the compiler counts: one exposed LDS round trip per stage instead of four (hipcc otherwise issues every
+        // group of reads right in front of its MFMAs)
+        u32x4 af[SCK][2], bq[SCK][2][2];   // [K step][ct] and [K step][plane][nt]
 #pragma unroll
         for (int kk = 0; kk < SCK; ++kk) {
-          const u32x4 a0 = rd(wa_sc + wo + kk * SLAB), a1 = rd(wa_sc + wo + kk * SLAB + 1024);
-          u32x4 bq[2][2];   // [plane][nt]
+          af[kk][0] = rd(wa_sc + wo + kk * SLAB);
+          af[kk][1] = rd(wa_sc + wo + kk * SLAB + 1024);
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) bq[pl][nt] = rd(xb_row + xo + (pl * 64 + nt * 32) * 64 + (((kk * 2 + lh) ^ xb_sw) * 16));
+            for (int nt = 0; nt < 2; ++nt) bq[kk][pl][nt] = rd(xb_row + xo + (pl * 64 + nt * 32) * 64 + (((kk * 2 + lh) ^ xb_sw) * 16));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < SCK; ++kk)
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-              acc[pl][0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bq[pl][nt]), acc[pl][0][nt], 0, 0, 0);
-              acc[pl][1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bq[pl][nt]), acc[pl][1][nt], 0, 0, 0);
+              acc[pl][0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[kk][0]), __builtin_bit_cast(bf16x8, bq[kk][pl][nt]), acc[pl][0][nt], 0, 0, 0);
+              acc[pl][1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[kk][1]), __builtin_bit_cast(bf16x8, bq[kk][pl][nt]), acc[pl][1][nt], 0, 0, 0);
             }
-        }
+        __builtin_amdgcn_sched_barrier(0);
         slot = slot + 1 == SCD ? 0 : slot + 1;
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-reads past the last stage
