@@ -8,6 +8,7 @@ timeout 600 python bench.py 2> $O/r4g_bench_cfg2.err | tail -1 > $O/r4g_bench_cf
 for N in 3 6; do
   timeout 600 python bench.py --preset flowdec_25s --batch 32 --solver midpoint --N $N --steps 3 --warmup 1 --no-cpu-baseline 2> $O/r4g_bench_cfg3_N$N.err | tail -1 > $O/r4g_bench_cfg3_N$N.json; cut -c1-300 $O/r4g_bench_cfg3_N$N.json
 done
+timeout 600 python bench.py --batch 32 --solver midpoint --N 3 --steps 3 --warmup 1 --no-cpu-baseline 2> /dev/null | tail -1 > $O/r4g_bench_cfg4_shard.json; cut -c1-300 $O/r4g_bench_cfg4_shard.json
 BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-e2e"
 rm -rf $O/prof_stats $O/pmc_fetch $O/pmc_write
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- $BENCH < /dev/null > $O/prof_stats.log 2>&1); echo "stats rc=$?"
