@@ -339,8 +339,8 @@ struct Fwd {
   bool auto_wino(const Tens& out) const { return fd_cdiv(out.H, 16) * fd_cdiv(out.W, 16) <= 96; }
   // FD_LOW_LATENCY (one short clip on the whole chip; profiles/r02_latency_tiles.txt): images of at most 24 tiles run the direct
   // kernel with 32-channel workgroups and chunk-resident weights (8 x the workgroups, one barrier per chunk); the F(2,3) kernel
-  // (128-channel workgroups) takes everything else up to 512 tiles unless a 1x1 shortcut is folded in; those run the direct kernel with
-  // 128-channel workgroups up to 128 tiles and the F(4,3) kernel above, which also takes everything above 512 tiles.  By image size only.
+  // (128-channel workgroups) takes everything else up to 128 tiles unless a 1x1 shortcut is folded in; those run the direct kernel with
+  // 128-channel workgroups up to 128 tiles; above 128 tiles everything runs the F(4,3) kernel.  By image size only.
   int conv(const Tens& a, const Tens* b, size_t aff, const Tens* s0, const Tens* s1, const void* w, const float* bias, int bias_rows,
            const Tens* skip, float scale, Tens& out, int ks, bool want_stats, bool wino = false, const void* w_wino = nullptr,
            const void* w_wino4 = nullptr) {
@@ -355,14 +355,13 @@ struct Fwd {
     else if (autosel && px_tiles <= 16 && out.C >= 64) tile = FD_TILE_BN64_CHUNK;   // the 96 x 32 level: 18.5 us vs 22.6 (Winograd) at 8 clips, 17.1 vs 21.9 at one
     // (never with a folded 1x1 shortcut: its input is the UN-NORMALISED residual stream, which the Winograd kernel would narrow to
     // the fp16 range; GroupNorm+SiLU outputs and their FIR-resampled versions are bounded)
-    else if (w_wino && !s0 && (auto_wino(out) || (latency && px_tiles <= 512))) { w = w_wino; wino = true; }
+    else if (w_wino && !s0 && (auto_wino(out) || (latency && px_tiles <= 128))) { w = w_wino; wino = true; }
     // images of more than 96 tiles (the two upper resolution levels of a 2 s clip): Winograd F(4,3) with 256-cout workgroups -- half the
     // MFMAs of the direct kernel, 1.09-1.19x per launch (profiles/r04_wino4_vs_direct.txt); whole 16 x 16 tiles only
     // (the 64-channel input of the first block included: 1.07x with the halo of a chunk pair per request)
     // (a folded 1x1 shortcut runs as a bf16 GEMM on the raw residual stream in that kernel's epilogue: no fp16 range issue)
-    // (FD_LOW_LATENCY: the folded-shortcut launches above 128 tiles, which the F(2,3) rule leaves to the direct kernel, and everything
-    // above that rule's 512 tiles: one 1 s clip 60.0 -> 62.9x, one 2 s clip 79 -> 88x real time)
-    else if ((autosel || (latency && ((s0 && px_tiles > 128) || px_tiles > 512))) && w_wino4 && !(s0 && skip) && out.H % 16 == 0 && out.W % 16 == 0 &&
+    // (FD_LOW_LATENCY: everything above 128 tiles: one 1 s clip 60.0 -> 63.4x, one 2 s clip 79 -> 88.8x real time)
+    else if ((autosel || (latency && px_tiles > 128)) && w_wino4 && !(s0 && skip) && out.H % 16 == 0 && out.W % 16 == 0 &&
              a.C + (b ? b->C : 0) >= 64) {
       w = w_wino4; wino4 = true;
       // every other F(4,3) launch of a forward walks its tiles backwards: a consumer then starts on the lines its producer wrote last,

@@ -60,9 +60,11 @@ extern "C" {
 /* fd_model_config.act_dtype only: Winograd for the blocks of resolution level >= 2 (small grids, where its 128-cout workgroups
  * fill the chip better), direct MFMA convolution elsewhere. */
 #define FD_WINOGRAD_LOWRES 0x200
-/* fd_model_config.act_dtype only: both packings are kept and every launch picks its kernel by the image size: the direct kernel with
- * FD_TILE_BN64_CHUNK for images of at most 16 tiles of 16 x 16 pixels, Winograd up to 96 tiles (the low-resolution levels), direct
- * otherwise.  Independent of the batch size, so that a clip gives the same bits alone and inside any batch. */
+/* fd_model_config.act_dtype only: all packings are kept and every launch picks its kernel by the image size: the direct kernel with
+ * FD_TILE_BN64_CHUNK for images of at most 16 tiles of 16 x 16 pixels, Winograd F(2,3) up to 96 tiles (the low-resolution levels;
+ * not with a folded 1x1 shortcut), Winograd F(4,3) for every other 3x3 convolution with 256 output channels and whole tiles (every
+ * other such launch of a forward with FD_TILE_REVERSED), direct for the rest.  Independent of the batch size, so that a clip gives the
+ * same bits alone and inside any batch. */
 #define FD_WINOGRAD_AUTO 0x400
 /* fd_conv_pack_weights / fd_conv2d / fd_model_config.act_dtype, with FD_F32 only: "bf16 operands, f32 residual stream" -- activations,
  * skip tensors and outputs stay f32 in memory; a convolution rounds its (activated) input to bf16 at the LDS store, its weights are
@@ -91,8 +93,8 @@ extern "C" {
 #define FD_TILE_MASK 0xf000
 /* fd_model_config.act_dtype only: low-latency schedule for ONE short clip -- both packings are kept (as with FD_WINOGRAD_AUTO) and
  * every convolution picks kernel and workgroup width by its IMAGE size (never by the batch size): FD_TILE_BN32_CHUNK for images of
- * at most 24 tiles, Winograd up to 512 tiles (unless a 1x1 shortcut is folded in), direct otherwise -- with FD_TILE_BN128 workgroups
- * for images of at most 128 tiles. */
+ * at most 24 tiles, Winograd F(2,3) up to 128 tiles (unless a 1x1 shortcut is folded in: direct with FD_TILE_BN128 workgroups there),
+ * Winograd F(4,3) above 128 tiles. */
 #define FD_LOW_LATENCY 0x800
 /* fd_model_config.act_dtype only: keep the side branches of a network evaluation (time embedding, pyramid-head chain) on the caller's
  * stream instead of forking them onto the model's second stream (default: forked; inside a graph capture they become parallel
