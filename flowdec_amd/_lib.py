@@ -64,6 +64,7 @@ SIGNATURES = {
     "fd_upfirdn2d_out_size": (c_int, [c_int] * 6),
     "fd_fused_bias_act": (c_int, [_P, _P, _P, c_ll, c_int, c_int, c_int, c_float, c_float, _P]),
     "fd_fir_resample": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "fd_conv_in": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "fd_channel_sums_tiles": (c_int, [c_int, c_int]),
     "fd_channel_sums": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "fd_gn_silu_apply": (c_int, [_P, _P, _P, c_int, c_ll, c_int, c_int, _P]),

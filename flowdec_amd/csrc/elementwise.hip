@@ -601,6 +601,93 @@ __global__ void pack_input_kernel(const float2* __restrict__ x, const float2* __
   }
 }
 
+// The input convolution all_modules.3 (conv3x3, 4 -> nf; ncsnpp.py:291, layers.py:128-134) with the GroupNorm partial sums of its output.
+// On the matrix cores this layer is all prologue and epilogue (K = 4 padded channels x 9 taps: 237 us at 8 x 768 x 256 for a launch that
+// writes 201 MB); here it is f32 vector FMAs next to the stores: one block = a 16 x 16 pixel tile, one thread = 8 couts x NG = Cout / 8
+// consecutive pixels of a tile row, taps ascending, input channels ascending, one fma each (deterministic; statistics of the f32 values,
+// fixed reduction order).  Input = the packed NHWC tensor of pack_input_kernel (4 real channels of 8), zero padding.
+typedef float f32x2e __attribute__((ext_vector_type(2)));
+typedef float f32x4e __attribute__((ext_vector_type(4)));
+template <typename T, int NG>
+__global__ __launch_bounds__(256) void conv_in_kernel(const T* __restrict__ in8, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      T* __restrict__ out, float* __restrict__ part, int H, int W) {
+  constexpr int C = 8 * NG;
+  constexpr int WBLK = 9;                         // f32x4 per (tap, cout group): 4 channels x 2 cout halves + 1 pad (bank spread)
+  __shared__ f32x4e halo[18][18];
+  __shared__ f32x4e wl[9 * NG * WBLK];
+  __shared__ float red[4][C][2];
+  const int t = threadIdx.x, tile = blockIdx.x, b = blockIdx.y;
+  const int tiles_w = W >> 4;
+  const int h0 = (tile / tiles_w) << 4, w0 = (tile % tiles_w) << 4;
+  for (int i = t; i < 18 * 18; i += 256) {
+    const int hr = i / 18, hc = i - hr * 18;
+    const int gh = h0 - 1 + hr, gw = w0 - 1 + hc;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (gh >= 0 && gh < H && gw >= 0 && gw < W) fd_load_vec<T, 4>(in8 + (((size_t)b * H + gh) * W + gw) * 8, v);
+    halo[hr][hc] = f32x4e{v[0], v[1], v[2], v[3]};
+  }
+  for (int e = t; e < C * 36; e += 256) {         // w: [Cout][4][3][3]
+    const int co = e / 36, r = e - co * 36, ci = r / 9, tap = r - ci * 9;
+    reinterpret_cast<float*>(wl)[(((tap * NG + (co >> 3)) * WBLK + ci * 2 + ((co & 7) >> 2)) << 2) + (co & 3)] = w[e];
+  }
+  __syncthreads();
+  const int cg = t % NG, slot = t / NG;
+  const int p0 = slot * NG, r = p0 >> 4, c0 = p0 & 15;
+  f32x2e acc[NG][4];
+#pragma unroll
+  for (int p = 0; p < NG; ++p)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[p][j] = f32x2e{bias[cg * 8 + 2 * j], bias[cg * 8 + 2 * j + 1]};
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int dy = tap / 3, dx = tap % 3;
+    f32x4e wv[4][2];
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) wv[ci][h] = wl[(tap * NG + cg) * WBLK + ci * 2 + h];
+#pragma unroll
+    for (int p = 0; p < NG; ++p) {
+      const f32x4e x = halo[r + dy][c0 + p + dx];
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) {
+        const f32x2e xx = {x[ci], x[ci]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x2e w2 = {wv[ci][j >> 1][2 * (j & 1)], wv[ci][j >> 1][2 * (j & 1) + 1]};
+          acc[p][j] = __builtin_elementwise_fma(xx, w2, acc[p][j]);
+        }
+      }
+    }
+  }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+  for (int p = 0; p < NG; ++p) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[2 * j] = acc[p][j][0]; v[2 * j + 1] = acc[p][j][1]; }
+    fd_store_vec<T, 8>(out + (((size_t)b * H + h0 + r) * W + w0 + c0 + p) * C + cg * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+  }
+  // lanes of a wave that share a cout group differ in the slot bits: fold them, then the four waves through LDS
+#pragma unroll
+  for (int msk = NG; msk < 64; msk <<= 1)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] += __shfl_xor(s1[j], msk, 64); s2[j] += __shfl_xor(s2[j], msk, 64); }
+  if ((t & 63) < NG) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[t >> 6][cg * 8 + j][0] = s1[j]; red[t >> 6][cg * 8 + j][1] = s2[j]; }
+  }
+  __syncthreads();
+  if (t < C * 2) {
+    const int c = t >> 1, which = t & 1;
+    part[(((size_t)b * gridDim.x + tile) * C + c) * 2 + which] = (red[0][c][which] + red[1][c][which]) + (red[2][c][which] + red[3][c][which]);
+  }
+}
+
 // Combine 'sum' (layerspp.py:54-69): out = conv1x1(p4) + bias + h, fused with the per-tile GroupNorm partial sums of `out`
 // (same [b][tile][C][2] format as channel_sums_kernel; the next ResnetBlock's GroupNorm_0 consumes them).  One block =
 // COMBINE_PX pixels of one image; one thread = 8 couts of every (256 / (Cout / 8))-th pixel.
@@ -983,6 +1070,19 @@ static int edge_launch(int which, const fd_edge_args& a, hipStream_t st) {
                          (const float2*)a.y, a.cy, a.coef, (const float2*)a.z, a.cz, (float2*)a.out, n);
       break;
     }
+    case 5: {  // input convolution 4 -> Cout with GroupNorm partials (16 x 16 tiles)
+      const dim3 grid((a.H >> 4) * (a.W >> 4), a.B);
+#define FD_CONV_IN(NG_) hipLaunchKernelGGL((conv_in_kernel<T, NG_>), grid, dim3(256), 0, st, (const T*)a.x, a.w, a.bias, (T*)a.out, a.stats, a.H, a.W)
+      switch (a.Cout) {
+        case 8: FD_CONV_IN(1); break;
+        case 16: FD_CONV_IN(2); break;
+        case 32: FD_CONV_IN(4); break;
+        case 64: FD_CONV_IN(8); break;
+        default: return fd_set_error(FD_EINVAL, "edge_launch: conv_in needs Cout in {8, 16, 32, 64}");
+      }
+#undef FD_CONV_IN
+      break;
+    }
     default: return fd_set_error(FD_EINVAL, "edge_launch: bad op");
   }
   FD_LAUNCH_CHECK();
@@ -990,8 +1090,18 @@ static int edge_launch(int which, const fd_edge_args& a, hipStream_t st) {
 }
 
 int fd_edge_op(int which, const fd_edge_args& a, int dtype, hipStream_t st) {
+  if (which == 5) FD_REQUIRE(a.x && a.w && a.bias && a.out && a.stats && a.H % 16 == 0 && a.W % 16 == 0, "edge op: conv_in needs whole 16 x 16 tiles, weights, bias and a stats buffer");
   if (which == 2) FD_REQUIRE(a.stats && a.Cout >= 8 && a.Cout <= 256 && (a.Cout & (a.Cout - 1)) == 0, "edge op: combine needs a stats buffer and a power-of-two Cout in [8, 256]");
   return dtype == FD_BF16 ? edge_launch<bf16>(which, a, st) : edge_launch<float>(which, a, st);
+}
+
+extern "C" int fd_conv_in(const void* in8, const float* w, const float* bias, void* out, float* stats, int B, int H, int W, int Cout, int dtype,
+                          void* stream) {
+  FD_REQUIRE(dtype == FD_BF16 || dtype == FD_F32, "fd_conv_in: dtype must be FD_BF16 or FD_F32");
+  FD_REQUIRE(B > 0 && H > 0 && W > 0, "fd_conv_in: bad shape");
+  fd_edge_args a;
+  a.x = in8; a.w = w; a.bias = bias; a.out = out; a.stats = stats; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
+  return fd_edge_op(5, a, dtype, fd_stream(stream));
 }
 
 int fd_init_state(const float* Y, const float* noise, const double* sigma_dev, int sigma_n, float sigma_fac, float* x0, int B,

@@ -31,7 +31,8 @@ int fd_time_embedding_impl(const float* t, float t_imm, int nt, const float* gfp
                            const float* w2, const float* b2, float* temb, hipStream_t st);
 int fd_temb_bias_batched(const fd_temb_job* jobs_dev, int njobs, const float* temb, int nt, int temb_dim, hipStream_t st);
 // which: 0 = pack_input, 2 = combine (1x1 4->Cout + h), 3 = output layer + state update,
-//        4 = output layer + score-sampler update
+//        4 = output layer + score-sampler update, 5 = input convolution 3x3 4 -> Cout (x = packed input, w = [Cout][4][3][3] f32) with
+//        the GroupNorm partials of its output in `stats` ([B][(H / 16) * (W / 16)][Cout][2])
 int fd_edge_op(int which, const fd_edge_args& a, int dtype, hipStream_t st);
 int fd_init_state(const float* Y, const float* noise, const double* sigma_dev, int sigma_n, float sigma_fac, float* x0, int B,
                   int F, int T, hipStream_t st);

@@ -63,6 +63,19 @@ def fir_resample(x, direction, affine=None, want_raw=True):
     return raw, act
 
 
+def conv_in(in8, w, bias):
+    """The input convolution conv3x3(4, Cout) on the packed input [B, H, W, 8]; returns (out [B, H, W, Cout], stats partials
+    [B, tiles, Cout, 2])."""
+    B, H, W, c8 = _nhwc(in8)
+    assert c8 == 8 and w.shape[1:] == (4, 3, 3) and w.dtype == torch.float32
+    Cout = w.shape[0]
+    out = torch.empty(B, H, W, Cout, dtype=in8.dtype, device=in8.device)
+    stats = torch.zeros(B, (H // 16) * (W // 16), Cout, 2, dtype=torch.float32, device=in8.device)
+    L.check(L.load().fd_conv_in(L.ptr(in8), L.ptr(w.contiguous()), L.ptr(bias), L.ptr(out), L.ptr(stats), B, H, W, Cout, L.dtype_id(in8.dtype),
+                                L.stream()))
+    return out, stats
+
+
 _WINO = {False: 0, 0: 0, True: L.FD_WINOGRAD, 4: L.FD_WINOGRAD4}   # (True == 1: the F(2,3) kernel)
 
 

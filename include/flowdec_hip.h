@@ -144,6 +144,14 @@ int fd_fused_bias_act(const float* x, const float* bias, float* out, long long n
 int fd_fir_resample(const void* x, const float* affine, void* out_raw, void* out_act, int B, int H, int W, int C,
                     int direction, int dtype, void* stream);
 
+/* The input convolution of NCSN++ (all_modules.3 = conv3x3(4, nf), ncsnpp.py:291 via layers.py:128-134) on the packed NHWC input
+ * [B][H][W][8] (channels 0..3 = x.re, x.im, y.re, y.im; 4..7 ignored), zero padding, as f32 vector FMAs (taps ascending, input channels
+ * ascending, one fma each), with the GroupNorm partial sums of the output: stats[B][(H / 16) * (W / 16)][Cout][2] = per 16 x 16 pixel
+ * tile (sum x, sum x^2) of the f32 values.  w = [Cout][4][3][3] float32 (the checkpoint's layout), Cout in {8, 16, 32, 64},
+ * H % 16 == W % 16 == 0.  dtype = storage type of `in8` and `out`. */
+int fd_conv_in(const void* in8, const float* w, const float* bias, void* out, float* stats, int B, int H, int W, int Cout, int dtype,
+               void* stream);
+
 /* GroupNorm statistics (nn.GroupNorm(min(C//4,32), C, eps=1e-6), layerspp.py:229,241), split in two so that one
  * statistics pass can be shared by consumers that group the channels differently:
  *  partial sums  : part[b][tile][stride][2] = per-channel (sum x, sum x^2) of one spatial tile, float32.  Produced

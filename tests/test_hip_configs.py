@@ -792,3 +792,39 @@ def test_bf16x3_precision_mode():
     check("enhance_nf64[euler,N=6,bf16x3]", xh.numpy(), g17["euler_N6"], TOL_WAVE_FULL["fp32"])
     xm = m.enhance(torch.from_numpy(g17["y"]), N=3, solver="midpoint", noise=torch.from_numpy(g17["noise"]))
     check("enhance_nf64[midpoint,N=3,bf16x3]", xm.numpy(), g17["midpoint_N3"], TOL_WAVE_FULL["fp32"])
+
+
+@pytest.mark.parametrize("Cout,B,H,W", [(64, 2, 32, 48), (8, 1, 16, 16), (16, 2, 48, 16), (32, 1, 16, 32), (64, 1, 768, 64)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_in(Cout, B, H, W, dtype):
+    """fd_conv_in (the vector-FMA input convolution 4 -> nf of the bf16 mode, all_modules.3) against the f64 convolution of the same
+    stored input: f32 storage 2e-6 (f32 fma chains of 36 terms), bf16 storage = its output rounding; the GroupNorm partial sums are
+    those of the unrounded f32 values; channels 4..7 of the packed input are ignored; bit-deterministic; and it agrees with the MFMA
+    kernel on the zero-padded 8-channel weights (the path of the other modes)."""
+    from flowdec_amd import ops
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(f"convin{Cout}{H}{W}".encode()))
+    x4 = rng.standard_normal((B, 4, H, W)).astype(np.float32)
+    if dtype == torch.bfloat16:
+        x4 = O.round_bf16(x4)
+    w = (rng.standard_normal((Cout, 4, 3, 3)) / 6).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    junk = rng.standard_normal((B, 4, H, W)).astype(np.float32)           # channels 4..7: must not matter
+    in8 = nhwc(np.concatenate([x4, junk], 1), dtype)
+    ref = O.conv2d(x4.astype(np.float64), w.astype(np.float64), bias.astype(np.float64))
+    out, stats = ops.conv_in(in8, dev(w), dev(bias))
+    torch.cuda.synchronize()
+    check(f"conv_in[{Cout},{H}x{W},{str(dtype)[6:]}]", from_nhwc(out), ref, 2e-6 if dtype == torch.float32 else 3e-3)
+    st = stats.double().sum(dim=1).cpu().numpy()
+    ref_s = np.stack([ref.sum(axis=(2, 3)), (ref ** 2).sum(axis=(2, 3))], axis=-1)
+    e = float(np.abs(st - ref_s).max() / np.abs(ref_s).max())
+    report(f"conv_in_stats[{Cout},{H}x{W},{str(dtype)[6:]}]", e, 1e-5)
+    assert e < 1e-5
+    out2, stats2 = ops.conv_in(in8, dev(w), dev(bias))
+    assert torch.equal(out, out2) and torch.equal(stats, stats2)
+    # the MFMA path on the zero-padded weights
+    w8 = np.zeros((Cout, 8, 3, 3), np.float32); w8[:, :4] = w
+    in8z = nhwc(np.concatenate([x4, np.zeros_like(x4)], 1), dtype)
+    pw = ops.pack_conv_weight(dev(w8), dtype=dtype)
+    outm = ops.conv2d(in8z, pw, Cout, 3, bias=dev(bias))
+    assert rel_err(from_nhwc(out), from_nhwc(outm)) < (2e-6 if dtype == torch.float32 else 5e-3)
