@@ -266,7 +266,8 @@ def main():
         L.check(lib.fd_profile_enable(h, 1))
         model.enhance(y, N=args.N, solver=args.solver, noise=noise, use_graph=False)
         torch.cuda.synchronize(dev)
-        ms, n, fl, by = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
+        ms, n, fl, by, flx = C.c_double(), C.c_longlong(), C.c_double(), C.c_double(), C.c_double()
+        L.check(lib.fd_profile_read_executed(h, C.byref(flx)))
         L.check(lib.fd_profile_read(h, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
         fms, fn_, fby = C.c_double(), C.c_longlong(), C.c_double()
         L.check(lib.fd_profile_read_fir(h, C.byref(fms), C.byref(fn_), C.byref(fby)))
@@ -280,6 +281,11 @@ def main():
                               "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "launches": int(n.value),
                               "avg_launch_ms": ms.value / nl, "conv_ms_per_step": ms.value, "algorithmic_tflop_per_step": fl.value / 1e12,
                               "algorithmic_tflop_per_launch": fl.value / 1e12 / nl, "algorithmic_bytes_per_launch": by.value / nl,
+                              # what the matrix cores really executed (Winograd launches execute 1/2 resp. 2/3 of the direct count of their
+                              # 3x3 part): `achieved` / `frac` above are EFFECTIVE rates on the direct convolution's count
+                              "executed_tflop_per_step": flx.value / 1e12,
+                              "executed_TFLOPs": flx.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0,
+                              "executed_frac_of_peak": flx.value / (ms.value * 1e-3) / 1e12 / peak if ms.value > 0 else 0.0,
                               "hbm_GBps_algorithmic": by.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0}
         fnl = max(int(fn_.value), 1)
         fach = fby.value / (fms.value * 1e-3) / 1e9 if fms.value > 0 else 0.0

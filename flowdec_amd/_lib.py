@@ -109,6 +109,7 @@ SIGNATURES = {
     "fd_score_eval": (c_int, [_P, _P, _P, c_float, C.POINTER(FdScoreConfig), c_int, _P, c_int, c_int, _P, c_size_t, _P]),
     "fd_regression_enhance": (c_int, [_P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "fd_profile_enable": (c_int, [_P, c_int]),
+    "fd_profile_read_executed": (c_int, [_P, C.POINTER(C.c_double)]),
     "fd_profile_read": (c_int, [_P, C.POINTER(C.c_double), C.POINTER(c_ll), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "fd_profile_read_fir": (c_int, [_P, C.POINTER(C.c_double), C.POINTER(c_ll), C.POINTER(C.c_double)]),
     "fd_profile_read_stft": (c_int, [_P, C.POINTER(C.c_double * 6), C.POINTER(c_int * 2)]),

@@ -136,6 +136,7 @@ struct fd_model {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   size_t ev_used = 0;
   double prof_flops = 0.0;
+  double prof_flops_exec = 0.0;   // multiply-adds the chosen algorithm executes (Winograd launches: fewer than the direct count)
   double prof_bytes = 0.0;   // algorithmic HBM bytes of the timed launches: every operand read once + output written once
   // second class: the FIR resampling launches (HBM-bound): events + algorithmic bytes
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_fir;
@@ -395,6 +396,8 @@ struct Fwd {
       m->prof_flops += 2.0 * B * out.H * out.W * (double)out.C *
                        ((a.C + (b ? b->C : 0)) * ks * ks + (s0 ? s0->C : 0) + (s1 ? s1->C : 0));
       const double cin = a.C + (b ? b->C : 0), csc = (s0 ? s0->C : 0) + (s1 ? s1->C : 0);
+      // F(4,3): 6 products per 4 outputs and kernel row instead of 12 (the folded shortcut runs as a plain GEMM); F(2,3): 4 instead of 6
+      m->prof_flops_exec += 2.0 * B * out.H * out.W * (double)out.C * (cin * ks * ks * (wino4 ? 0.5 : wino ? 2.0 / 3.0 : 1.0) + csc);
       m->prof_bytes += (double)B * out.H * out.W * esz * (cin + csc + (skip ? out.C : 0) + out.C) + (double)esz * out.C * (cin * ks * ks + csc);
     }
     return rc;
@@ -486,7 +489,10 @@ struct Fwd {
                     a.B = B; a.H = F; a.W = T; a.Cout = md.cout; FD_TRY(fd_edge_op(5, a, dt, st)); }
       } else {
         FD_TRY(conv(in4, nullptr, (size_t)-1, nullptr, nullptr, md.w0, md.b_f32, 1, nullptr, 1.f, h0, 3, true));
-        if (!dry && m->profiling) m->prof_flops -= 2.0 * B * F * T * (double)md.cout * 4 * 9;  // the 4 padding channels are not algorithmic work
+        if (!dry && m->profiling) {   // the 4 padding channels are not algorithmic work
+          m->prof_flops -= 2.0 * B * F * T * (double)md.cout * 4 * 9;
+          m->prof_flops_exec -= 2.0 * B * F * T * (double)md.cout * 4 * 9;
+        }
       }
       hs.push_back(h0);
     }
@@ -1327,6 +1333,7 @@ extern "C" int fd_profile_enable(fd_model* m, int enable) {
   m->profiling = enable != 0;
   m->ev_used = 0;
   m->prof_flops = 0.0;
+  m->prof_flops_exec = 0.0;
   m->prof_bytes = 0.0;
   m->ev_fir_used = 0;
   m->prof_fir_bytes = 0.0;
@@ -1372,5 +1379,12 @@ extern "C" int fd_profile_read(fd_model* m, double* conv_ms_total, long long* co
   m->prof_bytes = 0.0;
   m->ev_used = 0;
   m->prof_flops = 0.0;
+  return FD_OK;
+}
+
+extern "C" int fd_profile_read_executed(fd_model* m, double* conv_flops_executed) {
+  FD_REQUIRE(m && conv_flops_executed, "fd_profile_read_executed: null argument");
+  *conv_flops_executed = m->prof_flops_exec;
+  m->prof_flops_exec = 0.0;
   return FD_OK;
 }

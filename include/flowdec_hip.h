@@ -355,6 +355,10 @@ int fd_regression_enhance(fd_model* m, const float* y, float* x_hat, int B, int 
 int fd_profile_enable(fd_model* m, int enable);
 int fd_profile_read(fd_model* m, double* conv_ms_total, long long* conv_launches, double* conv_flops_total,
                     double* conv_bytes_total /* algorithmic HBM bytes: operands read once + output written once */);
+/* The multiply-add FLOPs the convolution launches actually EXECUTED since fd_profile_enable / the last call of this function (reads and
+ * resets its own counter; call it before or after fd_profile_read): a Winograd F(4,3) launch executes half, an F(2,3) launch two thirds
+ * of the direct count of its 3x3 part.  conv_flops_total of fd_profile_read stays the DIRECT convolution's count. */
+int fd_profile_read_executed(fd_model* m, double* conv_flops_executed);
 /* Same for the HBM-bound FIR resampling launches (fd_fir_resample inside the model): total time, launches and algorithmic
  * bytes (input read once + every output written once) since fd_profile_enable. */
 int fd_profile_read_fir(fd_model* m, double* ms_total, long long* launches, double* bytes_total);
