@@ -828,3 +828,94 @@ def test_conv_in(Cout, B, H, W, dtype):
     pw = ops.pack_conv_weight(dev(w8), dtype=dtype)
     outm = ops.conv2d(in8z, pw, Cout, 3, bias=dev(bias))
     assert rel_err(from_nhwc(out), from_nhwc(outm)) < (2e-6 if dtype == torch.float32 else 5e-3)
+
+
+def _wino4_numerics_model(x, w, a=None, d=None):
+    """NumPy model of conv_wino4.hip's ARITHMETIC for a raw (un-activated) bf16 input: fp16 operands (z = fp16(x); V = B^T z in the
+    kernel's packed-fp16 operation order, every fma rounded once; U = fp16(G g) from the pack kernel's f32 expressions), exact products,
+    wide accumulation over (channel, kernel row), output transform A^T.  Returns the f32 result before bias / residual / scale / output
+    rounding.  x: [B, C, H, W] (bf16-representable float32), w: [Co, C, 3, 3] float32."""
+    B, C, H, W = x.shape
+    f16 = np.float16
+    z = np.zeros((B, C, H + 2, W + 6), f16)                      # zero halo: one row / column around (+ room up to column 4 j + 4)
+    if a is None:
+        z[:, :, 1:H + 1, 1:W + 1] = np.clip(x, -6000.0, 6000.0).astype(f16)
+    else:       # GroupNorm + SiLU operand transform in f32: u = fma(x, a, d), silu(u) = u / (1 + exp(-u)); zero padding AFTER the activation
+        u = (x.astype(np.float64) * a[:, :, None, None].astype(np.float64) + d[:, :, None, None].astype(np.float64)).astype(np.float32)
+        z[:, :, 1:H + 1, 1:W + 1] = (u / (np.float32(1) + np.exp(-u))).astype(np.float32).astype(f16)
+    fma = lambda a, b, c: (a.astype(np.float64) * np.float64(b) + c.astype(np.float64)).astype(f16)   # one rounding, like v_pk_fma_f16
+    d = [z[:, :, :, k:k + W:4] for k in range(6)]                # d_k of tile j = padded column 4 j + k = pixel 4 j - 1 + k
+    t1, t2 = fma(d[2], -4.0, d[4]), fma(d[1], -4.0, d[3])
+    t3, t4 = (d[4].astype(np.float64) - d[2].astype(np.float64)).astype(f16), (d[3].astype(np.float64) - d[1].astype(np.float64)).astype(f16)
+    V = [fma(d[0], 4.0, fma(d[2], -5.0, d[4])),
+         (t1.astype(np.float64) + t2.astype(np.float64)).astype(f16), (t1.astype(np.float64) - t2.astype(np.float64)).astype(f16),
+         fma(t4, 2.0, t3), fma(t4, -2.0, t3),
+         fma(d[1], 4.0, fma(d[3], -5.0, d[5]))]
+    g0, g1, g2 = (w[..., k].astype(np.float32) for k in range(3))   # [Co, C, 3 (dy)]
+    six, tf, tw = np.float32(6), np.float32(24), np.float32(12)
+    U = [np.float32(0.25) * g0, -(g0 + g1 + g2) / six, (-g0 + g1 - g2) / six, g0 / tf + g1 / tw + g2 / six, g0 / tf - g1 / tw + g2 / six, g2]
+    U = [u.astype(f16).astype(np.float64) for u in U]
+    M = []
+    for xi in range(6):
+        v = V[xi].astype(np.float64)                              # [B, C, H + 2, W / 4]
+        acc = np.zeros((B, w.shape[0], H, W // 4))
+        for dy in range(3):
+            acc += np.einsum("oc,bchj->bohj", U[xi][:, :, dy], v[:, :, dy:dy + H, :])
+        M.append(acc)
+    y = np.zeros((B, w.shape[0], H, W))
+    y[..., 0::4] = M[0] + M[1] + M[2] + M[3] + M[4]
+    y[..., 1::4] = M[1] - M[2] + 2 * M[3] - 2 * M[4]
+    y[..., 2::4] = M[1] + M[2] + 4 * M[3] + 4 * M[4]
+    y[..., 3::4] = M[1] - M[2] + 8 * M[3] - 8 * M[4] + M[5]
+    return y.astype(np.float32)
+
+
+@pytest.mark.parametrize("case", WINO4_CASES, ids=[c[0] for c in WINO4_CASES])
+def test_conv2d_winograd4_matches_its_numerics_model(case):
+    """The F(4,3) kernel against a NumPy model of its own arithmetic (fp16 operand roundings in the kernel's operation order, exact
+    products, wide accumulation): what is left between the two is the f32 summation order of the matrix cores, i.e. a bf16 output that
+    differs from the model's in a handful of last-place roundings -- 20x tighter than the parity bound against the f64 convolution, so a
+    misplaced tap, a wrong transform coefficient or a lost channel cannot hide behind the bf16 tolerance."""
+    from flowdec_amd import ops
+    import zlib
+    name, B, H, W, C0, C1, Cout, use_aff, bias_rows, use_skip, S0, S1 = case
+    rng = np.random.default_rng(zlib.crc32(("w4m" + name).encode()))
+    bf = lambda a: O.round_bf16(np.asarray(a, np.float32))
+    Cin = C0 + C1
+    x = bf(rng.standard_normal((B, Cin, H, W)))
+    w = bf(rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9))
+    aff = av = dv = None
+    if use_aff:
+        av = (1 + 0.2 * rng.standard_normal((B, Cin))).astype(np.float32)
+        dv = (0.3 * rng.standard_normal((B, Cin))).astype(np.float32)
+        aff = dev(np.stack([av, dv], axis=-1))
+    y = _wino4_numerics_model(x, w, av, dv).astype(np.float32)
+    sc0 = sc1 = w_sc = None
+    if S0:   # the folded 1x1 shortcut: bf16 x bf16 products on the raw tensors, added to the same planes
+        xs = bf(rng.standard_normal((B, S0 + S1, H, W)))
+        ws = (rng.standard_normal((Cout, S0 + S1, 1, 1)) / np.sqrt(S0 + S1)).astype(np.float32)
+        y = (y + np.einsum("oc,bchw->bohw", bf(ws)[:, :, 0, 0].astype(np.float64), xs.astype(np.float64))).astype(np.float32)
+        sc0 = nhwc(xs[:, :S0], torch.bfloat16)
+        sc1 = nhwc(xs[:, S0:], torch.bfloat16) if S1 else None
+        w_sc = dev(ws)
+    bias = None
+    if bias_rows:
+        bv = rng.standard_normal((bias_rows, Cout)).astype(np.float32)
+        bias = dev(bv if bias_rows > 1 else bv[0])
+    skip, scale = None, np.float32(1.0)
+    if use_skip:
+        sk = bf(rng.standard_normal((B, Cout, H, W)))
+        skip = nhwc(sk, torch.bfloat16)
+        y = y + sk
+        scale = np.float32(1 / np.sqrt(2))
+    if bias_rows:
+        y = y + (bv[:, :, None, None] if bias_rows > 1 else bv[0][None, :, None, None])   # the kernel: ((m [+ skip]) + bias) * scale in f32
+    model = bf(y * scale)
+    pw = ops.pack_conv_weight(dev(w), C0=C0, dtype=torch.bfloat16, w_sc=w_sc, S0=S0 if S0 else None, winograd=4)
+    out = ops.conv2d(nhwc(x[:, :C0], torch.bfloat16), pw, Cout, 3, x1=nhwc(x[:, C0:], torch.bfloat16) if C1 else None, affine=aff, bias=bias,
+                     skip=skip, scale=float(scale), sc0=sc0, sc1=sc1, winograd=4)
+    got = from_nhwc(out)
+    e = rel_err(got, model)
+    differing = float(np.mean(got != model))
+    report(f"conv2d_winograd4_vs_numerics_model[{name}]", e, 2e-4)
+    assert e < 2e-4 and differing < 0.01, (e, differing)
