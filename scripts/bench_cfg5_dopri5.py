@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """BASELINE config 5 as written, per-GPU shard: FlowDec-75m, 8 x 4 s clips (of the 64 x 4 s global batch over 8 GPUs), the
-"32-step adaptive" solver = torchdyn's dopri5 over t_span = linspace(0, 1, 33) at the NeuralODE defaults atol = rtol = 1e-4
-(flowdec/model.py:511-514), in fp32 (the config's dtype) and in `bf16x3` (f32 tolerances on the bf16 matrix cores).
+"32-step adaptive" solver = torchdyn's dopri5 over t_span = linspace(0, 1, 33) (flowdec/model.py:511-514) at atol = rtol = --tol
+(default here 1e-4, the tighter reading; torchdyn's NeuralODE default per its published source is 1e-3 = flowdec_amd's
+ADAPTIVE_DEFAULT_TOL: profiles/r03_bench_cfg5_dopri5_tol1e-3.json), in fp32 (the config's dtype) and in `bf16x3` (f32 tolerances on the bf16 matrix cores).
 Reports wall time, realised NFE and the waveform agreement of the two precisions -> gpurun_out/bench_cfg5_dopri5.json
 (committed as profiles/r03_bench_cfg5_dopri5.json).   python scripts/bench_cfg5_dopri5.py [--clips 8] [--seconds 4] [--tol 1e-4]"""
 import argparse
