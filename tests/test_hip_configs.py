@@ -919,3 +919,71 @@ def test_conv2d_winograd4_matches_its_numerics_model(case):
     differing = float(np.mean(got != model))
     report(f"conv2d_winograd4_vs_numerics_model[{name}]", e, 2e-4)
     assert e < 2e-4 and differing < 0.01, (e, differing)
+
+
+def _wino2_numerics_model(x, w, a=None, d=None):
+    """NumPy model of conv_wino.hip's arithmetic (Winograd F(2,3) along W, even W): z = fp16(x) or fp16(silu(a x + d)), V = B^T z with
+    one fp16 rounding per entry (d0 - d2, d1 + d2, d2 - d1, d1 - d3), U = fp16 of the pack kernel's f32 expressions, exact products,
+    wide accumulation, y0 = M0 + M1 + M2, y1 = M1 - M2 - M3."""
+    B, C, H, W = x.shape
+    f16 = np.float16
+    z = np.zeros((B, C, H + 2, W + 2), f16)
+    if a is None:
+        z[:, :, 1:H + 1, 1:W + 1] = x.astype(f16)
+    else:
+        u = (x.astype(np.float64) * a[:, :, None, None].astype(np.float64) + d[:, :, None, None].astype(np.float64)).astype(np.float32)
+        z[:, :, 1:H + 1, 1:W + 1] = (u / (np.float32(1) + np.exp(-u))).astype(np.float32).astype(f16)
+    dd = [z[:, :, :, k:k + W:2].astype(np.float64) for k in range(4)]     # d_k of tile j = padded column 2 j + k
+    V = [(dd[0] - dd[2]).astype(f16), (dd[1] + dd[2]).astype(f16), (dd[2] - dd[1]).astype(f16), (dd[1] - dd[3]).astype(f16)]
+    g0, g1, g2 = (w[..., k].astype(np.float32) for k in range(3))
+    h = np.float32(0.5)
+    U = [g0, h * (g0 + g1 + g2), h * (g0 - g1 + g2), g2]
+    M = []
+    for xi in range(4):
+        u64, v = U[xi].astype(f16).astype(np.float64), V[xi].astype(np.float64)
+        acc = np.zeros((B, w.shape[0], H, W // 2))
+        for dy in range(3):
+            acc += np.einsum("oc,bchj->bohj", u64[:, :, dy], v[:, :, dy:dy + H, :])
+        M.append(acc)
+    y = np.zeros((B, w.shape[0], H, W))
+    y[..., 0::2] = M[0] + M[1] + M[2]
+    y[..., 1::2] = M[1] - M[2] - M[3]
+    return y.astype(np.float32)
+
+
+@pytest.mark.parametrize("case", [c for c in WINO_CASES if not c[10] and c[3] % 2 == 0], ids=[c[0] for c in WINO_CASES if not c[10] and c[3] % 2 == 0])
+def test_conv2d_winograd_matches_its_numerics_model(case):
+    """The F(2,3) kernel against a NumPy model of its own arithmetic, like test_conv2d_winograd4_matches_its_numerics_model."""
+    from flowdec_amd import ops
+    import zlib
+    name, B, H, W, C0, C1, Cout, use_aff, bias_rows, use_skip, _, _ = case
+    rng = np.random.default_rng(zlib.crc32(("w2m" + name).encode()))
+    bf = lambda a: O.round_bf16(np.asarray(a, np.float32))
+    Cin = C0 + C1
+    x = bf(rng.standard_normal((B, Cin, H, W)))
+    w = bf(rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9))
+    aff = av = dv = None
+    if use_aff:
+        av = (1 + 0.2 * rng.standard_normal((B, Cin))).astype(np.float32)
+        dv = (0.3 * rng.standard_normal((B, Cin))).astype(np.float32)
+        aff = dev(np.stack([av, dv], axis=-1))
+    y = _wino2_numerics_model(x, w, av, dv)
+    bias = None
+    skip, scale = None, np.float32(1.0)
+    if use_skip:
+        sk = bf(rng.standard_normal((B, Cout, H, W)))
+        skip = nhwc(sk, torch.bfloat16)
+        y = y + sk
+        scale = np.float32(1 / np.sqrt(2))
+    if bias_rows:
+        bv = rng.standard_normal((bias_rows, Cout)).astype(np.float32)
+        bias = dev(bv if bias_rows > 1 else bv[0])
+        y = y + (bv[:, :, None, None] if bias_rows > 1 else bv[0][None, :, None, None])
+    model = bf(y * scale)
+    pw = ops.pack_conv_weight(dev(w), C0=C0, dtype=torch.bfloat16, winograd=True)
+    out = ops.conv2d(nhwc(x[:, :C0], torch.bfloat16), pw, Cout, 3, x1=nhwc(x[:, C0:], torch.bfloat16) if C1 else None, affine=aff, bias=bias,
+                     skip=skip, scale=float(scale), winograd=True)
+    got = from_nhwc(out)
+    e = rel_err(got, model)
+    report(f"conv2d_winograd_vs_numerics_model[{name}]", e, 2e-4)
+    assert e < 2e-4 and float(np.mean(got != model)) < 0.01, e
