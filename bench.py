@@ -3,9 +3,14 @@
 
 One "step" = one pass of the hot path (FlowModel.enhance: STFT -> 6 x NCSN++ inside the Euler solver -> iSTFT) over one
 batch of synthetic clips.  Workload at N = 1 is BASELINE.json configs[1]: FlowDec-75m, batch = 8 x 2 s clips @ 48 kHz, 6-step
-Euler, bf16.  `value` is timed with the inputs already resident in HBM (the bench contract); the same K steps are then timed
-again from PINNED HOST waveforms to host waveforms ("H2D of waveform -> D2H of waveform") and reported next to it
-as `e2e` -- the two differ by the 2 x 6 MB of PCIe copies (< 0.3 ms of ~140).
+Euler, bf16.  `value` is timed with the inputs already resident in HBM (the bench contract: "inputs already resident in HBM when
+the timed region starts ... the PCIe-inclusive rate is never `value`"); the same K steps are then timed again from PINNED HOST
+waveforms to host waveforms ("H2D of waveform -> D2H of waveform") and reported next to it as `e2e` -- the two differ
+by the 2 x 6 MB of PCIe copies (< 1 ms of ~120).  The initial noise of every clip is drawn INSIDE the timed call, as the reference
+does (flowdec/model.py:512 `_get_noise`): `sharded_enhance(..., seed=)`, one Philox stream per (step, global clip).
+
+`--config cfg2|cfg3|cfg3_n6|cfg4|cfg5` selects a BASELINE.json configuration by name (explicit flags given after it still apply):
+cfg 4 = FlowDec-75m, 32 x 2 s clips PER GPU, midpoint N = 3 (NFE 6), bf16 -- under `--gpus 8` that is the 256-clip batch of config 4.
 
 Multi-GPU: one process per GPU, the GLOBAL batch (default 8 clips per GPU = weak scaling; `--global-batch G`
 fixes the total = strong scaling, e.g. 256 for BASELINE config 4) is sharded by clip with `flowdec_amd.dist.sharded_enhance`
@@ -27,7 +32,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_FILE = "r04_conv_traffic.json"
+TRAFFIC_FILE = "r05_conv_traffic.json"
 REF_CPU_FILE = "r02_reference_cpu_timing.json"
 F32_MFMA_PEAK_TFLOPS = 157.3   # dense f32 MFMA (the exact-f32 DFT GEMMs of the STFT front / back end)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "mixed": 2500.0, "bf16x3": 2500.0 / 3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
@@ -101,8 +106,19 @@ def relaunch(args):
     os.execv(sys.executable, cmd)
 
 
+# BASELINE.json configurations by name: what `--config` sets (flags given explicitly on the command line win)
+CONFIGS = {
+    "cfg2": dict(preset="flowdec_75m", batch=8, seconds=2.0, N=6, solver="euler", precision="bf16"),
+    "cfg3": dict(preset="flowdec_25s", batch=32, seconds=2.0, N=3, solver="midpoint", precision="bf16"),       # "6-step midpoint" read as NFE 6
+    "cfg3_n6": dict(preset="flowdec_25s", batch=32, seconds=2.0, N=6, solver="midpoint", precision="bf16"),    # ... read as N = 6 (NFE 12, model.py:487)
+    "cfg4": dict(preset="flowdec_75m", batch=32, seconds=2.0, N=3, solver="midpoint", precision="bf16"),       # x 8 GPUs = 256 clips
+    "cfg5": dict(preset="flowdec_75m", batch=8, seconds=4.0, N=32, solver="euler", precision="fp32"),          # x 8 GPUs = 64 clips; fixed-step reading
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="a BASELINE.json configuration by name (per-GPU shard; see CONFIGS)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
@@ -123,6 +139,11 @@ def main():
     ap.add_argument("--stub-step", action="store_true", help="replace enhance() by a trivial CPU function (tests of the launcher only)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (with --backend gloo: exercises the N > 1 path on a 1-GPU box)")
     args = ap.parse_args()
+    if args.config:
+        given = {a.split("=")[0] for a in sys.argv[1:] if a.startswith("--")}
+        for k, v in CONFIGS[args.config].items():
+            if "--" + k.replace("_", "-") not in given and "--" + k not in given:
+                setattr(args, k, v)
 
     world = int(os.environ.get("WORLD_SIZE", "0"))
     if world == 0:
@@ -157,7 +178,7 @@ def main():
         nfe = {"euler": args.N, "midpoint": 2 * args.N, "heun2": 2 * args.N, "heun2_eulerlast": 2 * args.N - 1, "dopri5": args.N}[args.solver]
         Tp, model, noise = 0, None, None
 
-        def step(src):
+        def step(src, k=0):
             t1 = time.perf_counter()
             out = sharded_apply(lambda yb: yb * 2.0 + 1.0, src)
             if stats is not None:
@@ -194,11 +215,11 @@ def main():
         y_host = y.cpu().pin_memory()
         lib = L.load()
         T = lib.fd_num_frames(Lw, 384); Tp = lib.fd_padded_frames(T)
-        noise = torch.randn(gbatch, 1, 768, Tp, dtype=torch.complex64, device=dev, generator=gen)
         nfe = {"euler": args.N, "midpoint": 2 * args.N, "heun2": 2 * args.N, "heun2_eulerlast": 2 * args.N - 1, "dopri5": None}[args.solver]
 
-        def step(src):   # src: the global batch, on the device (timed `value`) or in pinned host memory (`e2e`)
-            return sharded_enhance(model, src, N=args.N, solver=args.solver, noise=noise, use_graph=not args.no_graph, stats=stats)
+        def step(src, k=0):   # src: the global batch, on the device (timed `value`) or in pinned host memory (`e2e`); k: step index
+            # the initial noise is drawn inside the call (model.py:512): clip i of step k has its own stream (seed 1000 + k, i)
+            return sharded_enhance(model, src, N=args.N, solver=args.solver, seed=1000 + k, use_graph=not args.no_graph, stats=stats)
 
     def sync_all():
         if dist is not None:
@@ -211,8 +232,8 @@ def main():
         if stats is not None:
             stats.clear()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            out = step(src)
+        for k in range(steps):
+            out = step(src, k)
         sync_all()
         el = time.perf_counter() - t0
         gs = stats.get("gather_s", 0.0) if stats is not None else 0.0
@@ -241,7 +262,8 @@ def main():
         "higher_is_better": True, "scaling": "strong" if args.global_batch is not None else "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic (0.1*randn waveforms, seeded random-init weights of the FlowDec-75m architecture)",
         "config": {"workload": f"{args.preset} enhance(): global batch={gbatch} x {args.seconds:g} s clips @48 kHz ({hi - lo} per GPU), {args.N}-step "
-                               f"{args.solver} (NFE {nfe}), T_pad={Tp} frames, inputs resident in HBM, output waveforms all-gathered",
+                               f"{args.solver} (NFE {nfe}), T_pad={Tp} frames, inputs resident in HBM, initial noise drawn inside the timed call, "
+                               f"output waveforms all-gathered" + (f" [--config {args.config}]" if args.config else ""),
                    "global_batch": gbatch, "clips_per_rank": shard_sizes(gbatch, world), "nfe": nfe, "parallelism": f"batch-shard x{world}",
                    "hipgraph": not args.no_graph, "conv_algo": args.conv_algo, "backend": args.backend if world > 1 else None},
         "per_rank_ms_per_step": per_rank_ms, "allgather_ms_per_step": gather_ms if world > 1 else 0.0,
@@ -250,7 +272,7 @@ def main():
         result["config"]["workload"] = "STUB step (launcher / collective test, no model)"
     elif not args.no_e2e:
         # the same K steps from pinned host memory to host memory: H2D of this rank's rows, solve, gather, D2H
-        out_h = step(y_host)
+        out_h = step(y_host, args.steps - 1)
         assert out_h.device.type == "cpu" and torch.equal(out_h, out.cpu()), "e2e result differs from the HBM-resident one"
         _, el2, _, _ = timed(y_host, args.steps)
         result["e2e"] = {"value": audio_seconds / el2, "unit": "audio-seconds/second", "ms_per_step": 1e3 * el2 / args.steps,
@@ -264,7 +286,7 @@ def main():
         # also when the Winograd kernel runs -- `achieved` is then an effective rate).
         h = model.backbone.handle()
         L.check(lib.fd_profile_enable(h, 1))
-        model.enhance(y, N=args.N, solver=args.solver, noise=noise, use_graph=False)
+        model.enhance(y, N=args.N, solver=args.solver, generator=gen, use_graph=False)
         torch.cuda.synchronize(dev)
         ms, n, fl, by, flx = C.c_double(), C.c_longlong(), C.c_double(), C.c_double(), C.c_double()
         L.check(lib.fd_profile_read_executed(h, C.byref(flx)))

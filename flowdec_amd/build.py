@@ -30,6 +30,30 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def check_wino4_isa(hipcc=None, extra=()):
+    """conv_wino4.hip writes M0 from inline asm without saving it (the LDS-DMA destination; hipcc refuses M0 on a clobber list) and counts
+    its own s_waitcnt vmcnt by hand.  Both rest on properties of the GENERATED code, so the build checks them and fails otherwise: no M0
+    use outside the kernel's own `s_mov_b32 m0` statements, no scratch (a spill inside the K loop would break the counted waits), and the
+    expected number of MFMA sites (one loop body per instantiation).  ~6 s, runs beside the object compiles."""
+    import tempfile
+    hipcc = hipcc or _hipcc()
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "w4.s")
+        r = subprocess.run([hipcc, *FLAGS, *extra, "-S", "--cuda-device-only", os.path.join(CSRC, "conv_wino4.hip"), "-o", out], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc -S failed for conv_wino4.hip:\n" + r.stderr[-4000:])
+        code = [l.split(";")[0] for l in open(out).read().splitlines()]
+    foreign = [l for l in code if ("m0" in l.split() or ", m0" in l or " m0," in l) and not l.strip().startswith("s_mov_b32 m0,")]
+    if foreign:
+        raise RuntimeError("conv_wino4.hip: M0 is used outside the kernel's own LDS-DMA statements: %r" % foreign[:5])
+    if any("scratch_" in l for l in code):
+        raise RuntimeError("conv_wino4.hip: a kernel spills to scratch (breaks the hand-counted s_waitcnt vmcnt)")
+    n = sum("v_mfma_f32_32x32x16_f16" in l for l in code)
+    if n != 6 * 72:   # six instantiations, 18 steps x 4 MFMAs each
+        raise RuntimeError("conv_wino4.hip: %d F(4,3) MFMA sites, expected %d (the K loop was duplicated or unswitched)" % (n, 6 * 72))
+    return True
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
@@ -47,8 +71,10 @@ def build(force=False, verbose=True):
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, " ".join(cmd), r.stderr[-4000:]))
         return obj
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+    with ThreadPoolExecutor(max_workers=len(SOURCES) + 1) as ex:
+        isa = ex.submit(check_wino4_isa, hipcc, tuple(extra))
         objs = list(ex.map(cc, SOURCES))
+        isa.result()
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

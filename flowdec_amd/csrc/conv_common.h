@@ -35,6 +35,7 @@ struct ConvArgs {
   const float* affine; int affC;   // [B][affC][2]
   const void* w;                   // packed [step][CoutPad][WROWB bytes]
   long long w_bytes;
+  const float* w_scale;            // Winograd kernels: [CoutPad] f32, inverse of the per-cout power-of-two scale of the packed weights
   const float* bias; int bias_rows;
   const void* skip;
   float scale;

@@ -484,6 +484,15 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino_kernel(ConvArgs p) {
       for (int j = 0; j < 8; ++j) bv[nh][j] = bp[j];
     }
   }
+  // inverse of the per-cout power-of-two scale of the packed weights (wino_scale_kernel): applied exactly, inside the fma that adds the
+  // residual / the bias
+  float iv[2][8];
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    const float* ip = p.w_scale + n0 + nh * 64 + oct * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) iv[nh][j] = ip[j];
+  }
   float ssum[2][8], ssq[2][8];
 #pragma unroll
   for (int nh = 0; nh < 2; ++nh)
@@ -536,14 +545,19 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino_kernel(ConvArgs p) {
     if constexpr (SKIP) {
       const bf16x8 s0 = __builtin_bit_cast(bf16x8, sk0), s1 = __builtin_bit_cast(bf16x8, sk1);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { y0[j] += (float)s0[j]; y1[j] += (float)s1[j]; }
+      for (int j = 0; j < 8; ++j) { y0[j] = fmaf(y0[j], iv[nh][j], (float)s0[j]); y1[j] = fmaf(y1[j], iv[nh][j], (float)s1[j]); }
     }
     const float k0 = v0 ? 1.f : 0.f, k1 = v1 ? 1.f : 0.f;   // pixels outside the image do not enter the statistics
     bf16x8 t0, t1;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      y0[j] = (y0[j] + bv[nh][j]) * p.scale;
-      y1[j] = (y1[j] + bv[nh][j]) * p.scale;
+      if constexpr (SKIP) {
+        y0[j] = (y0[j] + bv[nh][j]) * p.scale;
+        y1[j] = (y1[j] + bv[nh][j]) * p.scale;
+      } else {
+        y0[j] = fmaf(y0[j], iv[nh][j], bv[nh][j]) * p.scale;
+        y1[j] = fmaf(y1[j], iv[nh][j], bv[nh][j]) * p.scale;
+      }
       const float a0 = y0[j] * k0, a1 = y1[j] * k1;
       ssum[nh][j] += a0 + a1;
       ssq[nh][j] = fmaf(a0, a0, fmaf(a1, a1, ssq[nh][j]));
@@ -586,8 +600,45 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino_kernel(ConvArgs p) {
 // ---- weight packing: [Cout][Cin][3][3] f32 -> [step = (segment, chunk, dy)][xi][CoutPad][64 B] fp16 ---------------------
 // U_xi = G(xi) . w[dy][0..2] with G = {(1,0,0), (.5,.5,.5), (.5,-.5,.5), (0,0,1)}; shortcut chunks (taps == 1):
 // one step per chunk with the slabs {W, W/2, W/2, -W} (see the kernel header).  16-byte columns XOR-swizzled by (cout >> 2) & 3.
-__global__ void wino_pack_kernel(const float* __restrict__ w, char* __restrict__ dst, int Cout, int CoutPad, int C0, int C1, int taps,
-                                 long long step0) {
+// Per-cout power-of-two scale (fp16 goes subnormal below 6.1e-5; a checkpoint may hold tiny weights in the layers the reference
+// zero-initialises, layers.py:100): one block per cout, m = max |U| over the 3x3 rows and the folded shortcut; tab[n] = 2^-k, tab[CoutPad +
+// n] = 2^k with m 2^k in [2^(U_EXP-1), 2^U_EXP).  Both weight sets of a cout get the same factor: they share the accumulators.
+constexpr int U_EXP = 9;
+__global__ void wino_scale_kernel(const float* __restrict__ w, const float* __restrict__ w_sc, float* __restrict__ tab, int Cout, int CoutPad,
+                                  int Cin, int S) {
+  __shared__ float red[256];
+  const int n = blockIdx.x, t = threadIdx.x;
+  float m = 0.f;
+  if (n < Cout) {
+    for (int i = t; i < Cin * 3; i += 256) {
+      const float* g = w + ((size_t)n * Cin * 3 + i) * 3;
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(g[0]), fabsf(g[2])), fmaxf(fabsf(0.5f * (g[0] + g[1] + g[2])), fabsf(0.5f * (g[0] - g[1] + g[2])))));
+    }
+    if (w_sc)
+      for (int i = t; i < S; i += 256) m = fmaxf(m, fabsf(w_sc[(size_t)n * S + i]));
+  }
+  red[t] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] = fmaxf(red[t], red[t + o]);
+    __syncthreads();
+  }
+  if (t == 0) {
+    int k = 0;
+    m = red[0];
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      frexpf(m, &e);
+      k = U_EXP - e;
+      k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    }
+    tab[n] = ldexpf(1.f, -k);
+    tab[CoutPad + n] = ldexpf(1.f, k);
+  }
+}
+
+__global__ void wino_pack_kernel(const float* __restrict__ w, char* __restrict__ dst, const float* __restrict__ tab, int Cout, int CoutPad,
+                                 int C0, int C1, int taps, long long step0) {
   const int nchunk0 = (C0 + CK - 1) / CK, nchunks = nchunk0 + (C1 + CK - 1) / CK;
   const int spc = taps == 9 ? 3 : 1;   // steps per chunk
   const long long total = (long long)nchunks * spc * 4 * CoutPad * CK;
@@ -616,7 +667,7 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, char* __restrict__
       }
     }
     const int col = (k / 8) ^ ((n >> 2) & 3);
-    d[(i - k) + col * 8 + (k % 8)] = (f16)v;
+    d[(i - k) + col * 8 + (k % 8)] = (f16)(v * tab[CoutPad + n]);
   }
 }
 
@@ -632,16 +683,24 @@ bool fd_wino_supported(int Cout, int C0, int C1, int S0, int S1, int ksize) {
          S0 % CK == 0 && S1 % CK == 0;
 }
 
+namespace {
+// byte offset of the scale table [2][CoutPad] f32 (inverse scales, scales) behind the packed steps
+long long wino_scale_off(int CoutPad, int C0, int C1, int S0, int S1) { return (wino_steps(C0, C1, 3) + wino_steps(S0, S1, 1)) * 4 * CoutPad * WROWB; }
+}  // namespace
+
 long long fd_wino_packed_bytes(int Cout, int C0, int C1, int S0, int S1) {
-  return (wino_steps(C0, C1, 3) + wino_steps(S0, S1, 1)) * 4 * pad_to(Cout, BN) * WROWB + 1024;
+  const int CoutPad = pad_to(Cout, BN);
+  return wino_scale_off(CoutPad, C0, C1, S0, S1) + 2ll * CoutPad * sizeof(float) + 1024;
 }
 
 int fd_wino_pack_weights(const float* w, const float* w_sc, void* packed, int Cout, int C0, int C1, int S0, int S1, hipStream_t st) {
   const int CoutPad = pad_to(Cout, BN);
+  float* const tab = reinterpret_cast<float*>(reinterpret_cast<char*>(packed) + wino_scale_off(CoutPad, C0, C1, w_sc ? S0 : 0, w_sc ? S1 : 0));
+  hipLaunchKernelGGL(wino_scale_kernel, dim3(CoutPad), dim3(256), 0, st, w, w_sc, tab, Cout, CoutPad, C0 + C1, w_sc ? S0 + S1 : 0);
   auto run = [&](const float* src, int c0, int c1, int taps, long long step0) {
     const long long total = wino_steps(c0, c1, taps == 9 ? 3 : 1) * 4 * CoutPad * CK;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, st, src, (char*)packed, Cout, CoutPad, c0, c1, taps, step0);
+    hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, st, src, (char*)packed, tab, Cout, CoutPad, c0, c1, taps, step0);
   };
   run(w, C0, C1, 9, 0);
   if (w_sc) run(w_sc, S0, S1, 1, wino_steps(C0, C1, 3));
@@ -662,6 +721,14 @@ int fd_wino_launch(ConvArgs a, hipStream_t st) {
   a.tiles_w = fd_cdiv(a.W, TW);
   a.tiles_n = a.Cout / BN;
   a.CoutPad = pad_to(a.Cout, BN);
+  {
+    int c3[2] = {0, 0}, cs[2] = {0, 0}, n3 = 0, ns = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+      if (a.seg[s].taps == 1) { if (ns < 2) cs[ns++] = a.seg[s].C; }
+      else if (n3 < 2) c3[n3++] = a.seg[s].C;
+    }
+    a.w_scale = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.w) + wino_scale_off(a.CoutPad, c3[0], c3[1], cs[0], cs[1]));
+  }
   const long long nblk = (long long)a.B * a.tiles_h * a.tiles_w * a.tiles_n;
   FD_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
   const dim3 grid((unsigned)nblk), block(NTH);

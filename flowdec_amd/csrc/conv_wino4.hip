@@ -80,10 +80,13 @@ constexpr int XS_OFF = SCD * WS_BYTES, XS_BYTES = SCK * 8192;   // SCD weight st
 constexpr int BIAS_OFF = 2 * S_BYTES;               // = 135168: [256] f32; above what E1 (2 X) and E3 (2 S, or S + 2 SK) use.  E2 (shortcut:
                                                     // buffers up to XS_OFF + SCD * XS_BYTES) overlaps it: the table is written after E2
 static_assert(BIAS_OFF >= 2 * X_BYTES && BIAS_OFF >= SK_OFF + 2 * SK_BYTES && XS_OFF + SCD * XS_BYTES <= 160 * 1024, "epilogue LDS map");
-constexpr int STAT_OFF = BIAS_OFF + 1024;           // [2][8 waves][16 octets][16] f32 = 16 KiB
+constexpr int ISC_OFF = BIAS_OFF + 1024;            // [256] f32: inverse of the per-cout power-of-two weight scale (wino4_scale_kernel)
+constexpr int STAT_OFF = ISC_OFF + 1024;            // [2][8 waves][16 octets][16] f32 = 16 KiB
 constexpr int LDS_BYTES = cmax(MAIN_BYTES, STAT_OFF + 16384);
 constexpr int NPIECE = HH * HW * 4;                 // 1296 raw pieces of 16 B (8 channels) per chunk pair
 static_assert(LDS_BYTES <= 160 * 1024 && NPIECE <= RAW_PASSES * NTH && HH * HW <= 2 * 256, "LDS layout");
+constexpr int U_EXP = 9;                            // packed weights: every cout's row of U = G g is scaled by a power of two so that its
+                                                    // largest magnitude lies in [2^(U_EXP-1), 2^U_EXP) -- fp16 keeps 23 binades below that
 constexpr float RAW_MAX = 6000.f;                   // raw (not activated) inputs saturate here: |V| <= 10 |z| stays finite in fp16
 
 __device__ __forceinline__ unsigned pack_f16(float a, float b) {
@@ -96,7 +99,8 @@ __device__ __forceinline__ unsigned u2(f16x2 v) { return __builtin_bit_cast(unsi
 // LDS-DMA from inline asm: not counted by hipcc, every wait for it is an explicit counted s_waitcnt vmcnt(N) below.  Each lane's 16 bytes
 // come from (wave-uniform base + per-lane 32-bit byte offset) and land at LDS byte (M0 + instruction offset + lane * 16).  M0 is written
 // in the same statement that uses it (cdna_hip_programming.md 5.7) and NOT restored: nothing else in this file uses M0 (gfx9+ LDS
-// instructions do not; the build checks the ISA for foreign M0 uses -- tests/test_host_cpu.py).
+// instructions do not).  M0 cannot go on the clobber list: hipcc treats it as a reserved register ("clobbering them may lead to undefined
+// behaviour", -Winline-asm), so the BUILD checks the ISA instead -- flowdec_amd/build.py: no M0 use outside these statements, no scratch.
 __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_dst) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
@@ -217,8 +221,10 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
       const unsigned u = raw[j];
       const float x0 = __builtin_bit_cast(float, u << 16), x1 = __builtin_bit_cast(float, u & 0xffff0000u);
       unsigned r;
-      if constexpr (ACT) r = pack_f16(fd_silu(fmaf(x0, aff[4 * j], aff[4 * j + 1])), fd_silu(fmaf(x1, aff[4 * j + 2], aff[4 * j + 3])));
-      else   // raw input (activated / resampled upstream): saturate so that the transform cannot overflow to inf
+      if constexpr (ACT) {   // silu >= -0.28: only the upper side can leave the range the transform tolerates (one packed min per pair)
+        const f16x2 zc = {(f16)RAW_MAX, (f16)RAW_MAX};
+        r = u2(__builtin_elementwise_min(h2(pack_f16(fd_silu(fmaf(x0, aff[4 * j], aff[4 * j + 1])), fd_silu(fmaf(x1, aff[4 * j + 2], aff[4 * j + 3])))), zc));
+      } else   // raw input (activated / resampled upstream): saturate so that the transform cannot overflow to inf
         r = pack_f16(__builtin_amdgcn_fmed3f(x0, -RAW_MAX, RAW_MAX), __builtin_amdgcn_fmed3f(x1, -RAW_MAX, RAW_MAX));
       o[j] = r & vm;
     }
@@ -416,7 +422,13 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   const bf16* const skip = SKIP ? reinterpret_cast<const bf16*>(p.skip) + (size_t)b * img_elems * p.Cout : nullptr;
   float* const biast = reinterpret_cast<float*>(smem + BIAS_OFF);      // [256] f32 (zeros without a bias)
   float* const statt = reinterpret_cast<float*>(smem + STAT_OFF);      // [ct][wave][oct 16][16] f32 partial sums
-  auto load_bias_table = [&]() { if (t < BN) biast[t] = p.bias ? p.bias[(size_t)(p.bias_rows > 1 ? b : 0) * p.Cout + t] : 0.f; };
+  float* const isct = reinterpret_cast<float*>(smem + ISC_OFF);        // [256] f32: 1 / (the cout's weight scale)
+  auto load_bias_table = [&]() {
+    if (t < BN) {
+      biast[t] = p.bias ? p.bias[(size_t)(p.bias_rows > 1 ? b : 0) * p.Cout + t] : 0.f;
+      isct[t] = p.w_scale[t];
+    }
+  };
   if constexpr (!SC) load_bias_table();   // (published by the barriers of the first round; with a shortcut: after E2, whose buffers overlap it)
   // element offset of pass ps of round (ct, nt) for this thread: staged pixel pp + 32 ps = plane ps of tile pp, cout octet oct
   auto out_off = [&](int tt, int ct, int nt, int ps) {
@@ -514,6 +526,10 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
       const int oct = tt & 15, pp = tt >> 4;
       const f32x4 bA = *reinterpret_cast<const f32x4*>(biast + ct * 128 + oct * 8), bB = *reinterpret_cast<const f32x4*>(biast + ct * 128 + oct * 8 + 4);
       const float bv[8] = {bA[0], bA[1], bA[2], bA[3], bB[0], bB[1], bB[2], bB[3]};
+      // the accumulators hold (power-of-two scale of the cout) x (convolution + shortcut): unscaled EXACTLY, inside the fma that adds the
+      // residual / the bias -- the same instruction count as the plain additions
+      const f32x4 iA = *reinterpret_cast<const f32x4*>(isct + ct * 128 + oct * 8), iB = *reinterpret_cast<const f32x4*>(isct + ct * 128 + oct * 8 + 4);
+      const float iv[8] = {iA[0], iA[1], iA[2], iA[3], iB[0], iB[1], iB[2], iB[3]};
 #pragma unroll
       for (int bt = 0; bt < 2; ++bt) {
         u32x4 packed[2];
@@ -529,7 +545,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
             const u32x4 skr = *reinterpret_cast<const u32x4*>(smem + SK_OFF + (rd_ & 1) * SK_BYTES + (ps * NTH + tt) * 16);
             const bf16x8 sk = __builtin_bit_cast(bf16x8, skr);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += (float)sk[j];
+            for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaf(v[j], iv[j], (float)sk[j]);
           }
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -537,7 +553,11 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
             f32x2 x = {v[2 * k], v[2 * k + 1]};
             const f32x2 b2 = {bv[2 * k], bv[2 * k + 1]}, sc2 = {p.scale, p.scale};
             f32x2 s1 = {ssum[2 * k], ssum[2 * k + 1]}, s2 = {ssq[2 * k], ssq[2 * k + 1]};
-            x = (x + b2) * sc2;
+            if constexpr (SKIP) x = (x + b2) * sc2;
+            else {
+              const f32x2 i2 = {iv[2 * k], iv[2 * k + 1]};
+              x = __builtin_elementwise_fma(x, i2, b2) * sc2;
+            }
             s1 += x;
             s2 = __builtin_elementwise_fma(x, x, s2);
             v[2 * k] = x[0]; v[2 * k + 1] = x[1];
@@ -720,7 +740,54 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
 
 // ---- weight packing: [Cout][Cin][3][3] f32 -> [chunk][xt][xi][dy][256 couts][32 B] fp16 ------------------------------------
 // U_xi = G(xi) . w[dy][0..2]; a row's two 16-byte halves (channels 0-7 / 8-15 of the chunk) are XOR-swizzled by (cout >> 3) & 1.
-__global__ void wino4_pack_kernel(const float* __restrict__ w, f16* __restrict__ dst, int Cout, int C0, int C1) {
+__device__ __forceinline__ float wino4_u(const float* g, int xi) {
+  const float g0 = g[0], g1 = g[1], g2 = g[2];
+  switch (xi) {
+    case 0: return 0.25f * g0;
+    case 1: return -(g0 + g1 + g2) / 6.f;
+    case 2: return (-g0 + g1 - g2) / 6.f;
+    case 3: return g0 / 24.f + g1 / 12.f + g2 / 6.f;
+    case 4: return g0 / 24.f - g1 / 12.f + g2 / 6.f;
+    default: return g2;
+  }
+}
+
+// Per-cout power-of-two scale.  G shrinks a kernel row by up to 24 x and fp16 goes subnormal below 6.1e-5: the rows of U of a cout whose
+// weights are small (the reference zero-initialises Conv_1 and the pyramid heads, layers.py:100 -- a trained checkpoint may hold tiny
+// weights exactly there) would lose their mantissa.  One block per cout: m = max |U| over (cin, dy, xi); scale = 2^k with m 2^k in
+// [2^(U_EXP-1), 2^U_EXP); tab[cout] = 2^-k (the kernel's epilogue multiplies by it, exactly), tab[256 + cout] = 2^k (the pack kernels).
+// The folded shortcut's weights get the same factor (exact in bf16): both land in the same accumulators.
+__global__ void wino4_scale_kernel(const float* __restrict__ w, float* __restrict__ tab, int Cout, int Cin) {
+  __shared__ float red[256];
+  const int co = blockIdx.x, t = threadIdx.x;
+  float m = 0.f;
+  if (co < Cout)
+    for (int i = t; i < Cin * 3; i += 256) {
+      const float* g = w + ((size_t)co * Cin * 3 + i) * 3;
+#pragma unroll
+      for (int xi = 0; xi < 6; ++xi) m = fmaxf(m, fabsf(wino4_u(g, xi)));
+    }
+  red[t] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] = fmaxf(red[t], red[t + o]);
+    __syncthreads();
+  }
+  if (t == 0) {
+    int k = 0;
+    m = red[0];
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      frexpf(m, &e);             // m = f 2^e, f in [0.5, 1)
+      k = U_EXP - e;
+      k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    }
+    tab[co] = ldexpf(1.f, -k);
+    tab[BN + co] = ldexpf(1.f, k);
+  }
+}
+
+__global__ void wino4_pack_kernel(const float* __restrict__ w, f16* __restrict__ dst, const float* __restrict__ tab, int Cout, int C0, int C1) {
   const int Cin = C0 + C1, nchunks = Cin / CK;
   const long long total = (long long)nchunks * 18 * BN * CK;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -734,25 +801,14 @@ __global__ void wino4_pack_kernel(const float* __restrict__ w, f16* __restrict__
     const int c = chunk * CK + k;   // (concat segments are multiples of 16 channels: a chunk never straddles them)
     const int co = ((n >> 5) & 1) * 128 + (n >> 6) * 32 + (n & 31);   // slab row n = [cq][ct][32] holds cout ct * 128 + cq * 32 + m
     float v = 0.f;
-    if (co < Cout) {
-      const float* g = w + (((size_t)co * Cin + c) * 3 + dy) * 3;
-      const float g0 = g[0], g1 = g[1], g2 = g[2];
-      switch (xi) {
-        case 0: v = 0.25f * g0; break;
-        case 1: v = -(g0 + g1 + g2) / 6.f; break;
-        case 2: v = (-g0 + g1 - g2) / 6.f; break;
-        case 3: v = g0 / 24.f + g1 / 12.f + g2 / 6.f; break;
-        case 4: v = g0 / 24.f - g1 / 12.f + g2 / 6.f; break;
-        default: v = g2; break;
-      }
-    }
+    if (co < Cout) v = wino4_u(w + (((size_t)co * Cin + c) * 3 + dy) * 3, xi) * tab[BN + co];
     const int half = (k >> 3) ^ ((n >> 3) & 1);
     dst[(i - k) + half * 8 + (k & 7)] = (f16)v;
   }
 }
 
 // shortcut weights [Cout][S] f32 -> [K step of 16 channels][slab row n = [cq][ct][32]][32 B] bf16, halves swizzled by (n >> 3) & 1
-__global__ void wino4_pack_sc_kernel(const float* __restrict__ w, bf16* __restrict__ dst, int Cout, int S) {
+__global__ void wino4_pack_sc_kernel(const float* __restrict__ w, bf16* __restrict__ dst, const float* __restrict__ tab, int Cout, int S) {
   const long long total = (long long)(S / CK) * BN * CK;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int k = (int)(i % CK);
@@ -760,7 +816,7 @@ __global__ void wino4_pack_sc_kernel(const float* __restrict__ w, bf16* __restri
     const int n = (int)(r % BN);
     const int ks = (int)(r / BN);
     const int co = ((n >> 5) & 1) * 128 + (n >> 6) * 32 + (n & 31);
-    const float v = co < Cout ? w[(size_t)co * S + ks * CK + k] : 0.f;
+    const float v = co < Cout ? w[(size_t)co * S + ks * CK + k] * tab[BN + co] : 0.f;   // (a power of two: the bf16 rounding is that of the plain weight)
     const int half = (k >> 3) ^ ((n >> 3) & 1);
     dst[(i - k) + half * 8 + (k & 7)] = (bf16)v;
   }
@@ -774,21 +830,28 @@ bool fd_wino4_supported(int Cout, int C0, int C1, int S0, int S1, int ksize) {
 }
 bool fd_wino4_shape_ok(int H, int W) { return H % TH == 0 && W % TW == 0; }
 
+namespace {
+// byte offset of the scale table [2][256] f32 (inverse scales, scales) behind the 3x3 part and the shortcut K steps
+long long wino4_scale_off(int C3, int S) { return (long long)(C3 / CK + 1) * 18 * SLAB + (long long)(S / CK) * SLAB; }
+}  // namespace
+
 long long fd_wino4_packed_bytes(int Cout, int C0, int C1, int S0, int S1) {
   (void)Cout;
-  // 3x3 part + one chunk (the weight stream runs a ring length past the last step), then the shortcut K steps
-  return (long long)((C0 + C1) / CK + 1) * 18 * SLAB + (long long)((S0 + S1) / CK) * SLAB + 16 * 1024;
+  // 3x3 part + one chunk (the weight stream runs a ring length past the last step), then the shortcut K steps, then the scale table
+  return wino4_scale_off(C0 + C1, S0 + S1) + 16 * 1024;
 }
 
 int fd_wino4_pack_weights(const float* w, const float* w_sc, void* packed, int Cout, int C0, int C1, int S0, int S1, hipStream_t st) {
   const long long total = (long long)((C0 + C1) / CK) * 18 * BN * CK;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(wino4_pack_kernel, dim3(blocks), dim3(256), 0, st, w, (f16*)packed, Cout, C0, C1);
+  float* const tab = reinterpret_cast<float*>(reinterpret_cast<char*>(packed) + wino4_scale_off(C0 + C1, w_sc ? S0 + S1 : 0));
+  hipLaunchKernelGGL(wino4_scale_kernel, dim3(BN), dim3(256), 0, st, w, tab, Cout, C0 + C1);
+  hipLaunchKernelGGL(wino4_pack_kernel, dim3(blocks), dim3(256), 0, st, w, (f16*)packed, tab, Cout, C0, C1);
   if (w_sc) {
     const long long tsc = (long long)((S0 + S1) / CK) * BN * CK;
     const int bsc = (int)((tsc + 255) / 256 > 4096 ? 4096 : (tsc + 255) / 256);
     hipLaunchKernelGGL(wino4_pack_sc_kernel, dim3(bsc), dim3(256), 0, st, w_sc,
-                       reinterpret_cast<bf16*>(reinterpret_cast<char*>(packed) + (size_t)((C0 + C1) / CK + 1) * 18 * SLAB), Cout, S0 + S1);
+                       reinterpret_cast<bf16*>(reinterpret_cast<char*>(packed) + (size_t)((C0 + C1) / CK + 1) * 18 * SLAB), tab, Cout, S0 + S1);
   }
   FD_LAUNCH_CHECK();
   return FD_OK;
@@ -819,7 +882,12 @@ int fd_wino4_init_attributes() {
 int fd_wino4_launch(ConvArgs a, hipStream_t st) {
   FD_REQUIRE(fd_wino4_shape_ok(a.H, a.W), "fd_conv2d: FD_WINOGRAD4 needs H %% 16 == 0 and W %% 16 == 0 (got %d x %d)", a.H, a.W);
   bool sc = false;
-  for (int s = 0; s < a.nseg; ++s) sc = sc || a.seg[s].taps == 1;
+  int c3 = 0, csc = 0;
+  for (int s = 0; s < a.nseg; ++s) {
+    sc = sc || a.seg[s].taps == 1;
+    (a.seg[s].taps == 1 ? csc : c3) += a.seg[s].C;
+  }
+  a.w_scale = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.w) + wino4_scale_off(c3, csc));
   FD_REQUIRE(!(sc && a.skip), "fd_conv2d: FD_WINOGRAD4 takes a folded shortcut or a residual input, not both");
   a.tiles_h = a.H / TH;
   a.tiles_w = a.W / TW;

@@ -358,7 +358,10 @@ struct Fwd {
     // the fp16 range; GroupNorm+SiLU outputs and their FIR-resampled versions are bounded)
     else if (w_wino && !s0 && (auto_wino(out) || (latency && px_tiles <= 128))) { w = w_wino; wino = true; }
     // images of more than 96 tiles (the two upper resolution levels of a 2 s clip): Winograd F(4,3) with 256-cout workgroups -- half the
-    // MFMAs of the direct kernel, 1.09-1.19x per launch (profiles/r04_wino4_vs_direct.txt); whole 16 x 16 tiles only
+    // MFMAs of the direct kernel, 1.09-1.19x per launch (profiles/r04_wino4_vs_direct.txt); whole 16 x 16 tiles only.  In `auto` mode this
+    // branch ALSO takes the folded-shortcut Conv_1 launches of images of 17..96 tiles (the F(2,3) branch above excludes them): 1.17-1.20x
+    // over the direct kernel at 192 x 64 x 8 clips (MEASUREMENTS R4.2, "L2" row).  One clip alone gives those launches 96 workgroups of
+    // 512 threads on 256 CUs -- that case is what conv_algo = 'latency' (FD_TILE_BN128 below) is for; the choice must not look at B.
     // (the 64-channel input of the first block included: 1.07x with the halo of a chunk pair per request)
     // (a folded 1x1 shortcut runs as a bf16 GEMM on the raw residual stream in that kernel's epilogue: no fp16 range issue)
     // (FD_LOW_LATENCY: everything above 128 tiles: one 1 s clip 60.0 -> 63.4x, one 2 s clip 79 -> 88.8x real time)
@@ -367,7 +370,7 @@ struct Fwd {
       w = w_wino4; wino4 = true;
       // every other F(4,3) launch of a forward walks its tiles backwards: a consumer then starts on the lines its producer wrote last,
       // which the memory-side cache still holds (the position in the launch sequence decides, so every forward has the same schedule)
-      if ((w4_launches++ & 1) != 0) order = FD_TILE_REVERSED;
+      if (!dry && (w4_launches++ & 1) != 0) order = FD_TILE_REVERSED;   // (counted in launching walks only: a planning walk cannot shift the schedule)
     }
     // one clip, folded-shortcut convolutions of the 384 x 64 level (96 tiles): 96 workgroups of 256 channels leave 160 CUs idle; 128-channel
     // workgroups are 1.28-1.39x per launch there (scripts/ab_conv_b1.py with AB_H=384 AB_W=64), same bits

@@ -70,8 +70,9 @@ def _split_pair(entry: str) -> List[str]:
 
 def read_list(listfile: str) -> FileList:
     """The list formats of the reference (enhance.py:146-164): one path per line, or pair lines `clean ---> coded` /
-    `clean,coded` of which the SECOND entry is the file to enhance.  A plain line after a pair line is an error there
-    (an assert); here it is a ValueError naming the line."""
+    `clean,coded` of which the SECOND entry is the file to enhance; further fields are ignored like there (the tool's own
+    `triples_list` output `clean ---> noisy ---> out` can be fed back in), with a warning.  A plain line after a pair line is an
+    error there (an assert); here it is a ValueError naming the line."""
     out = FileList()
     with open(listfile, "r") as f:
         for lineno, raw in enumerate(f, 1):
@@ -80,8 +81,8 @@ def read_list(listfile: str) -> FileList:
                 continue
             parts = _split_pair(entry)
             if len(parts) > 2:
-                raise ValueError(f"{listfile}:{lineno}: {len(parts)} fields in a pair line (expected `clean ---> coded` or `clean,coded`)")
-            if len(parts) == 2:
+                print(f"warning: {listfile}:{lineno}: {len(parts)} fields in a pair line, using the first two (clean, coded)", file=sys.stderr)
+            if len(parts) >= 2:
                 if out.clean is None:
                     if out.inputs:
                         raise ValueError(f"{listfile}:{lineno}: pair line after plain paths -- inconsistent file list format")
@@ -280,6 +281,103 @@ class RunResult:
         return 3 if self.n_over_precision_limit else 0
 
 
+@dataclass
+class FileJob:
+    """One entry of the work list: where the input is, where the output goes, the clean reference of a pair list, and whether there
+    is anything to compute (`pending` is False when the output exists and --skip-existing holds)."""
+    index: int
+    src: str
+    dst: str
+    clean: Optional[str]
+    pending: bool
+
+
+def plan_jobs(noisy: List[str], clean: Optional[List[str]], outdir: str, i_min: Optional[int], i_max: Optional[int],
+              skip_existing: bool, exclude: Optional[str] = None):
+    """The work list of a run as a generator of FileJob: the exclusion pattern first (it renumbers the list), then the inclusive
+    index window [i_min, i_max] over what is left, then the exists-check."""
+    entries = [(n, clean[k] if clean is not None else None) for k, n in enumerate(noisy) if exclude is None or exclude not in n]
+    lo = 0 if i_min is None else max(i_min, 0)
+    hi = len(entries) - 1 if i_max is None else min(i_max, len(entries) - 1)
+    for index in range(lo, hi + 1):
+        src, cl = entries[index]
+        dst = os.path.join(outdir, os.path.basename(src))
+        yield FileJob(index, src, dst, cl, pending=not (skip_existing and os.path.exists(dst)))
+
+
+class GpuTimer:
+    """`with GpuTimer(enabled) as t: ...` -> t.seconds = device time between entry and exit on the current stream (None when disabled)."""
+
+    def __init__(self, enabled: bool):
+        self.enabled, self.seconds = enabled, None
+
+    def __enter__(self):
+        if self.enabled:
+            self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._ev[0].record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled and exc[0] is None:
+            self._ev[1].record()
+            torch.cuda.synchronize()
+            self.seconds = self._ev[0].elapsed_time(self._ev[1]) / 1000.0
+        return False
+
+
+class RunLog:
+    """The two side files of a run, in the reference's FORMATS (enhance.py:94,135,143): `rtfs{suffix}.csv` with the header
+    path,runtime,filetime,rtf (--rtf) and `triples_list{suffix}.txt` with `clean ---> noisy ---> enhanced` lines (pair lists)."""
+
+    def __init__(self, outdir: str, suffix: str, want_rtf: bool, want_triples: bool):
+        self._stack = contextlib.ExitStack()
+        self._rtf = self._stack.enter_context(open(os.path.join(outdir, f"rtfs{suffix}.csv"), "w")) if want_rtf else None
+        self._tri = self._stack.enter_context(open(os.path.join(outdir, f"triples_list{suffix}.txt"), "w")) if want_triples else None
+        if self._rtf:
+            print("path,runtime,filetime,rtf", file=self._rtf)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return self._stack.__exit__(*exc)
+
+    def rtf(self, dst: str, runtime: float, filetime: float):
+        print(runtime, filetime, "-> rtf =", runtime / filetime)
+        if self._rtf:
+            print(f"{dst},{runtime:.5f},{filetime:.5f},{runtime / filetime:.5f}", file=self._rtf)
+
+    def triple(self, job: FileJob):
+        if self._tri:
+            print(f"{job.clean} ---> {job.src} ---> {job.dst}", file=self._tri)
+
+
+def enhance_file(model: FlowModel, job: FileJob, args, gen, log: RunLog, res: RunResult, max_seconds: float) -> None:
+    """Load -> length rules -> resample to the model rate -> enhance (timed under --rtf) -> save.  Updates `res`."""
+    y, sr = load_wav(job.src)
+    seconds = y.shape[-1] / sr
+    if seconds > MAX_SECONDS:
+        res.n_too_long += 1
+        print("Skipping file due to length:", job.src)
+        return
+    if seconds > max_seconds:
+        res.n_over_precision_limit += 1
+        print(f"Skipping file: {seconds:.1f} s exceeds the {max_seconds:g} s limit of precision={args.precision} "
+              f"(the reference's limit is {MAX_SECONDS:g} s; use --precision bf16 for files up to it):", job.src)
+        return
+    if sr != model.sampling_rate:
+        print("RESAMPLING from", sr, "to", model.sampling_rate)
+        y, sr = resample(y, sr, model.sampling_rate), model.sampling_rate
+    # use_graph=False: every file has its own length, and a replay would not be faster anyway -- a one-clip solve is bound by the GPU,
+    # not by the host's launches (profiles/r02_graph_cost.txt: eager 18.06 ms, replay 18.10 ms; capture + instantiate 2.4 ms)
+    with GpuTimer(args.rtf) as timer:
+        x_hat = model.enhance(y, N=args.N, solver=args.solver, generator=gen, use_graph=False)
+    if timer.seconds is not None:
+        log.rtf(job.dst, timer.seconds, y.shape[-1] / sr)
+    save_wav(job.dst, x_hat.cpu(), sr)
+    res.n_done += 1
+
+
 def main(argv=None, model: Optional[FlowModel] = None) -> int:
     """Runs the CLI and returns the number of files enhanced (the detailed result: `run()`)."""
     return run(argv, model).n_done
@@ -298,57 +396,16 @@ def run(argv=None, model: Optional[FlowModel] = None) -> RunResult:
         model = load_from_checkpoint(args.ckpt, map_location=args.device, ema=args.ema, precision=args.precision)
         print("Done loading model.")
     noisy, clean = collect_files(args.files, args.single_file)
-    if args.exclude_files_matching is not None:
-        keep = [i for i, f in enumerate(noisy) if args.exclude_files_matching not in f]
-        noisy = [noisy[i] for i in keep]
-        clean = [clean[i] for i in keep] if clean is not None else None
-    suffix = f"_{args.i_min}-{args.i_max}" if args.i_max else ""
-    triples_path = os.path.join(args.outdir, f"triples_list{suffix}.txt") if clean is not None else None
-    rtf_path = os.path.join(args.outdir, f"rtfs{suffix}.csv") if args.rtf else None
-    gen = None
-    if args.seed is not None:
-        gen = torch.Generator(device=model.device).manual_seed(args.seed)
-    res = RunResult()
+    gen = torch.Generator(device=model.device).manual_seed(args.seed) if args.seed is not None else None
     max_seconds = min(MAX_SECONDS, PRECISION_MAX_SECONDS.get(args.precision, MAX_SECONDS))
     print(f"flowdec_amd: precision={args.precision} ({PRECISION_NOTE[args.precision]}), solver={args.solver}, N={args.N}")
-    with (open(triples_path, "w") if triples_path else contextlib.nullcontext()) as trf, \
-            (open(rtf_path, "w") if rtf_path else contextlib.nullcontext()) as rtf_f:
-        if rtf_f is not None:
-            print("path,runtime,filetime,rtf", file=rtf_f)
-        for i, path in enumerate(noisy):
-            if args.i_min is not None and i < args.i_min:
-                continue
-            if args.i_max is not None and i > args.i_max:
-                continue
-            out_path = os.path.join(args.outdir, os.path.basename(path))
-            if not os.path.exists(out_path) or not args.skip_existing:
-                y, sr = load_wav(path)
-                if y.shape[-1] / sr <= max_seconds:
-                    if sr != model.sampling_rate:
-                        print("RESAMPLING from", sr, "to", model.sampling_rate)
-                        y, sr = resample(y, sr, model.sampling_rate), model.sampling_rate
-                    if args.rtf:
-                        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        start.record()
-                    # use_graph=False: every file has its own length, a captured graph would never be replayed
-                    x_hat = model.enhance(y, N=args.N, solver=args.solver, generator=gen, use_graph=False)
-                    if args.rtf:
-                        end.record()
-                        torch.cuda.synchronize()
-                        runtime, filetime = start.elapsed_time(end) / 1000.0, y.shape[-1] / sr
-                        print(runtime, filetime, "-> rtf =", runtime / filetime)
-                        print(f"{out_path},{runtime:.5f},{filetime:.5f},{runtime / filetime:.5f}", file=rtf_f)
-                    save_wav(out_path, x_hat.cpu(), sr)
-                    res.n_done += 1
-                elif y.shape[-1] / sr <= MAX_SECONDS:
-                    res.n_over_precision_limit += 1
-                    print(f"Skipping file: {y.shape[-1] / sr:.1f} s exceeds the {max_seconds:g} s limit of precision={args.precision} "
-                          f"(the reference's limit is {MAX_SECONDS:g} s; use --precision bf16 for files up to it):", path)
-                else:
-                    res.n_too_long += 1
-                    print("Skipping file due to length:", path)
-            if trf is not None:
-                print(f"{clean[i]} ---> {noisy[i]} ---> {out_path}", file=trf)
+    res = RunResult()
+    suffix = f"_{args.i_min}-{args.i_max}" if args.i_max else ""
+    with RunLog(args.outdir, suffix, want_rtf=args.rtf, want_triples=clean is not None) as log:
+        for job in plan_jobs(noisy, clean, args.outdir, args.i_min, args.i_max, args.skip_existing, args.exclude_files_matching):
+            if job.pending:
+                enhance_file(model, job, args, gen, log, res, max_seconds)
+            log.triple(job)
     return res
 
 

@@ -4,7 +4,9 @@ roundings modelled in float32 NumPy arithmetic -- conv operands rounded to bf16 
 between kernels rounded to bf16 (storage_round) -- against the reference output stored in G10.  Writes g19_bf16_prediction.json;
 tests/test_hip_model.py::test_bf16_error_is_the_predicted_one holds the HIP bf16 forward to 1.3 x the prediction (the factor covers
 summation order, the fused SiLU's transcendental ulps and the fp16-operand Winograd launches, which round LESS than the model here).
-CPU only, ~5 min:  python tests/golden/make_golden_bf16_prediction.py"""
+CPU only, ~5 min:  python tests/golden/make_golden_bf16_prediction.py
+`--cfg2clip` (round 5, ~20 min): ONLY the prediction for G21 (one 2 s clip, T_pad = 256, Euler-6: the image size bench.py times), merged
+into the existing json as enhance_rel_l2["cfg2clip_euler_N6"]."""
 import json
 import os
 import sys
@@ -16,9 +18,36 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import flowdec_oracle as O  # noqa: E402
 
+rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel()))
+
+
+def g21_inputs(g21):
+    """(y, noise) of G21: y is stored, the noise is re-drawn in the generator's order (make_golden_nf64_enhance.py --cfg2clip)."""
+    rng = np.random.default_rng(int(g21["rng_seed"]))
+    y = (0.1 * rng.standard_normal(g21["y"].shape)).astype(np.float32)
+    assert np.array_equal(y, g21["y"])
+    shape = (1, 1, 768, O.padded_frames(O.num_frames(y.shape[-1])))
+    noise = ((rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) / np.sqrt(2.0)).astype(np.complex64)
+    assert abs(noise.astype(np.complex128).sum() - complex(g21["noise_sum"])) < 1e-6
+    return y, noise
+
+
+if "--cfg2clip" in sys.argv:
+    g21 = np.load(os.path.join(HERE, "g21_enhance_nf64_cfg2clip.npz"))
+    y21, nz21 = g21_inputs(g21)
+    t0 = time.time()
+    net = O.NCSNppOracle(O.random_state_dict(seed=int(g21["seed"]), nf=64), nf=64, operand_round="bf16", storage_round="bf16")
+    xh = O.enhance(net, y21, nz21, g21["sigma_y"], N=6, solver="euler")
+    e = rel(xh, g21["euler_N6"])
+    print(f"cfg2clip enhance euler N=6: predicted waveform rel L2 err {e:.3e}  ({time.time() - t0:.0f} s)", flush=True)
+    path = os.path.join(HERE, "g19_bf16_prediction.json")
+    j = json.load(open(path))
+    j["enhance_rel_l2_cfg2clip"] = {"euler_N6": e}
+    json.dump(j, open(path, "w"), indent=1)
+    sys.exit(0)
+
 g = np.load(os.path.join(HERE, "g10_ncsnpp_nf64.npz"))
 sd = O.random_state_dict(seed=int(g["seed"]), nf=64)
-rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel()))
 t = np.array([float(g["t"])] if "t" in g.files else [0.5], np.float32)
 out = {}
 for name, kw in (("f32", {}), ("bf16_operands", dict(operand_round="bf16")), ("bf16_operands_and_storage", dict(operand_round="bf16", storage_round="bf16"))):

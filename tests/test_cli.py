@@ -45,14 +45,35 @@ def test_read_list_formats(tmp_path):
     c = tmp_path / "comma.txt"; c.write_text("c/a,1.wav ---> n/a,1.wav\n")
     fl = read_list(str(c))
     assert fl.clean == ["c/a,1.wav"] and fl.inputs == ["n/a,1.wav"]
-    for name, text in (("bad3.txt", "a.wav,b.wav,c.wav\n"), ("bad4.txt", "a ---> b ---> c\n")):
-        bad = tmp_path / name; bad.write_text(text)
-        with pytest.raises(ValueError, match=r":1: 3 fields"):
-            read_list(str(bad))
+    # more than two fields: the reference keeps the whole split and uses fields 0 and 1 (enhance.py:153-158), so the tool's own
+    # triples_list output (`clean ---> noisy ---> out`) or a CSV with extra columns can be fed back in; here the same, with a warning
+    for name, text in (("tri1.txt", "a.wav,b.wav,c.wav\n"), ("tri2.txt", "a.wav ---> b.wav ---> c.wav\n")):
+        tri = tmp_path / name; tri.write_text(text)
+        fl = read_list(str(tri))
+        assert fl.clean == ["a.wav"] and fl.inputs == ["b.wav"]
     (tmp_path / "d").mkdir()
     for n in ("b.wav", "a.wav", "c.txt"):
         (tmp_path / "d" / n).write_bytes(b"")
     assert [os.path.basename(f) for f in collect_files(str(tmp_path / "d"), False)[0]] == ["a.wav", "b.wav"]
+
+
+def test_plan_jobs_filters(tmp_path):
+    """The work list: exclusion pattern (renumbers), inclusive index window, exists-check under --skip-existing; pair lists carry the
+    clean path along."""
+    from flowdec_amd.enhance_cli import plan_jobs
+    out = tmp_path / "out"; out.mkdir()
+    noisy = [f"n/{k}.wav" for k in "abcde"]
+    clean = [f"c/{k}.wav" for k in "abcde"]
+    (out / "c.wav").write_bytes(b"")
+    jobs = list(plan_jobs(noisy, clean, str(out), None, None, True))
+    assert [j.index for j in jobs] == [0, 1, 2, 3, 4] and [j.pending for j in jobs] == [True, True, False, True, True]
+    assert jobs[1].src == "n/b.wav" and jobs[1].clean == "c/b.wav" and jobs[1].dst == os.path.join(str(out), "b.wav")
+    assert all(j.pending for j in plan_jobs(noisy, None, str(out), None, None, False)) and next(plan_jobs(noisy, None, str(out), None, None, False)).clean is None
+    assert [j.src for j in plan_jobs(noisy, clean, str(out), 1, 3, True)] == ["n/b.wav", "n/c.wav", "n/d.wav"]
+    assert [j.src for j in plan_jobs(noisy, clean, str(out), 3, 99, True)] == ["n/d.wav", "n/e.wav"]
+    ex = list(plan_jobs(noisy, clean, str(out), 1, 2, True, exclude="b.wav"))      # the window counts what the exclusion left
+    assert [(j.index, j.src, j.clean) for j in ex] == [(1, "n/c.wav", "c/c.wav"), (2, "n/d.wav", "c/d.wav")]
+    assert list(plan_jobs([], None, str(out), None, None, True)) == []
 
 
 def test_wav_roundtrip_and_resample(tmp_path):
