@@ -26,7 +26,7 @@ def main(d, steps):
     print(f"# {steps} steps with kernel records; listed kernels {tot / steps:.2f} ms per step")
     conv = fir = once = 0.0
     nconv = nstep = 0
-    ONCE = ("__amd_rocclr_copyBuffer", "pack_weights_kernel", "wino_pack_kernel", "wino4_pack", "at::native", "fillBuffer")   # model load / weight packing / torch's input generation
+    ONCE = ("__amd_rocclr_copyBuffer", "pack_weights_kernel", "wino_pack_kernel", "wino4_pack", "wino4_scale", "wino_scale", "at::native", "fillBuffer")   # model load / weight packing / torch's input generation
     for k, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         short = k.replace("_ZN12_GLOBAL__N_1", "").replace("(anonymous namespace)::", "").replace("void ", "")[:84]
         if any(o in k for o in ONCE):
