@@ -358,11 +358,6 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
   // Two chunks per iteration: 18 steps = three turns of the ring = six turns of the fragment quads, and the V buffers swap back, so
   // that every LDS offset is an immediate and the loop has ONE set of MFMA sites (two bodies in one loop double the accumulators).
   constexpr int NW = 2 * (NRING - 2);   // weight pieces that may stay in flight at the wait
-#if defined(W4_PRIO_XT1)
-  if (xt == 1) __builtin_amdgcn_s_setprio(1);   // static priority for the second-dispatched wave group (MI355X_MICROARCH "two waves per SIMD", item 4)
-#elif defined(W4_PRIO_XT0)
-  if (xt == 0) __builtin_amdgcn_s_setprio(1);   // ... or for the group that converts two slots per chunk
-#endif
   for (int c = 0; c < n3; c += 2) {
     int xg = xt;                       // (opaque per iteration: hipcc otherwise unswitches the loop on the wave group -- two loop bodies,
     asm volatile("" : "+s"(xg));       //  two sets of MFMA sites, spilled accumulators)
@@ -405,9 +400,6 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4_kernel(ConvArgs p) {
     wp += 36 * SLAB;
     asm volatile("" : "+s"(wp));
   }
-#if defined(W4_PRIO_XT1) || defined(W4_PRIO_XT0)
-  __builtin_amdgcn_s_setprio(0);
-#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // all fragment reads / DMA done before the epilogue reuses the LDS
   FD_T2(const unsigned long long t2_loop = __builtin_amdgcn_s_memtime();)

@@ -5,8 +5,8 @@ between kernels rounded to bf16 (storage_round) -- against the reference output 
 tests/test_hip_model.py::test_bf16_error_is_the_predicted_one holds the HIP bf16 forward to 1.3 x the prediction (the factor covers
 summation order, the fused SiLU's transcendental ulps and the fp16-operand Winograd launches, which round LESS than the model here).
 CPU only, ~5 min:  python tests/golden/make_golden_bf16_prediction.py
-`--cfg2clip` (round 5, ~20 min): ONLY the prediction for G21 (one 2 s clip, T_pad = 256, Euler-6: the image size bench.py times), merged
-into the existing json as enhance_rel_l2["cfg2clip_euler_N6"]."""
+`--cfg2clip` / `--cfg3clip` (round 5, ~15 min each): ONLY the prediction for G21 (one 2 s clip, T_pad = 256, Euler-6: the image size
+bench.py times) / G23 (the same for FlowDec-25s, midpoint N = 3), merged into the existing json as enhance_rel_l2_cfg2clip / _cfg3clip."""
 import json
 import os
 import sys
@@ -32,19 +32,22 @@ def g21_inputs(g21):
     return y, noise
 
 
-if "--cfg2clip" in sys.argv:
-    g21 = np.load(os.path.join(HERE, "g21_enhance_nf64_cfg2clip.npz"))
-    y21, nz21 = g21_inputs(g21)
-    t0 = time.time()
-    net = O.NCSNppOracle(O.random_state_dict(seed=int(g21["seed"]), nf=64), nf=64, operand_round="bf16", storage_round="bf16")
-    xh = O.enhance(net, y21, nz21, g21["sigma_y"], N=6, solver="euler")
-    e = rel(xh, g21["euler_N6"])
-    print(f"cfg2clip enhance euler N=6: predicted waveform rel L2 err {e:.3e}  ({time.time() - t0:.0f} s)", flush=True)
-    path = os.path.join(HERE, "g19_bf16_prediction.json")
-    j = json.load(open(path))
-    j["enhance_rel_l2_cfg2clip"] = {"euler_N6": e}
-    json.dump(j, open(path, "w"), indent=1)
-    sys.exit(0)
+CLIPS = {"--cfg2clip": ("g21_enhance_nf64_cfg2clip.npz", "euler", 6, "enhance_rel_l2_cfg2clip"),
+         "--cfg3clip": ("g23_enhance_nf64_cfg3clip.npz", "midpoint", 3, "enhance_rel_l2_cfg3clip")}
+for flag, (fname, solver, N, table) in CLIPS.items():
+    if flag in sys.argv:
+        gc = np.load(os.path.join(HERE, fname))
+        yc, nzc = g21_inputs(gc)
+        t0 = time.time()
+        net = O.NCSNppOracle(O.random_state_dict(seed=int(gc["seed"]), nf=64), nf=64, operand_round="bf16", storage_round="bf16")
+        xh = O.enhance(net, yc, nzc, gc["sigma_y"], N=N, solver=solver)
+        e = rel(xh, gc[f"{solver}_N{N}"])
+        print(f"{flag[2:]} enhance {solver} N={N}: predicted waveform rel L2 err {e:.3e}  ({time.time() - t0:.0f} s)", flush=True)
+        path = os.path.join(HERE, "g19_bf16_prediction.json")
+        j = json.load(open(path))
+        j[table] = {f"{solver}_N{N}": e}
+        json.dump(j, open(path, "w"), indent=1)
+        sys.exit(0)
 
 g = np.load(os.path.join(HERE, "g10_ncsnpp_nf64.npz"))
 sd = O.random_state_dict(seed=int(g["seed"]), nf=64)

@@ -7,6 +7,8 @@ through the stub recipe of make_golden.py); only the arrays travel.  Weights are
     python tests/golden/make_golden_nf64_enhance.py          # ~1-2 min of CPU, writes tests/golden/g17_enhance_nf64.npz
     python tests/golden/make_golden_nf64_enhance.py --cfg1   # G18: BASELINE config 1 EXACTLY -- one 1 s clip, 6-step Euler, fp32 -- ~2 min,
                                                              # writes tests/golden/g18_enhance_nf64_cfg1.npz
+    python tests/golden/make_golden_nf64_enhance.py --cfg3clip   # G23: like G21 for BASELINE config 3: FlowDec-25s (sigma_y curve of
+                                                             # data/flowdec_autoparams_25s.npy), one 2 s clip, midpoint N = 3 (NFE 6)
     python tests/golden/make_golden_nf64_enhance.py --cfg2clip   # G21: ONE clip of BASELINE config 2's shape -- 2 s, T_pad = 256 frames, 6-step
                                                              # Euler, fp32 -- ~4 min; the image size bench.py times (the kernel schedule of
                                                              # a 768 x 256 image differs from every shorter golden).  The noise is
@@ -42,14 +44,16 @@ def main():
                  output_layer_kwargs=dict(kernel_size=1, bias=False, padding="same", padding_mode="zeros"),
                  bottleneck_attn=False)
     fe = AmplitudeCompressedComplexSTFT(window_fn="hann", n_fft=1534, n_hops=4, sampling_rate=48000, alpha=0.3, beta=0.33)
-    sig = sigma_models.from_file(os.path.join(MG.REF, "data", "flowdec_autoparams_75m.npy"), factor=1, kernel_bandwidth=3)
+    sig = sigma_models.from_file(os.path.join(MG.REF, "data", "flowdec_autoparams_25s.npy" if "--cfg3clip" in sys.argv else "flowdec_autoparams_75m.npy"),
+                                 factor=1, kernel_bandwidth=3)
     fm = FlowModel(flow_matcher=None, sigma_x=0.0, sigma_y=sig, backbone=NCSNpp(nf=64, **bb_kw), feature_extractor=fe,
                    sampling_rate=48000, lr=1e-4, full_config={}).eval()
     sd = O.random_state_dict(seed=64, nf=64)
     fm.backbone.load_state_dict(MG.to_t(MG.strip(sd, "backbone.")))
     cfg1 = "--cfg1" in sys.argv
-    cfg2 = "--cfg2clip" in sys.argv
-    rng_seed = 2101 if cfg2 else 1801 if cfg1 else 1764
+    cfg3 = "--cfg3clip" in sys.argv     # G23: one clip of BASELINE config 3's shape: FlowDec-25s (per-frequency sigma_y curve), 2 s, midpoint N = 3
+    cfg2 = "--cfg2clip" in sys.argv or cfg3
+    rng_seed = 2303 if cfg3 else 2101 if cfg2 else 1801 if cfg1 else 1764
     rng = np.random.default_rng(rng_seed)
     L = 96000 if cfg2 else 48000 if cfg1 else 24000
     y = (0.1 * rng.standard_normal((1, 1, L))).astype(np.float32)
@@ -62,12 +66,12 @@ def main():
         del g["noise"]
         g.update(rng_seed=np.int64(rng_seed), noise_sum=np.complex128(noise.astype(np.complex128).sum()),
                  noise_abs2=np.float64((np.abs(noise.astype(np.complex128)) ** 2).sum()))
-    for solver, N in ((("euler", 6),) if (cfg1 or cfg2) else (("euler", 6), ("midpoint", 3))):
+    for solver, N in ((("midpoint", 3),) if cfg3 else (("euler", 6),) if (cfg1 or cfg2) else (("euler", 6), ("midpoint", 3))):
         t0 = time.time()
         xh = fm.enhance(torch.from_numpy(y), N=N, solver=solver)
         print(f"{solver} N={N}: {time.time() - t0:.1f} s on {torch.get_num_threads()} threads", flush=True)
         g[f"{solver}_N{N}"] = xh.numpy()
-    name = "g21_enhance_nf64_cfg2clip.npz" if cfg2 else "g18_enhance_nf64_cfg1.npz" if cfg1 else "g17_enhance_nf64.npz"
+    name = "g23_enhance_nf64_cfg3clip.npz" if cfg3 else "g21_enhance_nf64_cfg2clip.npz" if cfg2 else "g18_enhance_nf64_cfg1.npz" if cfg1 else "g17_enhance_nf64.npz"
     np.savez_compressed(os.path.join(HERE, name), **g)
     print(name, os.path.getsize(os.path.join(HERE, name)) // 1024, "KiB")
 

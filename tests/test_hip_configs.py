@@ -134,6 +134,23 @@ def test_cfg2_image_size_vs_reference(prec):
         assert torch.equal(xb[5], x[0]), "a clip inside cfg 2's batch differs from the same clip alone"
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_cfg3_image_size_vs_reference(prec):
+    """BASELINE config 3's model and solver at its image size, against the REFERENCE's own FlowModel.enhance (golden G23 =
+    make_golden_nf64_enhance.py --cfg3clip): FlowDec-25s -- the per-frequency sigma_y curve of data/flowdec_autoparams_25s.npy
+    (flowdec/data/sigma_models.py from_file) -- one 2 s clip, midpoint N = 3 (NFE 6).  fp32: 5e-4; bf16: 1.6 x the prediction of the
+    oracle with bf16 roundings on this clip, and not below 0.3 x it."""
+    g = load_golden("g23_enhance_nf64_cfg3clip.npz")
+    y, noise = _g21_inputs(g)
+    m, _ = _preset_model("flowdec_25s", 64, int(g["seed"]), prec)
+    assert np.allclose(m.sigma_y.detach().cpu().numpy(), g["sigma_y"], rtol=1e-12)
+    x = m.enhance(torch.from_numpy(y), N=3, solver="midpoint", noise=torch.from_numpy(noise))
+    assert x.shape == (1, 1, 96000)
+    check(f"cfg3clip_enhance_nf64[midpoint,N=3,{prec}]", x.numpy(), g["midpoint_N3"], tol_wave_full(prec, "midpoint_N3", "enhance_rel_l2_cfg3clip"))
+    if prec == "bf16":
+        assert rel_err(x.numpy(), g["midpoint_N3"]) > 0.3 * BF16_PRED["enhance_rel_l2_cfg3clip"]["midpoint_N3"]
+
+
 def test_cfg5_fp32_4s_32step_and_adaptive():
     """BASELINE config 5, per-GPU shape: fp32, 8 x 4 s clips, 32 solver steps (fixed-step reading), clip independence.  The adaptive
     reading (dopri5 over the same 33-point t_span) at FULL size takes minutes (494 / 530 evaluations at atol = rtol = 1e-4:
