@@ -46,12 +46,15 @@ extern "C" {
 /* Algorithm flag, OR-ed into the `dtype` / `wdtype` / `act_dtype` arguments that select a convolution (storage type =
  * value & 0xff): 3x3 convolutions with Cout % 128 == 0 and all channel counts % 32 == 0 run as Winograd F(2,3) along W
  * (1.5x fewer MFMAs; bf16 storage, fp16 MFMA operands, f32 accumulation; conv_wino.hip).  The packed weights of the two
- * algorithms differ: pack and launch with the same flag. */
+ * algorithms differ: pack and launch with the same flag.  Both Winograd packings scale every output channel's transformed weights
+ * (and its folded shortcut weights) by a power of two before the fp16 rounding and carry the inverse table behind the packed steps;
+ * the kernels undo it exactly in the epilogue -- weights of any magnitude (1e-6 .. 1e2 tested, per channel) keep their mantissa. */
 #define FD_WINOGRAD 0x100
 /* Same places as FD_WINOGRAD: 3x3 convolutions with Cout == 256, all channel counts % 32 == 0 and whole 16 x 16 pixel tiles
  * (H % 16 == W % 16 == 0) as Winograd F(4,3) along W -- HALF the MFMAs of the direct kernel; 256-cout workgroups with the input
  * transform done once per workgroup when the activated halo is stored (conv_wino4.hip).  bf16 storage, fp16 MFMA operands, f32
- * accumulation; raw (not activated) inputs saturate at +-6000.  Pack and launch with the same flag. */
+ * accumulation; 3x3 inputs, raw or activated, saturate at +-6000 in their fp16 form (a folded shortcut input never passes through
+ * fp16).  Pack and launch with the same flag. */
 #define FD_WINOGRAD4 0x80000
 /* fd_conv2d with FD_WINOGRAD4 only: walk the pixel tiles in DESCENDING order.  Same result, bit for bit; a consumer that starts where
  * its producer stopped finds the producer's last output lines still in the memory-side cache (the model alternates the direction from
