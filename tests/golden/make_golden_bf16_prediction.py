@@ -33,7 +33,8 @@ def g21_inputs(g21):
 
 
 CLIPS = {"--cfg2clip": ("g21_enhance_nf64_cfg2clip.npz", "euler", 6, "enhance_rel_l2_cfg2clip"),
-         "--cfg3clip": ("g23_enhance_nf64_cfg3clip.npz", "midpoint", 3, "enhance_rel_l2_cfg3clip")}
+         "--cfg3clip": ("g23_enhance_nf64_cfg3clip.npz", "midpoint", 3, "enhance_rel_l2_cfg3clip"),
+         "--cfg4clip": ("g24_enhance_nf64_cfg4clip.npz", "midpoint", 3, "enhance_rel_l2_cfg4clip")}
 for flag, (fname, solver, N, table) in CLIPS.items():
     if flag in sys.argv:
         gc = np.load(os.path.join(HERE, fname))

@@ -101,7 +101,7 @@ def _g21_inputs(g):
     rng = np.random.default_rng(int(g["rng_seed"]))
     y = (0.1 * rng.standard_normal(g["y"].shape)).astype(np.float32)
     assert np.array_equal(y, g["y"])
-    shape = (1, 1, 768, 256)
+    shape = (1, 1, 768, O.padded_frames(O.num_frames(y.shape[-1])))
     noise = ((rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) / np.sqrt(2.0)).astype(np.complex64)
     assert abs(noise.astype(np.complex128).sum() - complex(g["noise_sum"])) < 1e-6
     assert abs((np.abs(noise.astype(np.complex128)) ** 2).sum() - float(g["noise_abs2"])) < 1e-6 * float(g["noise_abs2"])
@@ -149,6 +149,33 @@ def test_cfg3_image_size_vs_reference(prec):
     check(f"cfg3clip_enhance_nf64[midpoint,N=3,{prec}]", x.numpy(), g["midpoint_N3"], tol_wave_full(prec, "midpoint_N3", "enhance_rel_l2_cfg3clip"))
     if prec == "bf16":
         assert rel_err(x.numpy(), g["midpoint_N3"]) > 0.3 * BF16_PRED["enhance_rel_l2_cfg3clip"]["midpoint_N3"]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_cfg4_image_size_vs_reference(prec):
+    """BASELINE config 4's model, solver and image size (FlowDec-75m, 2 s clips, midpoint N = 3 -- what each of the 8 GPUs runs on its 32
+    clips) against the REFERENCE's own FlowModel.enhance on one such clip (golden G24 = make_golden_nf64_enhance.py --cfg4clip)."""
+    g = load_golden("g24_enhance_nf64_cfg4clip.npz")
+    y, noise = _g21_inputs(g)
+    m = make_model(64, int(g["seed"]), prec)
+    x = m.enhance(torch.from_numpy(y), N=3, solver="midpoint", noise=torch.from_numpy(noise))
+    check(f"cfg4clip_enhance_nf64[midpoint,N=3,{prec}]", x.numpy(), g["midpoint_N3"], tol_wave_full(prec, "midpoint_N3", "enhance_rel_l2_cfg4clip"))
+    if prec == "bf16":
+        assert rel_err(x.numpy(), g["midpoint_N3"]) > 0.3 * BF16_PRED["enhance_rel_l2_cfg4clip"]["midpoint_N3"]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_cfg5_clip_vs_reference(prec):
+    """BASELINE config 5's precision, clip length and step count -- fp32, 4 s clips (T_pad = 512 frames: a 768 x 512 image), 32 solver steps
+    in the fixed-step reading (Euler) -- against the REFERENCE's own FlowModel.enhance on one such clip (golden G25 =
+    make_golden_nf64_enhance.py --cfg5clip, ~20 min of CPU there): the exact-f32 mode and the fp32-tolerance mode `bf16x3` at 5e-4.
+    (The adaptive reading needs torchdyn's controller, which is not available offline: scripts/pin_third_party.py.)"""
+    g = load_golden("g25_enhance_nf64_cfg5clip.npz")
+    y, noise = _g21_inputs(g)
+    assert y.shape == (1, 1, 192000) and noise.shape[-1] == 512
+    m = make_model(64, int(g["seed"]), prec)
+    x = m.enhance(torch.from_numpy(y), N=32, solver="euler", noise=torch.from_numpy(noise))
+    check(f"cfg5clip_enhance_nf64[euler,N=32,{prec}]", x.numpy(), g["euler_N32"], TOL_WAVE_FULL[prec])
 
 
 def test_cfg5_fp32_4s_32step_and_adaptive():
@@ -1051,7 +1078,7 @@ def test_conv2d_winograd4_matches_its_numerics_model(case):
         y = y + sk
         scale = np.float32(1 / np.sqrt(2))
     if bias_rows:
-        y = y + (bv[:, :, None, None] if bias_rows > 1 else bv[0][None, :, None, None])   # the kernel: ((m [+ skip]) + bias) * scale in f32
+        y = y + (bv[:, :, None, None] if bias_rows > 1 else bv[0][None, :, None, None])   # the kernel: m (scale / wscale) + (skip scale + bias scale), fused: <= 2 f32 ulps from this
     model = bf(y * scale)
     pw = ops.pack_conv_weight(dev(w), C0=C0, dtype=torch.bfloat16, w_sc=w_sc, S0=S0 if S0 else None, winograd=4)
     out = ops.conv2d(nhwc(x[:, :C0], torch.bfloat16), pw, Cout, 3, x1=nhwc(x[:, C0:], torch.bfloat16) if C1 else None, affine=aff, bias=bias,
