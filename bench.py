@@ -9,8 +9,9 @@ waveforms to host waveforms ("H2D of waveform -> D2H of waveform") 
 by the 2 x 6 MB of PCIe copies (< 1 ms of ~120).  The initial noise of every clip is drawn INSIDE the timed call, as the reference
 does (flowdec/model.py:512 `_get_noise`): `sharded_enhance(..., seed=)`, one Philox stream per (step, global clip).
 
-`--config cfg2|cfg3|cfg3_n6|cfg4|cfg5` selects a BASELINE.json configuration by name (explicit flags given after it still apply):
-cfg 4 = FlowDec-75m, 32 x 2 s clips PER GPU, midpoint N = 3 (NFE 6), bf16 -- under `--gpus 8` that is the 256-clip batch of config 4.
+`--config cfg2|cfg3|cfg4|cfg5|cfg3_nfe6|cfg4_nfe6|cfg5_dopri5` selects a BASELINE.json configuration by name (explicit flags given after
+it still apply): cfg 4 = FlowDec-75m, 32 x 2 s clips PER GPU, midpoint N = 6 (12 evaluations: the reference counts solver steps,
+flowdec/model.py:487), bf16 -- under `--gpus 8` that is the 256-clip batch of config 4; `cfg4_nfe6` = the N = 3 (NFE 6) reading.
 
 Multi-GPU: one process per GPU, the GLOBAL batch (default 8 clips per GPU = weak scaling; `--global-batch G`
 fixes the total = strong scaling, e.g. 256 for BASELINE config 4) is sharded by clip with `flowdec_amd.dist.sharded_enhance`
@@ -108,16 +109,25 @@ def relaunch(args):
 
 # BASELINE.json configurations by name: what `--config` sets (flags given explicitly on the command line win)
 CONFIGS = {
+    # "6-step midpoint": the reference counts SOLVER STEPS -- enhance(N=6, solver='midpoint') evaluates the network 2 N = 12 times
+    # (flowdec/model.py:487) -- so cfg3 / cfg4 are N = 6.  The notebook's "NFE 6" operating point (demo.ipynb cell 3: N = 3) stays
+    # available under the explicit names *_nfe6 (cfg3_n6 = the former name of today's cfg3).
     "cfg2": dict(preset="flowdec_75m", batch=8, seconds=2.0, N=6, solver="euler", precision="bf16"),
-    "cfg3": dict(preset="flowdec_25s", batch=32, seconds=2.0, N=3, solver="midpoint", precision="bf16"),       # "6-step midpoint" read as NFE 6
-    "cfg3_n6": dict(preset="flowdec_25s", batch=32, seconds=2.0, N=6, solver="midpoint", precision="bf16"),    # ... read as N = 6 (NFE 12, model.py:487)
-    "cfg4": dict(preset="flowdec_75m", batch=32, seconds=2.0, N=3, solver="midpoint", precision="bf16"),       # x 8 GPUs = 256 clips
-    "cfg5": dict(preset="flowdec_75m", batch=8, seconds=4.0, N=32, solver="euler", precision="fp32"),          # x 8 GPUs = 64 clips; fixed-step reading
+    "cfg3": dict(preset="flowdec_25s", batch=32, seconds=2.0, N=6, solver="midpoint", precision="bf16"),
+    "cfg3_n6": dict(preset="flowdec_25s", batch=32, seconds=2.0, N=6, solver="midpoint", precision="bf16"),
+    "cfg3_nfe6": dict(preset="flowdec_25s", batch=32, seconds=2.0, N=3, solver="midpoint", precision="bf16"),
+    "cfg4": dict(preset="flowdec_75m", batch=32, seconds=2.0, N=6, solver="midpoint", precision="bf16"),       # x 8 GPUs = 256 clips
+    "cfg4_n6": dict(preset="flowdec_75m", batch=32, seconds=2.0, N=6, solver="midpoint", precision="bf16"),
+    "cfg4_nfe6": dict(preset="flowdec_75m", batch=32, seconds=2.0, N=3, solver="midpoint", precision="bf16"),
+    # "32-step adaptive": cfg5 = the fixed-step reading (32 Euler steps); cfg5_dopri5 = torchdyn's adaptive dopri5 over the 33-point
+    # t_span at the solver's default tolerances (realised NFE reported; minutes per step in fp32 -- scripts/bench_cfg5_dopri5.py)
+    "cfg5": dict(preset="flowdec_75m", batch=8, seconds=4.0, N=32, solver="euler", precision="fp32"),          # x 8 GPUs = 64 clips
+    "cfg5_dopri5": dict(preset="flowdec_75m", batch=8, seconds=4.0, N=32, solver="dopri5", precision="fp32"),
 }
 
 
 def main():
-    ap = argparse.ArgumentParser()
+    ap = argparse.ArgumentParser(allow_abbrev=False)   # (an abbreviated flag would slip past the --config override test below)
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="a BASELINE.json configuration by name (per-GPU shard; see CONFIGS)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -133,6 +143,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the ~0.3 s box calibration (fd_calibrate_mfma) and the clock / power sampling")
     ap.add_argument("--no-e2e", action="store_true", help="skip the second timed loop (pinned host waveforms in -> host waveforms out)")
     ap.add_argument("--no-side-stream", action="store_true", help="FD_NO_SIDE_STREAM: keep the side branches on the launch stream")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --stub-step: launcher / collective test on CPU")
@@ -247,9 +258,25 @@ def main():
             el = max(float(t[0]) for t in allt)
         return out, el, per_rank, 1e3 * gs / steps
 
+    # Box calibration (round 6): the boxes of the pool differ by +-2.5 % and the chip runs the step at its power limit, so the line
+    # carries what THIS box sustains on a fixed matrix-core loop (+ clock / power while it runs) and the clock / power of the timed
+    # region itself; `value_per_calibration` = value / mfma_tflops is the figure to compare across boxes and rounds.
+    calib = power = None
+    probe = dev.type == "cuda" and not args.no_calibration and not args.stub_step
+    if probe:
+        from flowdec_amd import boxprobe
+        try:
+            calib = boxprobe.calibrate(dev)
+        except Exception as e:   # never lose a bench line to the probe
+            calib = {"error": repr(e)}
     for _ in range(args.warmup):
         out = step(y)
-    out, elapsed, per_rank_ms, gather_ms = timed(y, args.steps)
+    if probe:
+        with boxprobe.PowerSampler(dev.index or 0, period_s=0.1) as sampler:
+            out, elapsed, per_rank_ms, gather_ms = timed(y, args.steps)
+        power = sampler.summary()
+    else:
+        out, elapsed, per_rank_ms, gather_ms = timed(y, args.steps)
     assert out.shape[0] == gbatch and out.device == y.device and torch.isfinite(out).all()
     if nfe is None:
         nfe = model.last_nfe   # adaptive solver: realised number of vector-field evaluations of the last step
@@ -268,6 +295,24 @@ def main():
                    "hipgraph": not args.no_graph, "conv_algo": args.conv_algo, "backend": args.backend if world > 1 else None},
         "per_rank_ms_per_step": per_rank_ms, "allgather_ms_per_step": gather_ms if world > 1 else 0.0,
     }
+    if calib is not None:
+        result["box_calibration"] = calib
+        result["power"] = power
+        if calib.get("mfma_tflops"):
+            result["value_per_calibration"] = result["value"] / world / calib["mfma_tflops"]   # per-GPU audio-s/s per calibration TFLOP/s
+    if dev.type == "cuda" and not args.stub_step:
+        # which devices the ranks really ran on (the first SCALE record must show N DISTINCT GPUs behind the RCCL world)
+        pr = torch.cuda.get_device_properties(dev)
+        me = {"rank": rank, "device": str(dev), "name": pr.name, "uuid": str(getattr(pr, "uuid", "")),
+              "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+              "mfma_tflops": (calib or {}).get("mfma_tflops")}
+        devs = [me]
+        if dist is not None:
+            devs = [None] * world
+            dist.all_gather_object(devs, me)
+        result["devices"] = devs
+        result["rccl_world"] = dist.get_world_size() if (dist is not None and args.backend == "nccl") else (1 if dist is None else 0)
+        result["distinct_devices"] = len({(d["uuid"], d["pci"]) for d in devs})
     if args.stub_step:
         result["config"]["workload"] = "STUB step (launcher / collective test, no model)"
     elif not args.no_e2e:

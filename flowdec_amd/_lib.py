@@ -84,6 +84,8 @@ SIGNATURES = {
     "fd_stft_plan_destroy": (None, [_P]),
     "fd_stft_compress": (c_int, [_P, _P, c_int, c_int, c_float, c_float, c_int, _P, _P, c_int, _P, c_size_t, _P]),
     "fd_decompress_istft": (c_int, [_P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, c_int, _P, c_size_t, _P]),
+    "fd_stft_compress_ragged": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, c_int, _P, _P, c_int, _P, c_size_t, _P]),
+    "fd_decompress_istft_ragged": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, c_int, _P, c_size_t, _P]),
     "fd_compress_spec": (c_int, [_P, _P, c_ll, c_float, c_float, c_int, _P]),
     "fd_num_frames": (c_int, [c_int, c_int]),
     "fd_padded_frames": (c_int, [c_int]),
@@ -103,7 +105,9 @@ SIGNATURES = {
     "fd_enhance_workspace_bytes": (c_size_t, [_P, c_int, c_int]),
     "fd_enhance_normfac_offset": (c_size_t, [_P, c_int, c_int]),
     "fd_model_set_normalize": (c_int, [_P, c_int]),
+    "fd_calibrate_mfma": (c_int, [_P, c_int, c_int, _P, _P, _P]),
     "fd_enhance": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
+    "fd_enhance_ragged": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "fd_score_num_draws": (c_int, [C.POINTER(FdScoreConfig)]),
     "fd_score_enhance": (c_int, [_P, _P, _P, C.POINTER(FdScoreConfig), _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     "fd_score_eval": (c_int, [_P, _P, _P, c_float, C.POINTER(FdScoreConfig), c_int, _P, c_int, c_int, _P, c_size_t, _P]),

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libflowdec_hip.so")
-SOURCES = ["api.hip", "conv_mfma.hip", "conv_wino.hip", "conv_wino4.hip", "conv_head.hip", "elementwise.hip", "stft.hip", "model.hip", "ndac.hip", "ndac_mfma.hip"]
+SOURCES = ["api.hip", "calib.hip", "conv_mfma.hip", "conv_wino.hip", "conv_wino4.hip", "conv_head.hip", "elementwise.hip", "stft.hip", "model.hip", "ndac.hip", "ndac_mfma.hip"]
 # -fno-slp-vectorize: hipcc (ROCm 7.2) otherwise packs adjacent f32 FMAs into v_pk_fma_f32; beside MFMAs that is slower
 # (guide: MI355X_MICROARCH "price of one filler beside MFMAs") and one such packing of the fused GroupNorm affine
 # produced wrong lanes (op_sel_hi broadcast) in the f32 conv path.
@@ -34,8 +34,13 @@ def check_wino4_isa(hipcc=None, extra=()):
     """conv_wino4.hip writes M0 from inline asm without saving it (the LDS-DMA destination; hipcc refuses M0 on a clobber list) and counts
     its own s_waitcnt vmcnt by hand.  Both rest on properties of the GENERATED code, so the build checks them and fails otherwise: no M0
     use outside the kernel's own `s_mov_b32 m0` statements, no scratch (a spill inside the K loop would break the counted waits), and the
-    expected number of MFMA sites (one loop body per instantiation).  ~6 s, runs beside the object compiles."""
+    expected number of MFMA sites (one loop body per instantiation).  ~6 s, runs beside the object compiles.
+    The M0 and scratch properties are hard requirements; the MFMA-site count depends on how a given hipcc unrolls and is a WARNING only
+    (a duplicated loop body costs registers, not correctness).  `FLOWDEC_SKIP_ISA_CHECK=1` skips the whole check (another toolchain)."""
     import tempfile
+    if os.environ.get("FLOWDEC_SKIP_ISA_CHECK", "") not in ("", "0"):
+        print("flowdec_amd.build: FLOWDEC_SKIP_ISA_CHECK set -- conv_wino4.hip ISA properties NOT verified", file=sys.stderr)
+        return False
     hipcc = hipcc or _hipcc()
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "w4.s")
@@ -50,7 +55,9 @@ def check_wino4_isa(hipcc=None, extra=()):
         raise RuntimeError("conv_wino4.hip: a kernel spills to scratch (breaks the hand-counted s_waitcnt vmcnt)")
     n = sum("v_mfma_f32_32x32x16_f16" in l for l in code)
     if n != 6 * 72:   # six instantiations, 18 steps x 4 MFMAs each
-        raise RuntimeError("conv_wino4.hip: %d F(4,3) MFMA sites, expected %d (the K loop was duplicated or unswitched)" % (n, 6 * 72))
+        print("flowdec_amd.build: WARNING conv_wino4.hip has %d F(4,3) MFMA sites, expected %d (the K loop was duplicated or unswitched by "
+              "this hipcc: slower, still correct)" % (n, 6 * 72), file=sys.stderr)
+        return False
     return True
 
 

@@ -684,23 +684,25 @@ bool fd_wino_supported(int Cout, int C0, int C1, int S0, int S1, int ksize) {
 }
 
 namespace {
-// byte offset of the scale table [2][CoutPad] f32 (inverse scales, scales) behind the packed steps
-long long wino_scale_off(int CoutPad, int C0, int C1, int S0, int S1) { return (wino_steps(C0, C1, 3) + wino_steps(S0, S1, 1)) * 4 * CoutPad * WROWB; }
+// The packed buffer starts with a header that holds the scale table [2][CoutPad] f32 (inverse scales, scales): a position that
+// depends on the weight alone, not on the segment list of a launch (conv_wino4.hip does the same); the packed steps follow.
+long long wino_hdr_bytes(int CoutPad) { return (2ll * CoutPad * (long long)sizeof(float) + 4095) / 4096 * 4096; }
 }  // namespace
 
 long long fd_wino_packed_bytes(int Cout, int C0, int C1, int S0, int S1) {
   const int CoutPad = pad_to(Cout, BN);
-  return wino_scale_off(CoutPad, C0, C1, S0, S1) + 2ll * CoutPad * sizeof(float) + 1024;
+  return wino_hdr_bytes(CoutPad) + (wino_steps(C0, C1, 3) + wino_steps(S0, S1, 1)) * 4 * CoutPad * WROWB + 1024;
 }
 
 int fd_wino_pack_weights(const float* w, const float* w_sc, void* packed, int Cout, int C0, int C1, int S0, int S1, hipStream_t st) {
   const int CoutPad = pad_to(Cout, BN);
-  float* const tab = reinterpret_cast<float*>(reinterpret_cast<char*>(packed) + wino_scale_off(CoutPad, C0, C1, w_sc ? S0 : 0, w_sc ? S1 : 0));
+  float* const tab = reinterpret_cast<float*>(packed);
+  char* const steps = reinterpret_cast<char*>(packed) + wino_hdr_bytes(CoutPad);
   hipLaunchKernelGGL(wino_scale_kernel, dim3(CoutPad), dim3(256), 0, st, w, w_sc, tab, Cout, CoutPad, C0 + C1, w_sc ? S0 + S1 : 0);
   auto run = [&](const float* src, int c0, int c1, int taps, long long step0) {
     const long long total = wino_steps(c0, c1, taps == 9 ? 3 : 1) * 4 * CoutPad * CK;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, st, src, (char*)packed, tab, Cout, CoutPad, c0, c1, taps, step0);
+    hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, st, src, steps, tab, Cout, CoutPad, c0, c1, taps, step0);
   };
   run(w, C0, C1, 9, 0);
   if (w_sc) run(w_sc, S0, S1, 1, wino_steps(C0, C1, 3));
@@ -721,14 +723,8 @@ int fd_wino_launch(ConvArgs a, hipStream_t st) {
   a.tiles_w = fd_cdiv(a.W, TW);
   a.tiles_n = a.Cout / BN;
   a.CoutPad = pad_to(a.Cout, BN);
-  {
-    int c3[2] = {0, 0}, cs[2] = {0, 0}, n3 = 0, ns = 0;
-    for (int s = 0; s < a.nseg; ++s) {
-      if (a.seg[s].taps == 1) { if (ns < 2) cs[ns++] = a.seg[s].C; }
-      else if (n3 < 2) c3[n3++] = a.seg[s].C;
-    }
-    a.w_scale = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.w) + wino_scale_off(a.CoutPad, c3[0], c3[1], cs[0], cs[1]));
-  }
+  a.w_scale = reinterpret_cast<const float*>(a.w);                                // header of the packed buffer
+  a.w = reinterpret_cast<const char*>(a.w) + wino_hdr_bytes(a.CoutPad);           // the packed steps
   const long long nblk = (long long)a.B * a.tiles_h * a.tiles_w * a.tiles_n;
   FD_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
   const dim3 grid((unsigned)nblk), block(NTH);

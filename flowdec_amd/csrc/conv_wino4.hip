@@ -761,31 +761,45 @@ __device__ __forceinline__ float wino4_u(const float* g, int xi) {
 // weights are small (the reference zero-initialises Conv_1 and the pyramid heads, layers.py:100 -- a trained checkpoint may hold tiny
 // weights exactly there) would lose their mantissa.  One block per cout: m = max |U| over (cin, dy, xi); scale = 2^k with m 2^k in
 // [2^(U_EXP-1), 2^U_EXP); tab[cout] = 2^-k (the kernel's epilogue multiplies by it, exactly), tab[256 + cout] = 2^k (the pack kernels).
-// The folded shortcut's weights get the same factor (exact in bf16): both land in the same accumulators.
-__global__ void wino4_scale_kernel(const float* __restrict__ w, float* __restrict__ tab, int Cout, int Cin) {
-  __shared__ float red[256];
+// The folded shortcut's weights get the same factor (exact in bf16): both land in the same f32 accumulators -- so the factor is also
+// bounded by THEIR magnitude (a cout whose 3x3 row is ~1e-30 next to O(1) shortcut weights must not push the shortcut products
+// towards the edge of f32: scaled shortcut weights stay below 2^SC_EXP_MAX; the 3x3 row then flushes to zero in fp16, which is
+// what it is next to the shortcut term).
+constexpr int SC_EXP_MAX = 60;
+__global__ void wino4_scale_kernel(const float* __restrict__ w, const float* __restrict__ w_sc, float* __restrict__ tab, int Cout, int Cin, int S) {
+  __shared__ float red[256], red_sc[256];
   const int co = blockIdx.x, t = threadIdx.x;
-  float m = 0.f;
-  if (co < Cout)
+  float m = 0.f, msc = 0.f;
+  if (co < Cout) {
     for (int i = t; i < Cin * 3; i += 256) {
       const float* g = w + ((size_t)co * Cin * 3 + i) * 3;
 #pragma unroll
       for (int xi = 0; xi < 6; ++xi) m = fmaxf(m, fabsf(wino4_u(g, xi)));
     }
+    if (w_sc)
+      for (int i = t; i < S; i += 256) msc = fmaxf(msc, fabsf(w_sc[(size_t)co * S + i]));
+  }
   red[t] = m;
+  red_sc[t] = msc;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if (t < o) red[t] = fmaxf(red[t], red[t + o]);
+    if (t < o) { red[t] = fmaxf(red[t], red[t + o]); red_sc[t] = fmaxf(red_sc[t], red_sc[t + o]); }
     __syncthreads();
   }
   if (t == 0) {
     int k = 0;
     m = red[0];
+    msc = red_sc[0];
     if (m > 0.f && m < 3.0e38f) {
       int e;
       frexpf(m, &e);             // m = f 2^e, f in [0.5, 1)
       k = U_EXP - e;
       k = k < -100 ? -100 : (k > 100 ? 100 : k);
+      if (msc > 0.f && msc < 3.0e38f) {
+        int es;
+        frexpf(msc, &es);
+        if (k > SC_EXP_MAX - es) k = SC_EXP_MAX - es;
+      }
     }
     tab[co] = ldexpf(1.f, -k);
     tab[BN + co] = ldexpf(1.f, k);
@@ -836,27 +850,30 @@ bool fd_wino4_supported(int Cout, int C0, int C1, int S0, int S1, int ksize) {
 bool fd_wino4_shape_ok(int H, int W) { return H % TH == 0 && W % TW == 0; }
 
 namespace {
-// byte offset of the scale table [2][256] f32 (inverse scales, scales) behind the 3x3 part and the shortcut K steps
-long long wino4_scale_off(int C3, int S) { return (long long)(C3 / CK + 1) * 18 * SLAB + (long long)(S / CK) * SLAB; }
+// The packed buffer starts with a fixed 4-KiB header: the scale table [2][256] f32 (inverse scales, scales).  Its position does
+// not depend on the segment list of a launch (it used to sit behind the shortcut steps: a weight packed with a folded shortcut but
+// launched without its shortcut segments read another table); the packed steps the kernel streams follow at W4_HDR.
+constexpr long long W4_HDR = 4096;
 }  // namespace
 
 long long fd_wino4_packed_bytes(int Cout, int C0, int C1, int S0, int S1) {
   (void)Cout;
-  // 3x3 part + one chunk (the weight stream runs a ring length past the last step), then the shortcut K steps, then the scale table
-  return wino4_scale_off(C0 + C1, S0 + S1) + 16 * 1024;
+  // header, 3x3 part + one chunk (the weight stream runs a ring length past the last step), then the shortcut K steps (+ slack)
+  return W4_HDR + (long long)((C0 + C1) / CK + 1) * 18 * SLAB + (long long)((S0 + S1) / CK) * SLAB + 16 * 1024;
 }
 
 int fd_wino4_pack_weights(const float* w, const float* w_sc, void* packed, int Cout, int C0, int C1, int S0, int S1, hipStream_t st) {
   const long long total = (long long)((C0 + C1) / CK) * 18 * BN * CK;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  float* const tab = reinterpret_cast<float*>(reinterpret_cast<char*>(packed) + wino4_scale_off(C0 + C1, w_sc ? S0 + S1 : 0));
-  hipLaunchKernelGGL(wino4_scale_kernel, dim3(BN), dim3(256), 0, st, w, tab, Cout, C0 + C1);
-  hipLaunchKernelGGL(wino4_pack_kernel, dim3(blocks), dim3(256), 0, st, w, (f16*)packed, tab, Cout, C0, C1);
+  float* const tab = reinterpret_cast<float*>(packed);
+  char* const steps = reinterpret_cast<char*>(packed) + W4_HDR;
+  hipLaunchKernelGGL(wino4_scale_kernel, dim3(BN), dim3(256), 0, st, w, w_sc, tab, Cout, C0 + C1, w_sc ? S0 + S1 : 0);
+  hipLaunchKernelGGL(wino4_pack_kernel, dim3(blocks), dim3(256), 0, st, w, (f16*)steps, tab, Cout, C0, C1);
   if (w_sc) {
     const long long tsc = (long long)((S0 + S1) / CK) * BN * CK;
     const int bsc = (int)((tsc + 255) / 256 > 4096 ? 4096 : (tsc + 255) / 256);
     hipLaunchKernelGGL(wino4_pack_sc_kernel, dim3(bsc), dim3(256), 0, st, w_sc,
-                       reinterpret_cast<bf16*>(reinterpret_cast<char*>(packed) + (size_t)((C0 + C1) / CK + 1) * 18 * SLAB), tab, Cout, S0 + S1);
+                       reinterpret_cast<bf16*>(steps + (size_t)((C0 + C1) / CK + 1) * 18 * SLAB), tab, Cout, S0 + S1);
   }
   FD_LAUNCH_CHECK();
   return FD_OK;
@@ -887,12 +904,9 @@ int fd_wino4_init_attributes() {
 int fd_wino4_launch(ConvArgs a, hipStream_t st) {
   FD_REQUIRE(fd_wino4_shape_ok(a.H, a.W), "fd_conv2d: FD_WINOGRAD4 needs H %% 16 == 0 and W %% 16 == 0 (got %d x %d)", a.H, a.W);
   bool sc = false;
-  int c3 = 0, csc = 0;
-  for (int s = 0; s < a.nseg; ++s) {
-    sc = sc || a.seg[s].taps == 1;
-    (a.seg[s].taps == 1 ? csc : c3) += a.seg[s].C;
-  }
-  a.w_scale = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.w) + wino4_scale_off(c3, csc));
+  for (int s = 0; s < a.nseg; ++s) sc = sc || a.seg[s].taps == 1;
+  a.w_scale = reinterpret_cast<const float*>(a.w);                   // header of the packed buffer (launch-independent position)
+  a.w = reinterpret_cast<const char*>(a.w) + W4_HDR;                 // the packed steps
   FD_REQUIRE(!(sc && a.skip), "fd_conv2d: FD_WINOGRAD4 takes a folded shortcut or a residual input, not both");
   a.tiles_h = a.H / TH;
   a.tiles_w = a.W / TW;

@@ -46,9 +46,10 @@ int fd_caxpy(const float* a, const float* q, float cq, float* dst, long long n, 
 int fd_conv_init_attributes();
 // stft.hip
 // (fd_stft_plan / fd_stft_plan_create / fd_stft_plan_destroy: public, include/flowdec_hip.h)
-int fd_stft_forward(fd_stft_plan* p, const float* y, int B, int L, float alpha, float beta, int normalize, float* normfac,
+// lens: device int32 [B] per-clip sample counts of a ragged batch, or nullptr (every clip is L samples long)
+int fd_stft_forward(fd_stft_plan* p, const float* y, const int* lens, int B, int L, float alpha, float beta, int normalize, float* normfac,
                     float* Y, int T_pad, void* ws, size_t ws_bytes, hipStream_t st);
-int fd_stft_inverse(fd_stft_plan* p, const float* X, int B, int T, int T_pad, float alpha, float beta, const float* normfac,
+int fd_stft_inverse(fd_stft_plan* p, const float* X, const int* lens, int B, int T, int T_pad, float alpha, float beta, const float* normfac,
                     float* y, int L, void* ws, size_t ws_bytes, hipStream_t st);
 size_t fd_stft_ws_bytes(int B, int L, int n_fft, int hop);
 // ndac_mfma.hip: the codec's wide convolutions on the matrix cores (split-bf16 operands, f32 tolerance)

@@ -93,12 +93,12 @@ struct Tens {
 // Everything a captured solve bakes into its kernel arguments.  Compared field by field (a memcmp over the struct would read
 // its padding bytes).
 struct GraphKey {
-  const void *Y = nullptr, *noise = nullptr, *X = nullptr, *traj = nullptr, *ws = nullptr, *y = nullptr, *xhat = nullptr;
+  const void *Y = nullptr, *noise = nullptr, *X = nullptr, *traj = nullptr, *ws = nullptr, *y = nullptr, *xhat = nullptr, *lens = nullptr;
   int B = 0, T = 0, N = 0, solver = 0, L = 0, kind = 0, normalize = 1;
   float sigma_fac = 0.f;
   fd_score_config score{};   // kind 3 only (zero otherwise)
   auto tie() const {
-    return std::tie(Y, noise, X, traj, ws, y, xhat, B, T, N, solver, L, kind, normalize, sigma_fac, score.theta, score.sigma_min, score.sigma_max,
+    return std::tie(Y, noise, X, traj, ws, y, xhat, lens, B, T, N, solver, L, kind, normalize, sigma_fac, score.theta, score.sigma_min, score.sigma_max,
                     score.t_eps, score.snr, score.N, score.predictor, score.corrector, score.corrector_steps, score.denoise);
   }
   bool operator<(const GraphKey& o) const { return tie() < o.tie(); }
@@ -1169,17 +1169,17 @@ extern "C" size_t fd_enhance_normfac_offset(const fd_model* m, int B, int L) {
   return 2 * fd_align(sizeof(float) * 2 * (size_t)B * m->n_freq * Tp);
 }
 
-extern "C" int fd_enhance(fd_model* m, const float* y, const float* noise, float sigma_fac, int N, int solver, float* x_hat, int B, int L, void* ws,
-                          size_t ws_bytes, int use_graph, void* stream) {
-  FD_MODEL_ENTER(m, "fd_enhance");
+namespace {
+int enhance_impl(fd_model* m, const char* who, const float* y, const int* lens, const float* noise, float sigma_fac, int N, int solver, float* x_hat, int B,
+                 int L, void* ws, size_t ws_bytes, int use_graph, void* stream) {
   FD_TRY(check_ready(m));
-  FD_REQUIRE(y && noise && x_hat && ws, "fd_enhance: null pointer");
-  FD_REQUIRE(N >= 1 && solver_nfe(solver, N) > 0, "fd_enhance: bad N / solver");
-  FD_REQUIRE(B > 0 && L > m->cfg.n_fft / 2, "fd_enhance: clips must be longer than %d samples", m->cfg.n_fft / 2);
+  FD_REQUIRE(y && noise && x_hat && ws, "%s: null pointer", who);
+  FD_REQUIRE(N >= 1 && solver_nfe(solver, N) > 0, "%s: bad N / solver", who);
+  FD_REQUIRE(B > 0 && L > m->cfg.n_fft / 2, "%s: clips must be longer than %d samples", who, m->cfg.n_fft / 2);
   const int T = 1 + L / m->cfg.hop, Tp = fd_padded_frames(T);
   FD_TRY(check_shape(m, B, Tp));
   const size_t need = fd_enhance_workspace_bytes(m, B, L);
-  if (ws_bytes < need) return fd_set_error(FD_ENOMEM, "fd_enhance: workspace %zu < required %zu bytes", ws_bytes, need);
+  if (ws_bytes < need) return fd_set_error(FD_ENOMEM, "%s: workspace %zu < required %zu bytes", who, ws_bytes, need);
   hipStream_t st = fd_stream(stream);
   const size_t state = fd_align(sizeof(float) * 2 * (size_t)B * m->n_freq * Tp);
   float* Y = (float*)ws;
@@ -1187,14 +1187,35 @@ extern "C" int fd_enhance(fd_model* m, const float* y, const float* noise, float
   float* normfac = (float*)((char*)ws + 2 * state);
   char* rest = (char*)ws + 2 * state + fd_align(sizeof(float) * B);
   const size_t rest_bytes = ws_bytes - (2 * state + fd_align(sizeof(float) * B));
-  GraphKey key; key.y = y; key.noise = noise; key.xhat = x_hat; key.ws = ws; key.B = B; key.L = L; key.N = N; key.solver = solver; key.kind = 2;
+  GraphKey key; key.y = y; key.noise = noise; key.xhat = x_hat; key.ws = ws; key.lens = lens; key.B = B; key.L = L; key.N = N; key.solver = solver; key.kind = 2;
   key.sigma_fac = sigma_fac; key.normalize = m->normalize;
   return run_maybe_graph(m, key, use_graph != 0, st, [&]() {
-    FD_TRY(fd_stft_forward(m->stft, y, B, L, m->cfg.alpha, m->cfg.beta, m->normalize, normfac, Y, Tp, rest, rest_bytes, st));
+    FD_TRY(fd_stft_forward(m->stft, y, lens, B, L, m->cfg.alpha, m->cfg.beta, m->normalize, normfac, Y, Tp, rest, rest_bytes, st));
     FD_TRY(ode_enqueue(m, Y, noise, sigma_fac, N, solver, X, nullptr, B, Tp, rest, rest_bytes, st));
-    FD_TRY(fd_stft_inverse(m->stft, X, B, T, Tp, m->cfg.alpha, m->cfg.beta, normfac, x_hat, L, rest, rest_bytes, st));
+    FD_TRY(fd_stft_inverse(m->stft, X, lens, B, T, Tp, m->cfg.alpha, m->cfg.beta, normfac, x_hat, L, rest, rest_bytes, st));
     return FD_OK;
   });
+}
+}  // namespace
+
+extern "C" int fd_enhance(fd_model* m, const float* y, const float* noise, float sigma_fac, int N, int solver, float* x_hat, int B, int L, void* ws,
+                          size_t ws_bytes, int use_graph, void* stream) {
+  FD_MODEL_ENTER(m, "fd_enhance");
+  return enhance_impl(m, "fd_enhance", y, nullptr, noise, sigma_fac, N, solver, x_hat, B, L, ws, ws_bytes, use_graph, stream);
+}
+
+// FlowModel.enhance on a RAGGED batch: the reference's driver enhances a directory file by file (enhance.py:96-137), every file its
+// own length; here the files whose spectrograms pad to the same T_pad (util/other.py:25-52) run as ONE batch.  y / x_hat are [B][L]
+// rows (L = the longest clip; workspace as for fd_enhance(B, L)), lengths (device int32 [B]) the clips' own sample counts -- the
+// CALLER guarantees fd_padded_frames(fd_num_frames(lengths[b])) == fd_padded_frames(fd_num_frames(L)) for every b (the kernels
+// clamp a length into (n_fft/2, L]).  Clip b's result is bit-identical to fd_enhance on that clip alone with the same noise
+// (noise is [B][1][F][T_pad] as usual); samples [lengths[b], L) of a row of x_hat are zero.  The hipGraph of a (B, L) bucket is
+// keyed on the POINTER `lengths`: its contents may change between replays.
+extern "C" int fd_enhance_ragged(fd_model* m, const float* y, const int* lengths, const float* noise, float sigma_fac, int N, int solver,
+                                 float* x_hat, int B, int L, void* ws, size_t ws_bytes, int use_graph, void* stream) {
+  FD_MODEL_ENTER(m, "fd_enhance_ragged");
+  FD_REQUIRE(lengths, "fd_enhance_ragged: null lengths");
+  return enhance_impl(m, "fd_enhance_ragged", y, lengths, noise, sigma_fac, N, solver, x_hat, B, L, ws, ws_bytes, use_graph, stream);
 }
 
 // Shared front end / back end of the three enhancement models:  STFT -> body(Y, X) -> iSTFT
@@ -1217,9 +1238,9 @@ static int enhance_common(fd_model* m, const char* who, const float* y, float* x
   const size_t rest_bytes = ws_bytes - (2 * state + fd_align(sizeof(float) * B));
   key.y = y; key.xhat = x_hat; key.ws = ws; key.B = B; key.L = L; key.normalize = m->normalize;
   return run_maybe_graph(m, key, use_graph != 0, st, [&]() {
-    FD_TRY(fd_stft_forward(m->stft, y, B, L, m->cfg.alpha, m->cfg.beta, m->normalize, normfac, Y, Tp, rest, rest_bytes, st));
+    FD_TRY(fd_stft_forward(m->stft, y, nullptr, B, L, m->cfg.alpha, m->cfg.beta, m->normalize, normfac, Y, Tp, rest, rest_bytes, st));
     FD_TRY(body(Y, X, Tp, (void*)rest, rest_bytes, st));
-    FD_TRY(fd_stft_inverse(m->stft, X, B, T, Tp, m->cfg.alpha, m->cfg.beta, normfac, x_hat, L, rest, rest_bytes, st));
+    FD_TRY(fd_stft_inverse(m->stft, X, nullptr, B, T, Tp, m->cfg.alpha, m->cfg.beta, normfac, x_hat, L, rest, rest_bytes, st));
     return FD_OK;
   });
 }

@@ -31,12 +31,25 @@ struct fd_stft_plan {
 
 namespace {
 
+// Ragged batches (fd_*_ragged): `lens` (device int32 [B], may be null) holds every clip's own sample count; clip b then occupies
+// the first lens[b] samples of its row of L (= the longest clip's length) and has its own frame count 1 + lens[b] / hop.  Every
+// kernel below does for clip b exactly the arithmetic it would do in a call with that clip alone (same reflect padding, same
+// frames, same overlap-add envelope), so a clip's output does not depend on its neighbours.  The value is clamped into what the
+// buffers hold: a wrong length can give a wrong waveform, never an out-of-bounds access.
+__device__ __forceinline__ int clip_len(const int* __restrict__ lens, int b, int L, int n_fft) {
+  if (!lens) return L;
+  const int l = lens[b], lo = n_fft / 2 + 1;
+  return l < lo ? lo : (l > L ? L : l);
+}
+
 // per-clip max |y| -> normfac (isclose(normfac, 0) -> 1), one block per clip
-__global__ __launch_bounds__(1024) void absmax_kernel(const float* __restrict__ y, int L, int normalize, float* __restrict__ normfac) {
+__global__ __launch_bounds__(1024) void absmax_kernel(const float* __restrict__ y, const int* __restrict__ lens, int L, int n_fft, int normalize,
+                                                      float* __restrict__ normfac) {
   const int b = blockIdx.x;
+  const int Lb = clip_len(lens, b, L, n_fft);
   float m = 0.f;
   if (normalize)
-    for (int i = threadIdx.x; i < L; i += 1024) m = fmaxf(m, fabsf(y[(size_t)b * L + i]));
+    for (int i = threadIdx.x; i < Lb; i += 1024) m = fmaxf(m, fabsf(y[(size_t)b * L + i]));
   m = fd_wave_max(m);
   __shared__ float red[16];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -49,8 +62,9 @@ __global__ __launch_bounds__(1024) void absmax_kernel(const float* __restrict__ 
   }
 }
 
-// frames[b*T + t][k] = y[b][reflect(hop*t + k - n_fft/2)] / normfac[b]; columns >= n_fft are zero
-__global__ void frame_kernel(const float* __restrict__ y, const float* __restrict__ normfac, float* __restrict__ frames, int B,
+// frames[b*T + t][k] = y[b][reflect(hop*t + k - n_fft/2)] / normfac[b]; columns >= n_fft are zero (ragged: also the frames a
+// shorter clip does not have)
+__global__ void frame_kernel(const float* __restrict__ y, const int* __restrict__ lens, const float* __restrict__ normfac, float* __restrict__ frames, int B,
                              int L, int T, int n_fft, int hop, int kpad) {
   const long long total = (long long)B * T * kpad;
   const int pad = n_fft / 2;
@@ -58,11 +72,12 @@ __global__ void frame_kernel(const float* __restrict__ y, const float* __restric
     const int k = (int)(i % kpad);
     const long long fr = i / kpad;
     const int t = (int)(fr % T), b = (int)(fr / T);
+    const int Lb = clip_len(lens, b, L, n_fft);
     float v = 0.f;
-    if (k < n_fft) {
+    if (k < n_fft && t < 1 + Lb / hop) {
       int s = hop * t + k - pad;
       s = s < 0 ? -s : s;
-      s = s >= L ? 2 * (L - 1) - s : s;
+      s = s >= Lb ? 2 * (Lb - 1) - s : s;
       v = y[(size_t)b * L + s] / normfac[b];
     }
     frames[i] = v;
@@ -156,15 +171,15 @@ static void launch_sgemm(const float* A, const float* Bm, float* C, int M, int N
 }
 
 // spec[b*T+t][2f,2f+1] -> Y[b][f][t] = beta * |X|^alpha * exp(j angle X); frames t >= T are zero padding
-__global__ void compress_kernel(const float* __restrict__ spec, float2* __restrict__ Y, int B, int F, int T, int T_pad, int kpad,
-                                float alpha, float beta) {
+__global__ void compress_kernel(const float* __restrict__ spec, const int* __restrict__ lens, float2* __restrict__ Y, int B, int F, int T, int T_pad,
+                                int kpad, int L, int n_fft, int hop, float alpha, float beta) {
   const long long total = (long long)B * F * T_pad;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int t = (int)(i % T_pad);
     const long long r = i / T_pad;
     const int f = (int)(r % F), b = (int)(r / F);
     float2 o = {0.f, 0.f};
-    if (t < T) {
+    if (t < (lens ? 1 + clip_len(lens, b, L, n_fft) / hop : T)) {
       const float2 x = *reinterpret_cast<const float2*>(spec + ((size_t)b * T + t) * kpad + 2 * f);
       float re = x.x, im = x.y;
       if (alpha != 1.0f) {
@@ -181,8 +196,8 @@ __global__ void compress_kernel(const float* __restrict__ spec, float2* __restri
 }
 
 // X[b][f][t] (t < T) -> Z[b*T+t][2f,2f+1] = |X/beta|^(1/alpha) exp(j angle(X/beta))
-__global__ void decompress_kernel(const float2* __restrict__ X, float* __restrict__ Z, int B, int F, int T, int T_pad, int kpad,
-                                  float alpha, float beta) {
+__global__ void decompress_kernel(const float2* __restrict__ X, const int* __restrict__ lens, float* __restrict__ Z, int B, int F, int T, int T_pad,
+                                  int kpad, int L, int n_fft, int hop, float alpha, float beta) {
   const long long total = (long long)B * T * (kpad / 2);
   const float inv_alpha = 1.0f / alpha;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -190,7 +205,7 @@ __global__ void decompress_kernel(const float2* __restrict__ X, float* __restric
     const long long fr = i / (kpad / 2);
     const int t = (int)(fr % T), b = (int)(fr / T);
     float2 o = {0.f, 0.f};
-    if (f < F) {
+    if (f < F && (!lens || t < 1 + clip_len(lens, b, L, n_fft) / hop)) {
       const float2 x = X[((size_t)b * F + f) * T_pad + t];
       float re = x.x / beta, im = x.y / beta;
       if (alpha != 1.0f) {
@@ -208,16 +223,18 @@ __global__ void decompress_kernel(const float2* __restrict__ X, float* __restric
 
 // y[b][s] = normfac[b] * (sum_t FR[b*T+t][s + n_fft/2 - hop*t]) / (sum_t w^2[...]),  s < L; beyond the
 // synthesised length the output is zero (torch.istft pads with zeros)
-__global__ void overlap_add_kernel(const float* __restrict__ FR, const float* __restrict__ w2, const float* __restrict__ normfac,
-                                   float* __restrict__ y, int B, int T, int L, int n_fft, int hop, int kpad) {
+__global__ void overlap_add_kernel(const float* __restrict__ FR, const int* __restrict__ lens, const float* __restrict__ w2,
+                                   const float* __restrict__ normfac, float* __restrict__ y, int B, int T, int L, int n_fft, int hop, int kpad) {
   const long long total = (long long)B * L;
-  const int total_len = n_fft + hop * (T - 1);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int s = (int)(i % L), b = (int)(i / L);
+    // ragged: clip b was synthesised from ITS frame count (torch.istft(length = its own length)); the row's tail stays zero
+    const int Lb = clip_len(lens, b, L, n_fft), Tb = lens ? 1 + Lb / hop : T;
+    const int total_len = n_fft + hop * (Tb - 1);
     const int p = s + n_fft / 2;
     float o = 0.f;
-    if (p < total_len) {
-      int t_hi = p / hop; if (t_hi > T - 1) t_hi = T - 1;
+    if (p < total_len && s < Lb) {
+      int t_hi = p / hop; if (t_hi > Tb - 1) t_hi = Tb - 1;
       int t_lo = (p - (n_fft - 1) + hop - 1) / hop; if (t_lo < 0) t_lo = 0;
       float acc = 0.f, env = 0.f;
       for (int t = t_lo; t <= t_hi; ++t) {
@@ -309,7 +326,7 @@ size_t fd_stft_ws_bytes(int B, int L, int n_fft, int hop) {
   return 2 * fd_align(sizeof(float) * (size_t)B * T * kpad) + 256;
 }
 
-int fd_stft_forward(fd_stft_plan* p, const float* y, int B, int L, float alpha, float beta, int normalize, float* normfac, float* Y,
+int fd_stft_forward(fd_stft_plan* p, const float* y, const int* lens, int B, int L, float alpha, float beta, int normalize, float* normfac, float* Y,
                     int T_pad, void* ws, size_t ws_bytes, hipStream_t st) {
   const int T = 1 + L / p->hop, K = p->kpad;
   FD_REQUIRE(L > p->n_fft / 2, "stft: clip of %d samples is too short for reflect padding of %d", L, p->n_fft / 2);
@@ -320,20 +337,20 @@ int fd_stft_forward(fd_stft_plan* p, const float* y, int B, int L, float alpha, 
   const int M = B * T;
   auto mark = [&](int i) { if (p->prof) (void)hipEventRecord(p->ev[i], st); };
   mark(0);
-  hipLaunchKernelGGL(absmax_kernel, dim3(B), dim3(1024), 0, st, y, L, normalize, normfac);
-  hipLaunchKernelGGL(frame_kernel, dim3(grid_cap((long long)M * K)), dim3(256), 0, st, y, normfac, frames, B, L, T, p->n_fft, p->hop, K);
+  hipLaunchKernelGGL(absmax_kernel, dim3(B), dim3(1024), 0, st, y, lens, L, p->n_fft, normalize, normfac);
+  hipLaunchKernelGGL(frame_kernel, dim3(grid_cap((long long)M * K)), dim3(256), 0, st, y, lens, normfac, frames, B, L, T, p->n_fft, p->hop, K);
   mark(1);
   launch_sgemm(frames, p->Dt, spec, M, K, K, st);
   mark(2);
-  hipLaunchKernelGGL(compress_kernel, dim3(grid_cap((long long)B * p->n_freq * T_pad)), dim3(256), 0, st, spec, (float2*)Y, B, p->n_freq, T,
-                     T_pad, K, alpha, beta);
+  hipLaunchKernelGGL(compress_kernel, dim3(grid_cap((long long)B * p->n_freq * T_pad)), dim3(256), 0, st, spec, lens, (float2*)Y, B, p->n_freq, T,
+                     T_pad, K, L, p->n_fft, p->hop, alpha, beta);
   mark(3);
   if (p->prof) ++p->calls[0];
   FD_LAUNCH_CHECK();
   return FD_OK;
 }
 
-int fd_stft_inverse(fd_stft_plan* p, const float* X, int B, int T, int T_pad, float alpha, float beta, const float* normfac, float* y,
+int fd_stft_inverse(fd_stft_plan* p, const float* X, const int* lens, int B, int T, int T_pad, float alpha, float beta, const float* normfac, float* y,
                     int L, void* ws, size_t ws_bytes, hipStream_t st) {
   const int K = p->kpad;
   FD_REQUIRE(T >= 1 && T_pad >= T, "istft: bad frame counts");
@@ -344,12 +361,12 @@ int fd_stft_inverse(fd_stft_plan* p, const float* X, int B, int T, int T_pad, fl
   const int M = B * T;
   auto mark = [&](int i) { if (p->prof) (void)hipEventRecord(p->ev[i], st); };
   mark(4);
-  hipLaunchKernelGGL(decompress_kernel, dim3(grid_cap((long long)M * (K / 2))), dim3(256), 0, st, (const float2*)X, Z, B, p->n_freq, T, T_pad, K,
-                     alpha, beta);
+  hipLaunchKernelGGL(decompress_kernel, dim3(grid_cap((long long)M * (K / 2))), dim3(256), 0, st, (const float2*)X, lens, Z, B, p->n_freq, T, T_pad, K,
+                     L, p->n_fft, p->hop, alpha, beta);
   mark(5);
   launch_sgemm(Z, p->E, FR, M, K, K, st);
   mark(6);
-  hipLaunchKernelGGL(overlap_add_kernel, dim3(grid_cap((long long)B * L)), dim3(256), 0, st, FR, p->w2, normfac, y, B, T, L, p->n_fft, p->hop, K);
+  hipLaunchKernelGGL(overlap_add_kernel, dim3(grid_cap((long long)B * L)), dim3(256), 0, st, FR, lens, p->w2, normfac, y, B, T, L, p->n_fft, p->hop, K);
   mark(7);
   if (p->prof) ++p->calls[1];
   FD_LAUNCH_CHECK();
@@ -390,11 +407,28 @@ extern "C" int fd_padded_frames(int T) { return (T % 64 == 0) ? T : T + (64 - T 
 extern "C" int fd_stft_compress(const fd_stft_plan* plan, const float* y, int B, int L, float alpha, float beta, int normalize,
                                 float* normfac, float* Y, int T_pad, void* ws, size_t ws_bytes, void* stream) {
   FD_REQUIRE(plan && y && normfac && Y && ws && B > 0 && L > 0, "fd_stft_compress: bad arguments");
-  return fd_stft_forward(const_cast<fd_stft_plan*>(plan), y, B, L, alpha, beta, normalize, normfac, Y, T_pad, ws, ws_bytes, fd_stream(stream));
+  return fd_stft_forward(const_cast<fd_stft_plan*>(plan), y, nullptr, B, L, alpha, beta, normalize, normfac, Y, T_pad, ws, ws_bytes, fd_stream(stream));
+}
+
+// Ragged batch: clip b holds lengths[b] samples (device int32 [B]; n_fft/2 < lengths[b] <= L) in its row of L; its frames
+// t >= 1 + lengths[b]/hop are zero, as pad_spec leaves them (util/other.py:25-52).  Bit-identical per clip to a call with that clip alone.
+extern "C" int fd_stft_compress_ragged(const fd_stft_plan* plan, const float* y, const int* lengths, int B, int L, float alpha, float beta,
+                                       int normalize, float* normfac, float* Y, int T_pad, void* ws, size_t ws_bytes, void* stream) {
+  FD_REQUIRE(plan && y && lengths && normfac && Y && ws && B > 0 && L > 0, "fd_stft_compress_ragged: bad arguments");
+  return fd_stft_forward(const_cast<fd_stft_plan*>(plan), y, lengths, B, L, alpha, beta, normalize, normfac, Y, T_pad, ws, ws_bytes, fd_stream(stream));
 }
 
 extern "C" int fd_decompress_istft(const fd_stft_plan* plan, const float* X, int B, int T, int T_pad, float alpha, float beta,
                                    const float* normfac, float* y, int L, void* ws, size_t ws_bytes, void* stream) {
   FD_REQUIRE(plan && X && y && ws && B > 0 && L > 0, "fd_decompress_istft: bad arguments");
-  return fd_stft_inverse(const_cast<fd_stft_plan*>(plan), X, B, T, T_pad, alpha, beta, normfac, y, L, ws, ws_bytes, fd_stream(stream));
+  return fd_stft_inverse(const_cast<fd_stft_plan*>(plan), X, nullptr, B, T, T_pad, alpha, beta, normfac, y, L, ws, ws_bytes, fd_stream(stream));
+}
+
+// Ragged batch: T = frames of the LONGEST clip (1 + L/hop); clip b is synthesised from its own 1 + lengths[b]/hop frames with
+// torch.istft(length = lengths[b]) semantics, samples [lengths[b], L) of its row are zero.
+extern "C" int fd_decompress_istft_ragged(const fd_stft_plan* plan, const float* X, const int* lengths, int B, int T, int T_pad, float alpha,
+                                          float beta, const float* normfac, float* y, int L, void* ws, size_t ws_bytes, void* stream) {
+  FD_REQUIRE(plan && X && lengths && y && ws && B > 0 && L > 0, "fd_decompress_istft_ragged: bad arguments");
+  FD_REQUIRE(T == 1 + L / plan->hop, "fd_decompress_istft_ragged: T must be the frame count of the row length L (1 + L / hop = %d, got %d)", 1 + L / plan->hop, T);
+  return fd_stft_inverse(const_cast<fd_stft_plan*>(plan), X, lengths, B, T, T_pad, alpha, beta, normfac, y, L, ws, ws_bytes, fd_stream(stream));
 }

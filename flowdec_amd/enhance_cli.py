@@ -14,6 +14,13 @@ selects the EMA weights exactly like `demo.ipynb` cell 2.
 Non-48 kHz input is resampled with a restatement of torchaudio.functional.resample(..., lowpass_filter_width=64)
 (enhance.py:118; torchaudio itself is not a dependency): `sinc_resample_kernel` / `resample` below.
 
+Batching (round 6): the reference enhances one file per call (enhance.py:96-137).  This driver reads the lengths first, buckets the
+files by the frame count their spectrogram pads to (T_pad, util/other.py:25-52) and runs up to `--batch-files` files of a bucket as
+ONE ragged native call (FlowModel.enhance_batch -> fd_enhance_ragged): every file's waveform is bit-identical to the one-file call,
+the GPU sees a batch.  With `--seed S` file i of the work list draws its noise from its own generator seeded S + i, so the result
+of a file does not depend on the batching (`--batch-files 1` = the reference's loop).  Under `--rtf` a batch is timed as a whole and
+its time is split over its files in proportion to their duration (every file of a batch gets the batch's rtf).
+
 Length limit: the reference skips files longer than 30 s; so does this driver, in every precision (one image of the conv kernels
 must stay below 2 GiB in bf16 and below 4 GiB with f32 storage -- 32-bit byte offsets inside an image -- both ~43 s of audio).
 `PRECISION_MAX_SECONDS` is where a precision with a shorter reach would say so: such files are then skipped WITH a message and
@@ -110,6 +117,21 @@ def load_wav(path: str) -> Tuple[torch.Tensor, int]:
     if x.ndim == 1:
         x = x[:, None]
     return torch.from_numpy(np.ascontiguousarray(x.T)), int(sr)
+
+
+def wav_info(path: str) -> Tuple[int, int, int]:
+    """-> (samples per channel, sampling rate, channels) from the header only (memory-mapped: the data is not read)."""
+    from scipy.io import wavfile
+    sr, data = wavfile.read(path, mmap=True)
+    return int(data.shape[0]), int(sr), (1 if data.ndim == 1 else int(data.shape[1]))
+
+
+def resampled_length(length: int, sr: int, target: int) -> int:
+    """Samples `resample` returns for `length` input samples: ceil(n * L / o) with o, n = sr, target over their gcd."""
+    if int(sr) == int(target):
+        return int(length)
+    g = math.gcd(int(sr), int(target))
+    return int(math.ceil((int(target) // g) * length / (int(sr) // g)))
 
 
 def save_wav(path: str, x: torch.Tensor, sr: int) -> None:
@@ -254,7 +276,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--i-max", type=int, default=None)
     p.add_argument("--rtf", action="store_true")
     p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32", "mixed", "bf16x3"])
-    p.add_argument("--seed", type=int, default=None, help="seed of the initial-noise generator (default: nondeterministic like the reference)")
+    p.add_argument("--seed", type=int, default=None, help="file i of the work list draws its initial noise from a generator seeded SEED + i "
+                                                          "(default: nondeterministic like the reference)")
+    p.add_argument("--batch-files", type=int, default=8, help="files of one T_pad bucket per native call (1 = one file per call, the reference's loop)")
     return p
 
 
@@ -275,6 +299,8 @@ class RunResult:
     n_done: int = 0
     n_over_precision_limit: int = 0
     n_too_long: int = 0
+    gpu_seconds: float = 0.0      # --rtf: GPU time and audio duration over the files enhanced in this run
+    audio_seconds: float = 0.0
 
     @property
     def exit_code(self) -> int:
@@ -327,16 +353,23 @@ class GpuTimer:
 
 class RunLog:
     """The two side files of a run, in the reference's FORMATS (enhance.py:94,135,143): `rtfs{suffix}.csv` with the header
-    path,runtime,filetime,rtf (--rtf) and `triples_list{suffix}.txt` with `clean ---> noisy ---> enhanced` lines (pair lists)."""
+    path,runtime,filetime,rtf (--rtf) and `triples_list{suffix}.txt` with `clean ---> noisy ---> enhanced` lines (pair lists).
+    The files are opened on __enter__ (a failing second open closes the first)."""
 
     def __init__(self, outdir: str, suffix: str, want_rtf: bool, want_triples: bool):
+        self._paths = (os.path.join(outdir, f"rtfs{suffix}.csv") if want_rtf else None,
+                       os.path.join(outdir, f"triples_list{suffix}.txt") if want_triples else None)
         self._stack = contextlib.ExitStack()
-        self._rtf = self._stack.enter_context(open(os.path.join(outdir, f"rtfs{suffix}.csv"), "w")) if want_rtf else None
-        self._tri = self._stack.enter_context(open(os.path.join(outdir, f"triples_list{suffix}.txt"), "w")) if want_triples else None
-        if self._rtf:
-            print("path,runtime,filetime,rtf", file=self._rtf)
+        self._rtf = self._tri = None
+        self.runtime = self.filetime = 0.0
 
     def __enter__(self):
+        with contextlib.ExitStack() as guard:
+            self._rtf = guard.enter_context(open(self._paths[0], "w")) if self._paths[0] else None
+            self._tri = guard.enter_context(open(self._paths[1], "w")) if self._paths[1] else None
+            self._stack = guard.pop_all()
+        if self._rtf:
+            print("path,runtime,filetime,rtf", file=self._rtf)
         return self
 
     def __exit__(self, *exc):
@@ -344,6 +377,8 @@ class RunLog:
 
     def rtf(self, dst: str, runtime: float, filetime: float):
         print(runtime, filetime, "-> rtf =", runtime / filetime)
+        self.runtime += runtime
+        self.filetime += filetime
         if self._rtf:
             print(f"{dst},{runtime:.5f},{filetime:.5f},{runtime / filetime:.5f}", file=self._rtf)
 
@@ -352,30 +387,85 @@ class RunLog:
             print(f"{job.clean} ---> {job.src} ---> {job.dst}", file=self._tri)
 
 
-def enhance_file(model: FlowModel, job: FileJob, args, gen, log: RunLog, res: RunResult, max_seconds: float) -> None:
-    """Load -> length rules -> resample to the model rate -> enhance (timed under --rtf) -> save.  Updates `res`."""
+def file_generator(model: FlowModel, seed: Optional[int], index: int):
+    """The noise generator of file `index` of the work list: seeded SEED + index, so that a file's result does not depend on which
+    files share its batch; None (the global device RNG, like the reference: model.py:512) without --seed."""
+    return None if seed is None else torch.Generator(device=model.device).manual_seed(int(seed) + int(index))
+
+
+def load_for_model(model: FlowModel, job: FileJob, res: RunResult, max_seconds: float, precision: str):
+    """Load -> the reference's length rule (enhance.py:115,139) -> resample to the model rate.  -> waveform [C, L] or None (skipped)."""
     y, sr = load_wav(job.src)
     seconds = y.shape[-1] / sr
     if seconds > MAX_SECONDS:
         res.n_too_long += 1
         print("Skipping file due to length:", job.src)
-        return
+        return None
     if seconds > max_seconds:
         res.n_over_precision_limit += 1
-        print(f"Skipping file: {seconds:.1f} s exceeds the {max_seconds:g} s limit of precision={args.precision} "
+        print(f"Skipping file: {seconds:.1f} s exceeds the {max_seconds:g} s limit of precision={precision} "
               f"(the reference's limit is {MAX_SECONDS:g} s; use --precision bf16 for files up to it):", job.src)
-        return
+        return None
     if sr != model.sampling_rate:
         print("RESAMPLING from", sr, "to", model.sampling_rate)
-        y, sr = resample(y, sr, model.sampling_rate), model.sampling_rate
+        y = resample(y, sr, model.sampling_rate)
+    return y
+
+
+def enhance_file(model: FlowModel, job: FileJob, args, log: RunLog, res: RunResult, max_seconds: float) -> None:
+    """One file per native call (the reference's loop): load -> enhance (timed under --rtf) -> save.  Updates `res`."""
+    y = load_for_model(model, job, res, max_seconds, args.precision)
+    if y is None:
+        return
+    sr = model.sampling_rate
     # use_graph=False: every file has its own length, and a replay would not be faster anyway -- a one-clip solve is bound by the GPU,
     # not by the host's launches (profiles/r02_graph_cost.txt: eager 18.06 ms, replay 18.10 ms; capture + instantiate 2.4 ms)
     with GpuTimer(args.rtf) as timer:
-        x_hat = model.enhance(y, N=args.N, solver=args.solver, generator=gen, use_graph=False)
+        x_hat = model.enhance(y, N=args.N, solver=args.solver, generator=file_generator(model, args.seed, job.index), use_graph=False)
     if timer.seconds is not None:
         log.rtf(job.dst, timer.seconds, y.shape[-1] / sr)
     save_wav(job.dst, x_hat.cpu(), sr)
     res.n_done += 1
+
+
+def plan_batches(model: FlowModel, jobs: List[FileJob], batch_files: int):
+    """Buckets the pending jobs by the frame count their spectrogram pads to (from the wav HEADERS: nothing is decoded here) and cuts
+    every bucket into batches of at most `batch_files` files, in work-list order.  Multi-channel files, unreadable headers and files
+    the length rule will skip go through the one-file path (their own messages).  -> list of lists of FileJob."""
+    from .model import padded_frames_of
+    hop = model.feature_extractor._cfg()["hop"]
+    buckets, singles = {}, []
+    for job in jobs:
+        try:
+            n, sr, channels = wav_info(job.src)
+        except Exception:   # an unreadable file fails in its own one-file call, with the reference's behaviour (an exception)
+            singles.append([job]); continue
+        if channels != 1 or n / sr > MAX_SECONDS or batch_files <= 1:
+            singles.append([job]); continue
+        buckets.setdefault(padded_frames_of(resampled_length(n, sr, model.sampling_rate), hop), []).append(job)
+    batches = []
+    for tp in sorted(buckets):
+        group = buckets[tp]
+        batches += [group[i:i + batch_files] for i in range(0, len(group), batch_files)]
+    return batches + singles
+
+
+def enhance_batch_files(model: FlowModel, batch: List[FileJob], args, log: RunLog, res: RunResult, max_seconds: float) -> None:
+    """One ragged native call for the files of `batch` (same T_pad bucket).  Every output equals the one-file call bit for bit."""
+    loaded = [(job, load_for_model(model, job, res, max_seconds, args.precision)) for job in batch]
+    loaded = [(job, y) for job, y in loaded if y is not None]
+    if not loaded:
+        return
+    sr = model.sampling_rate
+    gens = [file_generator(model, args.seed, job.index) for job, _ in loaded]
+    with GpuTimer(args.rtf) as timer:
+        outs = model.enhance_batch([y for _, y in loaded], N=args.N, solver=args.solver, generator=gens)
+    total = sum(y.shape[-1] for _, y in loaded) / sr
+    for (job, y), x_hat in zip(loaded, outs):
+        if timer.seconds is not None:   # the batch's time, split in proportion to the files' durations
+            log.rtf(job.dst, timer.seconds * (y.shape[-1] / sr) / total, y.shape[-1] / sr)
+        save_wav(job.dst, x_hat.cpu(), sr)
+        res.n_done += 1
 
 
 def main(argv=None, model: Optional[FlowModel] = None) -> int:
@@ -396,16 +486,25 @@ def run(argv=None, model: Optional[FlowModel] = None) -> RunResult:
         model = load_from_checkpoint(args.ckpt, map_location=args.device, ema=args.ema, precision=args.precision)
         print("Done loading model.")
     noisy, clean = collect_files(args.files, args.single_file)
-    gen = torch.Generator(device=model.device).manual_seed(args.seed) if args.seed is not None else None
     max_seconds = min(MAX_SECONDS, PRECISION_MAX_SECONDS.get(args.precision, MAX_SECONDS))
-    print(f"flowdec_amd: precision={args.precision} ({PRECISION_NOTE[args.precision]}), solver={args.solver}, N={args.N}")
+    print(f"flowdec_amd: precision={args.precision} ({PRECISION_NOTE[args.precision]}), solver={args.solver}, N={args.N}, "
+          f"files per native call <= {max(args.batch_files, 1)}")
     res = RunResult()
     suffix = f"_{args.i_min}-{args.i_max}" if args.i_max else ""
+    jobs = list(plan_jobs(noisy, clean, args.outdir, args.i_min, args.i_max, args.skip_existing, args.exclude_files_matching))
+    batchable = args.solver in ("euler", "midpoint", "heun2", "heun2_eulerlast")   # (the adaptive solvers step clip by clip)
     with RunLog(args.outdir, suffix, want_rtf=args.rtf, want_triples=clean is not None) as log:
-        for job in plan_jobs(noisy, clean, args.outdir, args.i_min, args.i_max, args.skip_existing, args.exclude_files_matching):
-            if job.pending:
-                enhance_file(model, job, args, gen, log, res, max_seconds)
+        for batch in plan_batches(model, [j for j in jobs if j.pending], args.batch_files if batchable else 1):
+            if len(batch) == 1:
+                enhance_file(model, batch[0], args, log, res, max_seconds)
+            else:
+                enhance_batch_files(model, batch, args, log, res, max_seconds)
+        for job in jobs:      # the pair list names every file of the window, enhanced now or found existing (enhance.py:143)
             log.triple(job)
+        if args.rtf and log.runtime > 0:
+            print(f"total: {log.filetime:.2f} s of audio in {log.runtime:.3f} s of GPU time -> rtf = {log.runtime / log.filetime:.5f} "
+                  f"({log.filetime / log.runtime:.1f} x real time)")
+    res.gpu_seconds, res.audio_seconds = log.runtime, log.filetime
     return res
 
 

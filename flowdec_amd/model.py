@@ -429,6 +429,12 @@ def sigma_y_from_file(filename: str, factor: float = 1.0, kernel_bandwidth: Opti
     return factor * torch.from_numpy(curve).unsqueeze(-1)
 
 
+def padded_frames_of(num_samples: int, hop: int = 384) -> int:
+    """T_pad of a clip of `num_samples` samples: pad_spec(1 + L // hop) (util/other.py:25-52) -- the bucket key of `enhance_batch`."""
+    lib = L.load()
+    return int(lib.fd_padded_frames(lib.fd_num_frames(int(num_samples), int(hop))))
+
+
 def _info_from_ws(lib, h, ws, B, Lw, T, squeeze_dims):
     """preprocess_info of the reference (model.py:161-162); normfac is read where fd_enhance's front end left it."""
     off = lib.fd_enhance_normfac_offset(h, B, Lw)
@@ -609,6 +615,78 @@ class FlowModel(nn.Module):
             x_hat = x_hat.squeeze(0)
         x_hat = x_hat.to(orig_device)
         return (x_hat, info) if return_preprocess_info else x_hat
+
+    @torch.no_grad()
+    @_serialized
+    def enhance_batch(self, clips, N: int = 50, solver: str = "euler", sigma_fac: float = 1.0, noise=None, generator=None,
+                      use_graph: bool = True):
+        """`[self.enhance(c, N=N, solver=solver) for c in clips]` as ONE native call (fd_enhance_ragged) for clips of DIFFERENT
+        lengths whose spectrograms pad to the same T_pad -- what the reference's driver does file by file (enhance.py:96-137).
+
+        clips: sequence of waveforms [L_i], [1, L_i] or [1, 1, L_i].  Returns a list of tensors, each with the shape and on the
+        device of its input.  Every clip's result is BIT-IDENTICAL to `self.enhance(clip)` with the same noise: per-clip
+        normalisation, reflect padding, frame count, zero padding of the frame axis, iSTFT length (model.py:129-190); the network
+        itself never mixes batch items.  Initial noise: `noise` = one [1, 1, F, T_pad] complex tensor per clip, or `generator` =
+        one torch.Generator (drawn clip by clip, i.e. the stream a one-by-one loop would consume) or a list of one per clip."""
+        if solver not in L.SOLVERS:
+            raise ValueError(f"enhance_batch: fixed-step solvers only ({sorted(L.SOLVERS)}), got {solver!r}")
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("flowdec_amd: move the model to the GPU first (`model.cuda()`)")
+        clips = list(clips)
+        if not clips:
+            return []
+        lib = L.load()
+        h = self._sync_native()
+        cfg = self.feature_extractor._cfg()
+        hop, F = cfg["hop"], cfg["n_fft"] // 2 + 1
+        flat = []
+        for i, c in enumerate(clips):
+            if c.ndim > 3 or any(d != 1 for d in c.shape[:-1]):
+                raise RuntimeError(f"enhance_batch: clip {i} must be [L], [1, L] or [1, 1, L] (got {tuple(c.shape)})")
+            flat.append(c.reshape(-1))
+        lens = [int(c.numel()) for c in flat]
+        Tps = {lib.fd_padded_frames(lib.fd_num_frames(l, hop)) for l in lens}
+        if len(Tps) != 1:
+            raise RuntimeError(f"enhance_batch: the clips pad to different frame counts {sorted(Tps)}; one call takes one T_pad bucket "
+                               f"(bucket with flowdec_amd.model.padded_frames_of)")
+        Tp = Tps.pop()
+        B = len(flat)
+        # the row length is the bucket's LARGEST possible clip (1 + Lrow // hop == T_pad): one workspace / one hipGraph per (B, T_pad)
+        Lrow = hop * Tp - 1
+        from . import ops
+        ops.check_ragged_lengths(lens, Lrow, cfg["n_fft"], hop)
+        gens = generator if isinstance(generator, (list, tuple)) else [generator] * B
+        if noise is not None and len(noise) != B or len(gens) != B:
+            raise RuntimeError("enhance_batch: one noise tensor / generator per clip")
+        with torch.cuda.device(dev):
+            io = self._io_buffers(B, Lrow, Tp, F, dev)
+            if "lens" not in io:
+                io["lens"] = torch.empty(B, dtype=torch.int32, device=dev)
+            io["y"].zero_()
+            for b, c in enumerate(flat):
+                io["y"][b, :lens[b]].copy_(c)
+                io["noise"][b:b + 1].copy_(self._get_noise_tensor((1, 1, F, Tp), dev, None if noise is None else noise[b], gens[b]))
+            io["lens"].copy_(torch.tensor(lens, dtype=torch.int32))
+            cur = torch.cuda.current_stream(dev)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(dev)
+            side = self._side_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                need = lib.fd_enhance_workspace_bytes(h, B, Lrow)
+                if need == 0:
+                    raise RuntimeError("flowdec_hip: " + lib.fd_last_error().decode())
+                ws = self.backbone.workspace(("enh", B, Lrow), need, dev)
+                L.check(lib.fd_enhance_ragged(h, L.ptr(io["y"]), L.ptr(io["lens"]), L.ptr(torch.view_as_real(io["noise"])), float(sigma_fac), int(N),
+                                              L.SOLVERS[solver], L.ptr(io["out"]), B, Lrow, L.ptr(ws), ws.numel(), int(use_graph), L.stream()))
+                outs = [io["out"][b, :lens[b]].clone() for b in range(B)]
+            cur.wait_stream(side)
+        res = []
+        for b, c in enumerate(clips):
+            outs[b].record_stream(cur)
+            res.append(outs[b].reshape(c.shape).to(c.device))
+        return res
 
     def _enhance_adaptive(self, lib, h, cfg, io, B, Lw, F, T, Tp, N, sigma_fac, return_traj, squeeze_dims, dev, atol, rtol, method=0):
         """solver='dopri5' / 'tsit5': adaptive 5(4) pair over t_span = linspace(0, 1, N+1) (torchdyn semantics restated, unpinned);

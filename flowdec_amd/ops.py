@@ -163,8 +163,25 @@ def stft_plan(n_fft, hop, device):
     return _PLANS[key].handle
 
 
-def stft_compress(y, n_fft=1534, hop=384, alpha=0.3, beta=0.33, normalize=True):
-    """y [B, L] float32 -> (Y complex64 [B, 1, F, T_pad], normfac [B], T)."""
+def check_ragged_lengths(lengths, Ls, n_fft, hop):
+    """A ragged batch is one T_pad bucket: every clip longer than the reflect padding, none longer than the row, and all of them
+    padding to the frame count of the row length (util/other.py:25-52).  -> (host list, T_pad).  The native kernels trust this."""
+    lib = L.load()
+    ls = [int(v) for v in (lengths.tolist() if torch.is_tensor(lengths) else lengths)]
+    Tp = lib.fd_padded_frames(lib.fd_num_frames(Ls, hop))
+    for b, l in enumerate(ls):
+        if not (n_fft // 2 < l <= Ls):
+            raise RuntimeError(f"ragged batch: clip {b} has {l} samples, need {n_fft // 2} < length <= row length {Ls}")
+        if lib.fd_padded_frames(lib.fd_num_frames(l, hop)) != Tp:
+            raise RuntimeError(f"ragged batch: clip {b} ({l} samples) pads to {lib.fd_padded_frames(lib.fd_num_frames(l, hop))} frames, the "
+                               f"row length {Ls} to {Tp}: one call takes ONE T_pad bucket")
+    return ls, Tp
+
+
+def stft_compress(y, n_fft=1534, hop=384, alpha=0.3, beta=0.33, normalize=True, lengths=None):
+    """y [B, L] float32 -> (Y complex64 [B, 1, F, T_pad], normfac [B], T).  `lengths` (B ints): a ragged batch -- clip b is the first
+    lengths[b] samples of its row and is transformed exactly as it would be alone (fd_stft_compress_ragged); T is then the frame
+    count of the row length."""
     L.require_cuda(y)
     lib = L.load()
     B, Ls = y.shape
@@ -174,19 +191,34 @@ def stft_compress(y, n_fft=1534, hop=384, alpha=0.3, beta=0.33, normalize=True):
     nf = torch.empty(B, dtype=torch.float32, device=y.device)
     nws = lib.fd_stft_workspace_bytes(B, Ls, n_fft, hop)
     ws = torch.empty(nws, dtype=torch.uint8, device=y.device)
+    if lengths is not None:
+        ls, _ = check_ragged_lengths(lengths, Ls, n_fft, hop)
+        lens = torch.tensor(ls, dtype=torch.int32, device=y.device)
+        L.check(lib.fd_stft_compress_ragged(stft_plan(n_fft, hop, y.device), L.ptr(y), L.ptr(lens), B, Ls, alpha, beta, int(normalize), L.ptr(nf),
+                                            L.ptr(Y), Tp, L.ptr(ws), nws, L.stream()))
+        lens.record_stream(torch.cuda.current_stream(y.device))
+        return Y, nf, T
     L.check(lib.fd_stft_compress(stft_plan(n_fft, hop, y.device), L.ptr(y), B, Ls, alpha, beta, int(normalize), L.ptr(nf), L.ptr(Y), Tp, L.ptr(ws),
                                  nws, L.stream()))
     return Y, nf, T
 
 
-def decompress_istft(X, T, length, normfac=None, n_fft=1534, hop=384, alpha=0.3, beta=0.33):
-    """X complex64 [B, 1, F, T_pad] -> y [B, length] float32."""
+def decompress_istft(X, T, length, normfac=None, n_fft=1534, hop=384, alpha=0.3, beta=0.33, lengths=None):
+    """X complex64 [B, 1, F, T_pad] -> y [B, length] float32.  `lengths` (B ints): ragged batch -- clip b is synthesised from its own
+    1 + lengths[b] // hop frames into the first lengths[b] samples of its row (the rest zero); T must be 1 + length // hop."""
     L.require_cuda(X)
     lib = L.load()
     B, Tp = X.shape[0], X.shape[-1]
     y = torch.empty(B, length, dtype=torch.float32, device=X.device)
     nws = lib.fd_stft_workspace_bytes(B, max(length, hop * T), n_fft, hop)
     ws = torch.empty(nws, dtype=torch.uint8, device=X.device)
+    if lengths is not None:
+        ls, _ = check_ragged_lengths(lengths, length, n_fft, hop)
+        lens = torch.tensor(ls, dtype=torch.int32, device=X.device)
+        L.check(lib.fd_decompress_istft_ragged(stft_plan(n_fft, hop, X.device), L.ptr(X), L.ptr(lens), B, T, Tp, alpha, beta, L.ptr(normfac), L.ptr(y),
+                                               length, L.ptr(ws), nws, L.stream()))
+        lens.record_stream(torch.cuda.current_stream(X.device))
+        return y
     L.check(lib.fd_decompress_istft(stft_plan(n_fft, hop, X.device), L.ptr(X), B, T, Tp, alpha, beta, L.ptr(normfac), L.ptr(y), length, L.ptr(ws),
                                     nws, L.stream()))
     return y

@@ -112,6 +112,11 @@ extern "C" {
 
 const char* fd_last_error(void);
 int fd_version(void);
+/* Box calibration (bench.py `box_calibration`): `repeats` timed launches of a fixed matrix-core issue loop (register-resident random
+ * bf16 operands, no LDS, no memory; iters <= 0: 100000 iterations, ~50 ms per launch) on `stream`; *tflops = the mean rate the box
+ * sustains at its power-limited clock, *ms_total (optional) the time of the timed launches.  scratch: 2 KiB of device memory.
+ * Synchronises the stream.  No counterpart in the reference (enhance.py:120-136 times one call with two events). */
+int fd_calibrate_mfma(float* scratch, int iters, int repeats, double* tflops, double* ms_total, void* stream);
 /* Device properties the bench reports: [0]=CU count, [1]=max clock kHz, [2]=wavefront size, [3]=gfx arch number. */
 int fd_device_info(int* out4);
 
@@ -245,6 +250,18 @@ int fd_stft_compress(const fd_stft_plan* plan, const float* y, int B, int L, flo
  * (model.py:165-190, feature_extractors.py:98-109,130-139).  normfac may be NULL. */
 int fd_decompress_istft(const fd_stft_plan* plan, const float* X, int B, int T, int T_pad, float alpha, float beta,
                         const float* normfac, float* y, int L, void* ws, size_t ws_bytes, void* stream);
+/* Ragged batches (round 6).  The reference's driver enhances a directory FILE BY FILE, every file its own length (enhance.py:96-137,
+ * model.py:129-163,476-528).  These variants take the files whose spectrograms pad to the same T_pad (util/other.py:25-52) as ONE
+ * batch: y / the output are [B][L] rows with L = the longest clip, `lengths` (DEVICE int32 [B], n_fft/2 < lengths[b] <= L) the clips'
+ * own sample counts.  Clip b gets exactly the arithmetic of a call with that clip alone: reflect padding at ITS end, its own
+ * 1 + lengths[b]/hop frames (the rest zero, as pad_spec would leave them), torch.istft(length = lengths[b]) with its own overlap-add
+ * envelope -- the result is bit-identical to the one-clip call; samples [lengths[b], L) of an output row are zero.  The caller
+ * guarantees fd_padded_frames(fd_num_frames(lengths[b], hop)) == T_pad for every b; the kernels clamp a length into (n_fft/2, L]. */
+int fd_stft_compress_ragged(const fd_stft_plan* plan, const float* y, const int* lengths, int B, int L, float alpha, float beta,
+                            int normalize, float* normfac, float* Y, int T_pad, void* ws, size_t ws_bytes, void* stream);
+/* T = 1 + L / hop (the frame count of the row length). */
+int fd_decompress_istft_ragged(const fd_stft_plan* plan, const float* X, const int* lengths, int B, int T, int T_pad, float alpha,
+                               float beta, const float* normfac, float* y, int L, void* ws, size_t ws_bytes, void* stream);
 /* CompressAmplitudesAndScale.forward (inverse = 0: beta |x|^alpha e^{j angle x}) / .invert (inverse = 1) on n complex64
  * values (feature_extractors.py:118-139) as a stand-alone pass; X == Y allowed. */
 int fd_compress_spec(const float* X, float* Y, long long n, float alpha, float beta, int inverse, void* stream);
@@ -313,6 +330,11 @@ size_t fd_enhance_normfac_offset(const fd_model* m, int B, int L);
 /* FlowModel.enhance (model.py:476-528) end to end on device buffers: y [B][L] f32 -> x_hat [B][L] f32. */
 int fd_enhance(fd_model* m, const float* y, const float* noise, float sigma_fac, int N, int solver, float* x_hat, int B,
                int L, void* ws, size_t ws_bytes, int use_graph, void* stream);
+/* FlowModel.enhance on a ragged batch (see "Ragged batches" above): workspace as for fd_enhance(B, L); noise [B][1][F][T_pad];
+ * clip b bit-identical to fd_enhance on that clip alone with the same noise.  A captured graph is keyed on the POINTER `lengths`
+ * (its contents may change between replays). */
+int fd_enhance_ragged(fd_model* m, const float* y, const int* lengths, const float* noise, float sigma_fac, int N, int solver,
+                      float* x_hat, int B, int L, void* ws, size_t ws_bytes, int use_graph, void* stream);
 /* normalize_mode of the model's front end: 1 = 'noisy' (default), 0 = 'none' (model.py:52, util/other.py:70). */
 int fd_model_set_normalize(fd_model* m, int normalize);
 

@@ -20,6 +20,7 @@ int main(int argc, char** argv) {
   NEED(fd_conv2d); NEED(fd_conv_pack_weights); NEED(fd_gn_finalize); NEED(fd_stft_compress); NEED(fd_decompress_istft);
   NEED(fd_model_create); NEED(fd_model_set_param); NEED(fd_model_finalize); NEED(fd_ncsnpp_forward); NEED(fd_ode_solve);
   NEED(fd_enhance); NEED(fd_score_enhance); NEED(fd_regression_enhance); NEED(fd_stft_plan_create); NEED(fd_stft_plan_destroy);
+  NEED(fd_calibrate_mfma); NEED(fd_enhance_ragged); NEED(fd_stft_compress_ragged); NEED(fd_decompress_istft_ragged);
   NEED(fd_enhance_normfac_offset); NEED(fd_model_set_normalize); NEED(fd_profile_read_fir); NEED(fd_conv_in);
 
   int (*version)(void) = (int (*)(void))dlsym(h, "fd_version");

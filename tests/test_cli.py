@@ -236,3 +236,32 @@ def test_real_checkpoint_check_script(tmp_path):
     assert all(r["bf16x3_rel_l2"] < 5e-4 and 1e-4 < r["bf16_rel_l2"] < 0.3 for r in rep["files"])   # (nf = 8 toy model: bf16 ~ 1e-1)
     rep = rcc.run(["--ckpt", str(tmp_path / "m.ckpt"), "--files", str(ind), "--N", "2", "--solver", "midpoint", "--tol", "1e-4"])
     assert rep["verdict"] == "FAIL"
+
+
+def test_plan_batches_buckets_by_padded_frames(tmp_path):
+    """(CPU) The CLI's batching plan: files are bucketed by the frame count their spectrogram pads to -- computed from the wav HEADERS
+    and the resampler's output length -- and cut into batches of at most --batch-files, in work-list order; files the length rule
+    skips, stereo files and unreadable ones go through the one-file path."""
+    from types import SimpleNamespace
+    from flowdec_amd import enhance_cli
+    from flowdec_amd.model import padded_frames_of
+    assert [padded_frames_of(n) for n in (24575, 24576, 49151, 49152, 96000)] == [64, 128, 128, 192, 256]
+    assert enhance_cli.resampled_length(12000, 16000, 48000) == 36000 and enhance_cli.resampled_length(1001, 44100, 48000) == 1090
+    assert enhance_cli.resample(torch.zeros(1, 1001), 44100, 48000).shape[-1] == 1090
+    rng = np.random.default_rng(0)
+    spec = [("a", 30000, 48000, 1), ("b", 41234, 48000, 1), ("c", 20000, 48000, 1), ("d", 12000, 16000, 1), ("e", 30000, 48000, 2),
+            ("f", 49151, 48000, 1), ("g", 31 * 8000, 8000, 1)]
+    for name, n, sr, ch in spec:
+        enhance_cli.save_wav(str(tmp_path / f"{name}.wav"), torch.from_numpy((0.1 * rng.standard_normal((ch, n))).astype(np.float32)), sr)
+    (tmp_path / "h.wav").write_bytes(b"not a wav file")
+    assert enhance_cli.wav_info(str(tmp_path / "e.wav")) == (30000, 48000, 2)
+    model = SimpleNamespace(sampling_rate=48000, feature_extractor=SimpleNamespace(_cfg=lambda: dict(n_fft=1534, hop=384, alpha=0.3, beta=0.33)))
+    jobs = list(enhance_cli.plan_jobs(sorted(str(p) for p in tmp_path.glob("*.wav")), None, str(tmp_path / "out"), None, None, True))
+    names = lambda plan: [[j.src.split("/")[-1][:-4] for j in b] for b in plan]
+    assert names(enhance_cli.plan_batches(model, jobs, 2)) == [["c"], ["a", "b"], ["d", "f"], ["e"], ["g"], ["h"]]
+    assert names(enhance_cli.plan_batches(model, jobs, 8)) == [["c"], ["a", "b", "d", "f"], ["e"], ["g"], ["h"]]
+    assert names(enhance_cli.plan_batches(model, jobs, 1)) == [[n] for n in "abcdefgh"]
+    # RunLog opens its files on __enter__; a failing second open must not leak the first handle
+    log = enhance_cli.RunLog(str(tmp_path / "missing_dir"), "", want_rtf=True, want_triples=True)
+    with pytest.raises(OSError):
+        log.__enter__()

@@ -90,6 +90,17 @@ def test_cfg3_flowdec_25s_b32_midpoint_N6_full_width():
     _size_properties(m, 32, 2.0, 6, "midpoint", "cfg3_b32_midpoint_N6")
 
 
+def test_cfg4_flowdec_75m_b32_per_gpu_shard_full_width():
+    """BASELINE config 4 BY NAME: FlowDec-75m, 256 x 2 s clips over 8 GPUs = 32 clips per GPU, midpoint, bf16 -- one GPU's shard at full
+    width and full size, in both readings of "6-step midpoint" (N = 3: NFE 6, demo.ipynb cell 3; N = 6: 12 evaluations, model.py:487).
+    Same kernel schedule as cfg 3 (the presets differ in the sigma_y curve only: config/flowdec_75m.yaml:18-22 vs flowdec_25s.yaml);
+    the clip-level parity of this model / size / solver against the reference is test_cfg4_image_size_vs_reference (G24), the
+    N-GPU == 1-GPU identity tests/test_hip_dist.py."""
+    m = make_model(64, 64, "bf16")
+    _size_properties(m, 32, 2.0, 3, "midpoint", "cfg4_shard_b32_midpoint_N3")
+    _size_properties(m, 32, 2.0, 6, "midpoint", "cfg4_shard_b32_midpoint_N6")
+
+
 def test_cfg2_flowdec_75m_b8_euler6_full_width():
     """BASELINE config 2 exactly: FlowDec-75m, batch = 8 x 2 s, 6-step Euler, bf16 (the bench.py workload)."""
     m = make_model(64, 64, "bf16")
@@ -582,6 +593,18 @@ def test_conv2d_winograd_weight_range(algo, wstd):
     pw3 = ops.pack_conv_weight(dev(w), dtype=torch.bfloat16, w_sc=dev(ws), S0=S, **kw)
     out3 = from_nhwc(ops.conv2d(x0, pw3, Co, 3, affine=aff, sc0=nhwc(xs, torch.bfloat16), **kw))
     check(f"conv2d_{algo}_weight_range_shortcut[{wstd:g}]", out3, ref3, tol)
+    # (4) a near-zero-initialised 3x3 layer (~1e-30) next to O(1) shortcut weights: the cout's power-of-two factor is bounded by the
+    # SHORTCUT's magnitude too (wino4_scale_kernel: scaled shortcut weights stay below 2^60), so the shared f32 accumulators stay far
+    # from the edge of their range -- also with residual-stream magnitudes of 1e4
+    if wstd == 1e-2:
+        wt = bf(1e-30 * rng.standard_normal((Co, C, 3, 3)))
+        w1 = bf(rng.standard_normal((Co, S, 1, 1)) / np.sqrt(S))
+        xs4 = bf(1e4 * rng.standard_normal((B, S, H, W)))
+        ref4 = O.conv2d(xin, wt.astype(np.float64), None) + O.conv2d(xs4.astype(np.float64), w1.astype(np.float64), None)
+        pw4 = ops.pack_conv_weight(dev(wt), dtype=torch.bfloat16, w_sc=dev(w1), S0=S, **kw)
+        out4 = from_nhwc(ops.conv2d(x0, pw4, Co, 3, affine=aff, sc0=nhwc(xs4, torch.bfloat16), **kw))
+        assert np.isfinite(out4).all()
+        check(f"conv2d_{algo}_tiny3x3_unit_shortcut", out4, ref4, tol)
 
 
 def test_small_weight_layers_full_width():

@@ -279,7 +279,8 @@ def test_bench_self_launch_gloo_world2():
 
 def test_bench_config_flag_cfg4_shard_line():
     """`bench.py --gpus N --config cfg4` is BASELINE config 4 in one command: FlowDec-75m, 32 x 2 s clips PER RANK (8 ranks = the 256-clip
-    batch), midpoint N = 3 (NFE 6), bf16, weak scaling; explicit flags still win over the named configuration (gloo + stub step here)."""
+    batch), midpoint N = 6 = 12 evaluations (the reference counts solver steps, flowdec/model.py:487; `cfg4_nfe6` is the N = 3 reading), bf16,
+    weak scaling; explicit flags still win over the named configuration, abbreviated flags are refused (gloo + stub step here)."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg4", "--backend", "gloo", "--stub-step",
@@ -287,10 +288,16 @@ def test_bench_config_flag_cfg4_shard_line():
     assert r.returncode == 0, r.stdout + r.stderr
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert res["n_gpus"] == 2 and res["config"]["clips_per_rank"] == [32, 32] and res["config"]["global_batch"] == 64
-    assert res["config"]["nfe"] == 6 and res["scaling"] == "weak" and res["dtype"] == "bf16"
+    assert res["config"]["nfe"] == 12 and res["scaling"] == "weak" and res["dtype"] == "bf16"
     sys.path.insert(0, ROOT)
     import bench
-    assert bench.CONFIGS["cfg4"] == dict(preset="flowdec_75m", batch=32, seconds=2.0, N=3, solver="midpoint", precision="bf16")
+    assert bench.CONFIGS["cfg4"] == dict(preset="flowdec_75m", batch=32, seconds=2.0, N=6, solver="midpoint", precision="bf16")
+    assert bench.CONFIGS["cfg4_nfe6"]["N"] == 3 and bench.CONFIGS["cfg3"]["N"] == 6 and bench.CONFIGS["cfg3_nfe6"]["N"] == 3
+    assert bench.CONFIGS["cfg5_dopri5"]["solver"] == "dopri5" and bench.CONFIGS["cfg3_n6"] == bench.CONFIGS["cfg3"]
+    # an abbreviated flag ("--prec") would slip past the override test of --config: argparse must refuse it
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg4", "--prec", "fp32", "--stub-step"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "unrecognized arguments" in r.stderr
     assert bench.CONFIGS["cfg5"]["precision"] == "fp32" and bench.CONFIGS["cfg5"]["seconds"] == 4.0 and bench.CONFIGS["cfg3"]["preset"] == "flowdec_25s"
 
 
