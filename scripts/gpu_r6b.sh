@@ -17,3 +17,6 @@ f=$(ls $O/prof_b1/*/*kernel_trace.csv | head -1)
 python scripts/step_breakdown.py $f 60 > $O/r6b_b1_breakdown.txt 2>&1; head -70 $O/r6b_b1_breakdown.txt
 find $O/prof_b1 -name '*kernel_trace.csv' -size +20M -delete
 timeout 300 python bench.py --batch 1 --seconds 1 --conv-algo latency --steps 20 --warmup 5 --no-cpu-baseline < /dev/null 2>/dev/null | tail -1 > $O/r6b_bench_b1_1s_latency.json; cut -c1-300 $O/r6b_bench_b1_1s_latency.json
+# the rest of the GPU suite (call A stopped at the first failure: a test-side magnitude that the F(2,3) kernel never supported)
+timeout 1500 python -m pytest tests -m gpu -q -x < /dev/null > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+tail -6 $O/pytest_gpu.log
