@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libflowdec_hip.so")
-SOURCES = ["api.hip", "calib.hip", "conv_mfma.hip", "conv_wino.hip", "conv_wino4.hip", "conv_head.hip", "elementwise.hip", "stft.hip", "model.hip", "ndac.hip", "ndac_mfma.hip"]
+SOURCES = ["api.hip", "calib.hip", "conv_mfma.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wino4f.hip", "conv_head.hip", "elementwise.hip", "stft.hip", "model.hip", "ndac.hip", "ndac_mfma.hip"]
 # -fno-slp-vectorize: hipcc (ROCm 7.2) otherwise packs adjacent f32 FMAs into v_pk_fma_f32; beside MFMAs that is slower
 # (guide: MI355X_MICROARCH "price of one filler beside MFMAs") and one such packing of the fused GroupNorm affine
 # produced wrong lanes (op_sel_hi broadcast) in the f32 conv path.
@@ -31,7 +31,7 @@ def needs_build():
 
 
 def check_wino4_isa(hipcc=None, extra=()):
-    """conv_wino4.hip writes M0 from inline asm without saving it (the LDS-DMA destination; hipcc refuses M0 on a clobber list) and counts
+    """conv_wino4.hip (and its float32 twin conv_wino4f.hip) writes M0 from inline asm without saving it (the LDS-DMA destination; hipcc refuses M0 on a clobber list) and counts
     its own s_waitcnt vmcnt by hand.  Both rest on properties of the GENERATED code, so the build checks them and fails otherwise: no M0
     use outside the kernel's own `s_mov_b32 m0` statements, no scratch (a spill inside the K loop would break the counted waits), and the
     expected number of MFMA sites (one loop body per instantiation).  ~6 s, runs beside the object compiles.
@@ -42,23 +42,27 @@ def check_wino4_isa(hipcc=None, extra=()):
         print("flowdec_amd.build: FLOWDEC_SKIP_ISA_CHECK set -- conv_wino4.hip ISA properties NOT verified", file=sys.stderr)
         return False
     hipcc = hipcc or _hipcc()
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "w4.s")
-        r = subprocess.run([hipcc, *FLAGS, *extra, "-S", "--cuda-device-only", os.path.join(CSRC, "conv_wino4.hip"), "-o", out], capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("hipcc -S failed for conv_wino4.hip:\n" + r.stderr[-4000:])
-        code = [l.split(";")[0] for l in open(out).read().splitlines()]
-    foreign = [l for l in code if ("m0" in l.split() or ", m0" in l or " m0," in l) and not l.strip().startswith("s_mov_b32 m0,")]
-    if foreign:
-        raise RuntimeError("conv_wino4.hip: M0 is used outside the kernel's own LDS-DMA statements: %r" % foreign[:5])
-    if any("scratch_" in l for l in code):
-        raise RuntimeError("conv_wino4.hip: a kernel spills to scratch (breaks the hand-counted s_waitcnt vmcnt)")
-    n = sum("v_mfma_f32_32x32x16_f16" in l for l in code)
-    if n != 6 * 72:   # six instantiations, 18 steps x 4 MFMAs each
-        print("flowdec_amd.build: WARNING conv_wino4.hip has %d F(4,3) MFMA sites, expected %d (the K loop was duplicated or unswitched by "
-              "this hipcc: slower, still correct)" % (n, 6 * 72), file=sys.stderr)
-        return False
-    return True
+    ok = True
+    # file -> (MFMA mnemonic, expected sites): conv_wino4.hip six instantiations x 18 steps x 4; conv_wino4f.hip (float32) six x 18 x 16 in the
+    # K loop + 64 per folded-shortcut stage body of the two shortcut instantiations
+    for src, (mnem, want) in {"conv_wino4.hip": ("v_mfma_f32_32x32x16_f16", 6 * 72), "conv_wino4f.hip": ("v_mfma_f32_32x32x2_f32", 6 * 288 + 2 * 64)}.items():
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "w4.s")
+            r = subprocess.run([hipcc, *FLAGS, *extra, "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc -S failed for %s:\n%s" % (src, r.stderr[-4000:]))
+            code = [l.split(";")[0] for l in open(out).read().splitlines()]
+        foreign = [l for l in code if ("m0" in l.split() or ", m0" in l or " m0," in l) and not l.strip().startswith("s_mov_b32 m0,")]
+        if foreign:
+            raise RuntimeError("%s: M0 is used outside the kernel's own LDS-DMA statements: %r" % (src, foreign[:5]))
+        if any("scratch_" in l for l in code):
+            raise RuntimeError("%s: a kernel spills to scratch (breaks the hand-counted s_waitcnt vmcnt)" % src)
+        n = sum(mnem in l for l in code)
+        if n != want:
+            print("flowdec_amd.build: WARNING %s has %d F(4,3) MFMA sites, expected %d (the K loop was duplicated or unswitched by "
+                  "this hipcc: slower, still correct)" % (src, n, want), file=sys.stderr)
+            ok = False
+    return ok
 
 
 def build(force=False, verbose=True):

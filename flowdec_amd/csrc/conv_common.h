@@ -68,6 +68,14 @@ int fd_wino4_init_attributes();
 bool fd_wino4_supported(int Cout, int C0, int C1, int S0, int S1, int ksize);
 bool fd_wino4_shape_ok(int H, int W);
 
+// conv_wino4f.hip (the same algorithm in exact float32: f32 storage, v_mfma_f32_32x32x2_f32; channel counts % 16 == 0)
+long long fd_wino4f_packed_bytes(int Cout, int C0, int C1, int S0, int S1);
+int fd_wino4f_pack_weights(const float* w, const float* w_sc, void* packed, int Cout, int C0, int C1, int S0, int S1, hipStream_t st);
+int fd_wino4f_launch(fdconv::ConvArgs a, hipStream_t st);
+int fd_wino4f_init_attributes();
+bool fd_wino4f_supported(int Cout, int C0, int C1, int S0, int S1, int ksize);
+bool fd_wino4f_shape_ok(int H, int W);
+
 // conv_head.hip (Cout = 4 pyramid heads, bf16)
 bool fd_head_supported(const fdconv::ConvArgs& a, int ksize, int dtype);
 int fd_head_launch(fdconv::ConvArgs a, hipStream_t st);

@@ -352,6 +352,9 @@ struct Fwd {
     const int px_tiles = fd_cdiv(out.H, 16) * fd_cdiv(out.W, 16);
     const bool latency = m && (m->cfg.act_dtype & FD_LOW_LATENCY) && dt == FD_BF16;
     const bool autosel = m && (m->cfg.act_dtype & FD_WINOGRAD_AUTO) && dt == FD_BF16;
+    // fp32 mode (pure f32: storage, operands, exact f32 MFMA): F(4,3) in float32 (conv_wino4f.hip) for images of at least 96 tiles -- the
+    // f32 matrix instruction is 16 x slower than the fp16 one, so halving the MFMAs is worth 1.8 x per launch there.  By image size only.
+    const bool autosel_f32 = m && (m->cfg.act_dtype & FD_WINOGRAD_AUTO) && dt == FD_F32 && opflag == 0;
     if (latency && px_tiles <= 24 && out.C >= 64) tile = FD_TILE_BN32_CHUNK;
     else if (autosel && px_tiles <= 16 && out.C >= 64) tile = FD_TILE_BN64_CHUNK;   // the 96 x 32 level: 18.5 us vs 22.6 (Winograd) at 8 clips, 17.1 vs 21.9 at one
     // (never with a folded 1x1 shortcut: its input is the UN-NORMALISED residual stream, which the Winograd kernel would narrow to
@@ -365,8 +368,8 @@ struct Fwd {
     // (the 64-channel input of the first block included: 1.07x with the halo of a chunk pair per request)
     // (a folded 1x1 shortcut runs as a bf16 GEMM on the raw residual stream in that kernel's epilogue: no fp16 range issue)
     // (FD_LOW_LATENCY: everything above 128 tiles: one 1 s clip 60.0 -> 63.4x, one 2 s clip 79 -> 88.8x real time)
-    else if ((autosel || (latency && px_tiles > 128)) && w_wino4 && !(s0 && skip) && out.H % 16 == 0 && out.W % 16 == 0 &&
-             a.C + (b ? b->C : 0) >= 64) {
+    else if ((autosel || (latency && px_tiles > 128) || (autosel_f32 && px_tiles >= 96)) && w_wino4 && !(s0 && skip) && out.H % 16 == 0 &&
+             out.W % 16 == 0 && a.C + (b ? b->C : 0) >= 64) {
       w = w_wino4; wino4 = true;
       // every other F(4,3) launch of a forward walks its tiles backwards: a consumer then starts on the lines its producer wrote last,
       // which the memory-side cache still holds (the position in the launch sequence decides, so every forward has the same schedule)
@@ -785,7 +788,8 @@ extern "C" int fd_model_create(const fd_model_config* cfg, fd_model** out) {
   {
     const int algo = cfg->act_dtype & (FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY);
     FD_REQUIRE((algo & (algo - 1)) == 0, "fd_model_create: at most one of FD_WINOGRAD / FD_WINOGRAD_LOWRES / FD_WINOGRAD_AUTO / FD_LOW_LATENCY (got 0x%x)", algo);
-    FD_REQUIRE(algo == 0 || (cfg->act_dtype & 0xff) == FD_BF16, "fd_model_create: the convolution-algorithm flags go with FD_BF16 storage");
+    FD_REQUIRE(algo == 0 || (cfg->act_dtype & 0xff) == FD_BF16 || (algo == FD_WINOGRAD_AUTO && act_nos == (FD_F32 | FD_WINOGRAD_AUTO)),
+               "fd_model_create: the convolution-algorithm flags go with FD_BF16 storage (FD_WINOGRAD_AUTO also with pure FD_F32: F(4,3) in float32)");
     FD_REQUIRE((cfg->act_dtype & FD_TILE_MASK) == 0, "fd_model_create: FD_TILE_* selects the workgroup width of ONE fd_conv2d launch, not of a model");
     FD_REQUIRE((cfg->act_dtype & ~(0xff | FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY | FD_BF16_OPERANDS | FD_BF16X3_OPERANDS |
                                   FD_NO_SIDE_STREAM)) == 0, "fd_model_create: unknown bits in act_dtype (0x%x)", cfg->act_dtype);

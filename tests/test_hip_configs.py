@@ -503,11 +503,100 @@ def test_conv2d_winograd4(case):
     assert rel_err(from_nhwc(out), from_nhwc(outd)) < 5e-3
 
 
+@pytest.mark.parametrize("case", WINO4_CASES + [("f32_c16", 1, 16, 32, 16, 0, 256, True, 1, False, 0, 0), ("f32_sc48", 1, 16, 16, 48, 16, 256, True, 1, False, 32, 16)],
+                         ids=[c[0] for c in WINO4_CASES] + ["f32_c16", "f32_sc48"])
+def test_conv2d_winograd4_f32(case):
+    """Winograd F(4,3) in EXACT FLOAT32 (conv_wino4f.hip; round 6): f32 storage, f32 transforms, v_mfma_f32_32x32x2_f32 -- the fp32 mode's
+    kernel for images of at least 96 tiles (half the MFMAs of the direct f32 kernel).  Same operator cases as the fp16-operand kernel plus
+    channel counts that are multiples of 16 only; reference = the f64 convolution of the SAME f32 tensors: 2e-5 (measured ~1e-6: the
+    transforms' row sums of 10 / 8 on f32 roundings; the direct f32 kernel: 3e-7), GroupNorm partial sums 2e-5, bit-deterministic in both
+    tile orders, and within 2e-5 of the direct f32 kernel."""
+    from flowdec_amd import ops
+    import zlib
+    name, B, H, W, C0, C1, Cout, use_aff, bias_rows, use_skip, S0, S1 = case
+    rng = np.random.default_rng(zlib.crc32(("w4f" + name).encode()))
+    Cin = C0 + C1
+    f32 = torch.float32
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
+    aff, xin = None, x.astype(np.float64)
+    if use_aff:
+        a = (1 + 0.2 * rng.standard_normal((B, Cin))).astype(np.float32)
+        d = (0.3 * rng.standard_normal((B, Cin))).astype(np.float32)
+        aff = dev(np.stack([a, d], axis=-1))
+        u = x.astype(np.float64) * a[:, :, None, None] + d[:, :, None, None]
+        xin = u / (1.0 + np.exp(-u))
+    ref = O.conv2d(xin, w.astype(np.float64), None)
+    sc0 = sc1 = w_sc = None
+    if S0:
+        xs = rng.standard_normal((B, S0 + S1, H, W)).astype(np.float32)
+        ws = (rng.standard_normal((Cout, S0 + S1, 1, 1)) / np.sqrt(S0 + S1)).astype(np.float32)
+        ref = ref + O.conv2d(xs.astype(np.float64), ws.astype(np.float64), None)
+        sc0 = nhwc(xs[:, :S0], f32)
+        sc1 = nhwc(xs[:, S0:], f32) if S1 else None
+        w_sc = dev(ws)
+    bias = None
+    if bias_rows:
+        bv = rng.standard_normal((bias_rows, Cout)).astype(np.float32)
+        bias = dev(bv if bias_rows > 1 else bv[0])
+        ref = ref + (bv[:, :, None, None] if bias_rows > 1 else bv[0][None, :, None, None])
+    skip, scale = None, 1.0
+    if use_skip:
+        sk = rng.standard_normal((B, Cout, H, W)).astype(np.float32)
+        skip = nhwc(sk, f32)
+        ref = ref + sk
+        scale = float(1 / np.sqrt(2))
+    ref = ref * scale
+    x0 = nhwc(x[:, :C0], f32)
+    x1 = nhwc(x[:, C0:], f32) if C1 else None
+    pw = ops.pack_conv_weight(dev(w), C0=C0, dtype=f32, w_sc=w_sc, S0=S0 if S0 else None, winograd=4)
+    kw = dict(x1=x1, affine=aff, bias=bias, skip=skip, scale=scale, sc0=sc0, sc1=sc1, want_stats=True)
+    out, stats = ops.conv2d(x0, pw, Cout, 3, winograd=4, **kw)
+    torch.cuda.synchronize()
+    assert out.dtype == f32
+    check(f"conv2d_winograd4_f32[{name}]", from_nhwc(out), ref, 2e-5)
+    st = stats.double().sum(dim=1).cpu().numpy()[:, :Cout]
+    ref_s = np.stack([ref.sum(axis=(2, 3)), (ref ** 2).sum(axis=(2, 3))], axis=-1)
+    e = float(np.abs(st - ref_s).max() / np.abs(ref_s).max())
+    report(f"conv2d_winograd4_f32_stats[{name}]", e, 2e-5)
+    assert e < 2e-5
+    out2, stats2 = ops.conv2d(x0, pw, Cout, 3, winograd=4, **kw)
+    assert torch.equal(out, out2) and torch.equal(stats, stats2)
+    out3, stats3 = ops.conv2d(x0, pw, Cout, 3, winograd=4, reversed_tiles=True, **kw)
+    assert torch.equal(out, out3) and torch.equal(stats, stats3)
+    pd = ops.pack_conv_weight(dev(w), C0=C0, dtype=f32, w_sc=w_sc, S0=S0 if S0 else None)
+    outd, _ = ops.conv2d(x0, pd, Cout, 3, **kw)
+    assert rel_err(from_nhwc(out), from_nhwc(outd)) < 2e-5
+
+
+def test_fp32_auto_runs_winograd4_f32_and_matches_direct():
+    """precision='fp32' with conv_algo='auto' (the default) sends the 3x3 convolutions of images of at least 96 tiles to the float32 F(4,3)
+    kernel; 'direct' keeps the direct f32 kernel everywhere.  One full-width forward of each on G10's inputs: both inside the fp32
+    tolerance against the reference, and within 2e-5 of each other (different summation orders of exact f32 products)."""
+    import flowdec_amd
+    g = load_golden("g10_ncsnpp_nf64.npz")
+    sd = O.random_state_dict(seed=int(g["seed"]), nf=64)
+    outs = {}
+    for algo in ("auto", "direct"):
+        m = flowdec_amd.from_preset("flowdec_75m", precision="fp32", conv_algo=algo)
+        assert m.backbone.conv_algo == algo
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        m = m.cuda()
+        outs[algo] = m(cu(g["x"]), cu(g["y"]), torch.tensor([0.5], device="cuda")).cpu().numpy()
+        check(f"ncsnpp_nf64[fp32,{algo}]", outs[algo], g["out"], TOL_FWD_FULL["fp32"])
+        del m
+    e = rel_err(outs["auto"], outs["direct"])
+    report("fp32_forward[auto (F(4,3) f32) vs direct]", e, 2e-5)
+    assert 0 < e < 2e-5, e            # (0 would mean the F(4,3) kernel did not run: G10's image is 768 x 64 = 192 tiles)
+    with pytest.raises(ValueError):
+        flowdec_amd.from_preset("flowdec_75m", precision="fp32", conv_algo="winograd")
+
+
 def test_conv2d_winograd4_rejects_unsupported():
     from flowdec_amd import ops
     bad = [(torch.randn(128, 32, 3, 3), torch.bfloat16),    # Cout != 256
            (torch.randn(256, 32, 1, 1), torch.bfloat16),    # 1x1
-           (torch.randn(256, 32, 3, 3), torch.float32),     # f32 storage
+           (torch.randn(256, 24, 3, 3), torch.float32),     # f32 storage (conv_wino4f.hip): channels % 16 != 0
            (torch.randn(256, 48, 3, 3), torch.bfloat16)]    # channels % 32 != 0
     for w, dt in bad:
         with pytest.raises(RuntimeError):
