@@ -188,7 +188,8 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4f_kernel(ConvArgs p) {
     u32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float x = __builtin_bit_cast(float, raw[j]);
+      const unsigned ur = raw[j];   // (element -> scalar first: see mma below)
+      float x = __builtin_bit_cast(float, ur);
       if constexpr (ACT) x = fd_silu(fmaf(x, aff[2 * j], aff[2 * j + 1]));
       o[j] = __builtin_bit_cast(unsigned, x) & vm;
     }
@@ -272,8 +273,12 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4f_kernel(ConvArgs p) {
   u32x4 qa[3], qb[3];
   auto mma = [&](int xl, int ct, int nt, const u32x4& a, const u32x4& bq) {   // 8 channels = four k = 2 matrix instructions (channels {j, 4 + j})
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      acc[xl][ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[j]), __builtin_bit_cast(float, bq[j]), acc[xl][ct][nt], 0, 0, 0);
+    for (int j = 0; j < 4; ++j) {
+      // (vector element -> scalar FIRST: __builtin_bit_cast applied directly to an ext-vector element lvalue reads element 0 for every
+      //  index with hipcc / ROCm 7.2 -- conv_mfma.hip act_slot)
+      const unsigned ua = a[j], ub = bq[j];
+      acc[xl][ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, ua), __builtin_bit_cast(float, ub), acc[xl][ct][nt], 0, 0, 0);
+    }
   };
   auto rd = [&](int off) { return *reinterpret_cast<const u32x4*>(smem + off); };
   // LDS offsets of the fragments of step k18 (0..17 inside the chunk pair; 18 = step 0 of the next pair)
@@ -650,8 +655,9 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4f_kernel(ConvArgs p) {
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                acc[pl][0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, af[kk][0][j]), __builtin_bit_cast(float, bq[kk][pl][nt][j]), acc[pl][0][nt], 0, 0, 0);
-                acc[pl][1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, af[kk][1][j]), __builtin_bit_cast(float, bq[kk][pl][nt][j]), acc[pl][1][nt], 0, 0, 0);
+                const unsigned u0 = af[kk][0][j], u1 = af[kk][1][j], ub = bq[kk][pl][nt][j];   // (element -> scalar first)
+                acc[pl][0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, u0), __builtin_bit_cast(float, ub), acc[pl][0][nt], 0, 0, 0);
+                acc[pl][1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, u1), __builtin_bit_cast(float, ub), acc[pl][1][nt], 0, 0, 0);
               }
         __builtin_amdgcn_sched_barrier(0);
         slot = slot + 1 == SCD ? 0 : slot + 1;

@@ -781,9 +781,9 @@ extern "C" int fd_model_create(const fd_model_config* cfg, fd_model** out) {
   FD_REQUIRE(cfg->nf >= 8 && cfg->nf % 8 == 0 && cfg->nf <= 64, "fd_model_create: nf must be a multiple of 8 in [8, 64] (got %d)", cfg->nf);
   FD_REQUIRE(cfg->num_levels >= 1 && cfg->num_levels <= 8 && cfg->num_res_blocks >= 1, "fd_model_create: bad level / block counts");
   const int act_nos = cfg->act_dtype & ~FD_NO_SIDE_STREAM;
-  FD_REQUIRE(((act_nos & 0xff) == FD_BF16 && !(act_nos & (FD_BF16_OPERANDS | FD_BF16X3_OPERANDS))) || act_nos == FD_F32 ||
+  FD_REQUIRE(((act_nos & 0xff) == FD_BF16 && !(act_nos & (FD_BF16_OPERANDS | FD_BF16X3_OPERANDS))) || act_nos == FD_F32 || act_nos == (FD_F32 | FD_WINOGRAD_AUTO) ||
                  act_nos == (FD_F32 | FD_BF16_OPERANDS) || act_nos == (FD_F32 | FD_BF16X3_OPERANDS),
-             "fd_model_create: act_dtype must be FD_BF16 [| FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY], FD_F32, "
+             "fd_model_create: act_dtype must be FD_BF16 [| FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY], FD_F32 [| FD_WINOGRAD_AUTO], "
              "FD_F32 | FD_BF16_OPERANDS or FD_F32 | FD_BF16X3_OPERANDS");
   {
     const int algo = cfg->act_dtype & (FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY);

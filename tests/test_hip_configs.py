@@ -508,9 +508,9 @@ def test_conv2d_winograd4(case):
 def test_conv2d_winograd4_f32(case):
     """Winograd F(4,3) in EXACT FLOAT32 (conv_wino4f.hip; round 6): f32 storage, f32 transforms, v_mfma_f32_32x32x2_f32 -- the fp32 mode's
     kernel for images of at least 96 tiles (half the MFMAs of the direct f32 kernel).  Same operator cases as the fp16-operand kernel plus
-    channel counts that are multiples of 16 only; reference = the f64 convolution of the SAME f32 tensors: 2e-5 (measured ~1e-6: the
-    transforms' row sums of 10 / 8 on f32 roundings; the direct f32 kernel: 3e-7), GroupNorm partial sums 2e-5, bit-deterministic in both
-    tile orders, and within 2e-5 of the direct f32 kernel."""
+    channel counts that are multiples of 16 only; reference = the f64 convolution of the SAME f32 tensors: 5e-6 (measured 2.3e-7 ... 9.0e-7:
+    the transforms' row sums of 10 / 8 on f32 roundings; the direct f32 kernel: 3e-7), GroupNorm partial sums 5e-6 (measured <= 2.2e-7),
+    bit-deterministic in both tile orders, and within 5e-6 of the direct f32 kernel."""
     from flowdec_amd import ops
     import zlib
     name, B, H, W, C0, C1, Cout, use_aff, bias_rows, use_skip, S0, S1 = case
@@ -554,19 +554,19 @@ def test_conv2d_winograd4_f32(case):
     out, stats = ops.conv2d(x0, pw, Cout, 3, winograd=4, **kw)
     torch.cuda.synchronize()
     assert out.dtype == f32
-    check(f"conv2d_winograd4_f32[{name}]", from_nhwc(out), ref, 2e-5)
+    check(f"conv2d_winograd4_f32[{name}]", from_nhwc(out), ref, 5e-6)
     st = stats.double().sum(dim=1).cpu().numpy()[:, :Cout]
     ref_s = np.stack([ref.sum(axis=(2, 3)), (ref ** 2).sum(axis=(2, 3))], axis=-1)
     e = float(np.abs(st - ref_s).max() / np.abs(ref_s).max())
-    report(f"conv2d_winograd4_f32_stats[{name}]", e, 2e-5)
-    assert e < 2e-5
+    report(f"conv2d_winograd4_f32_stats[{name}]", e, 5e-6)
+    assert e < 5e-6
     out2, stats2 = ops.conv2d(x0, pw, Cout, 3, winograd=4, **kw)
     assert torch.equal(out, out2) and torch.equal(stats, stats2)
     out3, stats3 = ops.conv2d(x0, pw, Cout, 3, winograd=4, reversed_tiles=True, **kw)
     assert torch.equal(out, out3) and torch.equal(stats, stats3)
     pd = ops.pack_conv_weight(dev(w), C0=C0, dtype=f32, w_sc=w_sc, S0=S0 if S0 else None)
     outd, _ = ops.conv2d(x0, pd, Cout, 3, **kw)
-    assert rel_err(from_nhwc(out), from_nhwc(outd)) < 2e-5
+    assert rel_err(from_nhwc(out), from_nhwc(outd)) < 5e-6
 
 
 def test_fp32_auto_runs_winograd4_f32_and_matches_direct():
