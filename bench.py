@@ -33,7 +33,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_FILE = "r05_conv_traffic.json"
+TRAFFIC_FILE = "r06_conv_traffic.json"
 REF_CPU_FILE = "r02_reference_cpu_timing.json"
 F32_MFMA_PEAK_TFLOPS = 157.3   # dense f32 MFMA (the exact-f32 DFT GEMMs of the STFT front / back end)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "mixed": 2500.0, "bf16x3": 2500.0 / 3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md

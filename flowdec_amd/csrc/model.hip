@@ -352,8 +352,9 @@ struct Fwd {
     const int px_tiles = fd_cdiv(out.H, 16) * fd_cdiv(out.W, 16);
     const bool latency = m && (m->cfg.act_dtype & FD_LOW_LATENCY) && dt == FD_BF16;
     const bool autosel = m && (m->cfg.act_dtype & FD_WINOGRAD_AUTO) && dt == FD_BF16;
-    // fp32 mode (pure f32: storage, operands, exact f32 MFMA): F(4,3) in float32 (conv_wino4f.hip) for images of at least 96 tiles -- the
-    // f32 matrix instruction is 16 x slower than the fp16 one, so halving the MFMAs is worth 1.8 x per launch there.  By image size only.
+    // fp32 mode (pure f32: storage, operands, exact f32 MFMA): F(4,3) in float32 (conv_wino4f.hip) wherever its shape rules hold (Cout = 256,
+    // whole 16 x 16 tiles, >= 64 input channels) -- the f32 matrix instruction is 16 x slower than the fp16 one, the launch is MFMA-bound at
+    // any grid size, and both kernels use one 256-cout workgroup per tile: halving the MFMAs is worth 1.6-1.9 x per launch.  By shape only.
     const bool autosel_f32 = m && (m->cfg.act_dtype & FD_WINOGRAD_AUTO) && dt == FD_F32 && opflag == 0;
     if (latency && px_tiles <= 24 && out.C >= 64) tile = FD_TILE_BN32_CHUNK;
     else if (autosel && px_tiles <= 16 && out.C >= 64) tile = FD_TILE_BN64_CHUNK;   // the 96 x 32 level: 18.5 us vs 22.6 (Winograd) at 8 clips, 17.1 vs 21.9 at one
@@ -368,7 +369,7 @@ struct Fwd {
     // (the 64-channel input of the first block included: 1.07x with the halo of a chunk pair per request)
     // (a folded 1x1 shortcut runs as a bf16 GEMM on the raw residual stream in that kernel's epilogue: no fp16 range issue)
     // (FD_LOW_LATENCY: everything above 128 tiles: one 1 s clip 60.0 -> 63.4x, one 2 s clip 79 -> 88.8x real time)
-    else if ((autosel || (latency && px_tiles > 128) || (autosel_f32 && px_tiles >= 96)) && w_wino4 && !(s0 && skip) && out.H % 16 == 0 &&
+    else if ((autosel || (latency && px_tiles > 128) || autosel_f32) && w_wino4 && !(s0 && skip) && out.H % 16 == 0 &&
              out.W % 16 == 0 && a.C + (b ? b->C : 0) >= 64) {
       w = w_wino4; wino4 = true;
       // every other F(4,3) launch of a forward walks its tiles backwards: a consumer then starts on the lines its producer wrote last,

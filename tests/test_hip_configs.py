@@ -507,7 +507,7 @@ def test_conv2d_winograd4(case):
                          ids=[c[0] for c in WINO4_CASES] + ["f32_c16", "f32_sc48"])
 def test_conv2d_winograd4_f32(case):
     """Winograd F(4,3) in EXACT FLOAT32 (conv_wino4f.hip; round 6): f32 storage, f32 transforms, v_mfma_f32_32x32x2_f32 -- the fp32 mode's
-    kernel for images of at least 96 tiles (half the MFMAs of the direct f32 kernel).  Same operator cases as the fp16-operand kernel plus
+    kernel for every 3x3 layer with 256 output channels (half the MFMAs of the direct f32 kernel).  Same operator cases as the fp16-operand kernel plus
     channel counts that are multiples of 16 only; reference = the f64 convolution of the SAME f32 tensors: 5e-6 (measured 2.3e-7 ... 9.0e-7:
     the transforms' row sums of 10 / 8 on f32 roundings; the direct f32 kernel: 3e-7), GroupNorm partial sums 5e-6 (measured <= 2.2e-7),
     bit-deterministic in both tile orders, and within 5e-6 of the direct f32 kernel."""
@@ -570,7 +570,7 @@ def test_conv2d_winograd4_f32(case):
 
 
 def test_fp32_auto_runs_winograd4_f32_and_matches_direct():
-    """precision='fp32' with conv_algo='auto' (the default) sends the 3x3 convolutions of images of at least 96 tiles to the float32 F(4,3)
+    """precision='fp32' with conv_algo='auto' (the default) sends the 3x3 convolutions with 256 output channels to the float32 F(4,3)
     kernel; 'direct' keeps the direct f32 kernel everywhere.  One full-width forward of each on G10's inputs: both inside the fp32
     tolerance against the reference, and within 2e-5 of each other (different summation orders of exact f32 products)."""
     import flowdec_amd
