@@ -68,11 +68,10 @@ int fd_wino4_init_attributes();
 bool fd_wino4_supported(int Cout, int C0, int C1, int S0, int S1, int ksize);
 bool fd_wino4_shape_ok(int H, int W);
 
-// conv_wino4f.hip (the same algorithm on f32 storage with f32 transforms, channel counts % 16 == 0: exact float32 on v_mfma_f32_32x32x2_f32,
-// or -- x3 -- split-bf16 operands, three v_mfma_f32_32x32x8_bf16 per product: FD_BF16X3_OPERANDS)
+// conv_wino4f.hip (the same algorithm in exact float32: f32 storage, v_mfma_f32_32x32x2_f32; channel counts % 16 == 0)
 long long fd_wino4f_packed_bytes(int Cout, int C0, int C1, int S0, int S1);
 int fd_wino4f_pack_weights(const float* w, const float* w_sc, void* packed, int Cout, int C0, int C1, int S0, int S1, hipStream_t st);
-int fd_wino4f_launch(fdconv::ConvArgs a, hipStream_t st, bool x3);
+int fd_wino4f_launch(fdconv::ConvArgs a, hipStream_t st);
 int fd_wino4f_init_attributes();
 bool fd_wino4f_supported(int Cout, int C0, int C1, int S0, int S1, int ksize);
 bool fd_wino4f_shape_ok(int H, int W);

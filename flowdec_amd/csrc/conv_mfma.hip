@@ -1250,8 +1250,7 @@ extern "C" int fd_conv_cout_pad(int Cout) { return cout_pad(Cout); }
 extern "C" int fd_conv_stats_tiles(int H, int W) { return fd_cdiv(H, 16) * fd_cdiv(W, 16); }
 
 extern "C" long long fd_conv_packed_bytes(int Cout, int C0, int C1, int ksize, int S0, int S1, int wdtype) {
-  if (wdtype == (FD_F32 | FD_WINOGRAD4) || wdtype == (FD_F32 | FD_BF16X3_OPERANDS | FD_WINOGRAD4))   // f32 weights: exact f32 or split in registers
-    return fd_wino4f_supported(Cout, C0, C1, S0, S1, ksize) ? fd_wino4f_packed_bytes(Cout, C0, C1, S0, S1) : 0;
+  if (wdtype == (FD_F32 | FD_WINOGRAD4)) return fd_wino4f_supported(Cout, C0, C1, S0, S1, ksize) ? fd_wino4f_packed_bytes(Cout, C0, C1, S0, S1) : 0;   // exact f32
   if (wdtype & FD_WINOGRAD4) return fd_wino4_supported(Cout, C0, C1, S0, S1, ksize) && (wdtype & 0xff) == FD_BF16 ? fd_wino4_packed_bytes(Cout, C0, C1, S0, S1) : 0;
   if (wdtype & FD_WINOGRAD) return fd_wino_supported(Cout, C0, C1, S0, S1, ksize) && (wdtype & 0xff) == FD_BF16 ? fd_wino_packed_bytes(Cout, C0, C1, S0, S1) : 0;
   if (wdtype == (FD_F32 | FD_BF16_OPERANDS)) wdtype = FD_BF16;   // weights follow the OPERAND type
@@ -1267,7 +1266,7 @@ extern "C" int fd_conv_pack_weights(const float* w, const float* w_sc, void* pac
   FD_REQUIRE(w && packed, "fd_conv_pack_weights: null pointer");
   FD_REQUIRE(ksize == 1 || ksize == 3, "fd_conv_pack_weights: ksize must be 1 or 3");
   FD_REQUIRE((S0 + S1 == 0) == (w_sc == nullptr), "fd_conv_pack_weights: shortcut weight / channel mismatch");
-  if (wdtype == (FD_F32 | FD_WINOGRAD4) || wdtype == (FD_F32 | FD_BF16X3_OPERANDS | FD_WINOGRAD4)) {   // F(4,3) on f32 storage (conv_wino4f.hip)
+  if (wdtype == (FD_F32 | FD_WINOGRAD4)) {   // F(4,3) in exact float32 (conv_wino4f.hip)
     FD_REQUIRE(fd_wino4f_supported(Cout, C0, C1, S0, S1, ksize), "fd_conv_pack_weights: FD_F32 | FD_WINOGRAD4 needs ksize 3, Cout == 256 and channel counts %% 16 == 0");
     return fd_wino4f_pack_weights(w, w_sc, packed, Cout, C0, C1, S0, S1, fd_stream(stream));
   }
@@ -1316,16 +1315,15 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   const bool wino = (dtype & FD_WINOGRAD) != 0, wino4 = (dtype & FD_WINOGRAD4) != 0;
   FD_REQUIRE(!(wino && wino4), "fd_conv2d: FD_WINOGRAD and FD_WINOGRAD4 exclude each other");
   const bool mixed = (dtype & FD_BF16_OPERANDS) != 0, split = (dtype & FD_BF16X3_OPERANDS) != 0;
-  FD_REQUIRE(!(mixed || split) || dtype == (FD_F32 | FD_BF16_OPERANDS) || dtype == (FD_F32 | FD_BF16X3_OPERANDS) ||
-                 (dtype & ~FD_TILE_REVERSED) == (FD_F32 | FD_BF16X3_OPERANDS | FD_WINOGRAD4),
-             "fd_conv2d: FD_BF16_OPERANDS / FD_BF16X3_OPERANDS go with FD_F32 storage and the default direct configuration (FD_BF16X3_OPERANDS also with FD_WINOGRAD4)");
+  FD_REQUIRE(!(mixed || split) || dtype == (FD_F32 | FD_BF16_OPERANDS) || dtype == (FD_F32 | FD_BF16X3_OPERANDS),
+             "fd_conv2d: FD_BF16_OPERANDS / FD_BF16X3_OPERANDS go with FD_F32 storage and the default direct configuration only");
   const bool reversed = (dtype & FD_TILE_REVERSED) != 0;
   FD_REQUIRE(!reversed || wino4, "fd_conv2d: FD_TILE_REVERSED goes with FD_WINOGRAD4 only");
   const int tile = dtype & FD_TILE_MASK;
   const int bn_hint = tile == FD_TILE_DUO128 ? -128 : (tile == FD_TILE_BN32 || tile == FD_TILE_BN32_CHUNK) ? 32 : (tile == FD_TILE_BN64 || tile == FD_TILE_BN64_CHUNK) ? 64 : tile == FD_TILE_BN128 ? 128 : 0;
   FD_REQUIRE(tile == 0 || bn_hint != 0 || tile == FD_TILE_PERSIST, "fd_conv2d: bad FD_TILE_* flag");
   dtype &= 0xff;
-  const bool wino4f = wino4 && dtype == FD_F32 && !mixed;   // F(4,3) on f32 storage (conv_wino4f.hip): exact float32, or split-bf16 operands (`split`)
+  const bool wino4f = wino4 && dtype == FD_F32 && !mixed && !split;   // F(4,3) in exact float32 (conv_wino4f.hip)
   FD_REQUIRE(!wino4f || (fd_wino4f_supported(Cout, C0, C1, S0, S1, ksize) && fd_wino4f_shape_ok(H, W)),
              "fd_conv2d: FD_F32 | FD_WINOGRAD4 needs ksize 3, Cout == 256, channel counts %% 16 == 0, H %% 16 == W %% 16 == 0");
   FD_REQUIRE(!wino4 || wino4f || (dtype == FD_BF16 && fd_wino4_supported(Cout, C0, C1, S0, S1, ksize) && fd_wino4_shape_ok(H, W)),
@@ -1362,7 +1360,7 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   FD_T2(a.dbg = g_dbg;)
   FD_REQUIRE(a.w_bytes < (1ll << 31), "fd_conv2d: packed weights exceed 2 GiB");
   FD_REQUIRE(affine == nullptr || (C0 + C1) * 8 <= AFF_BYTES, "fd_conv2d: at most %d activated input channels", AFF_BYTES / 8);
-  if (wino4f) return fd_wino4f_launch(a, fd_stream(stream), split);
+  if (wino4f) return fd_wino4f_launch(a, fd_stream(stream));
   if (wino4) return fd_wino4_launch(a, fd_stream(stream));
   if (wino) return fd_wino_launch(a, fd_stream(stream));
   if (mixed) return dispatch_conv_mixed(a, fd_stream(stream));

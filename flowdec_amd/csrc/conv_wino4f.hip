@@ -14,9 +14,6 @@
 //   * conversion and transform in f32 (no fp16 range, no saturation, no per-cout weight scale: the table holds ones);
 //   * the folded 1x1 shortcut (E2) is an f32 GEMM on the raw f32 shortcut input; the residual input arrives as 2 x 16 bytes per
 //     thread and pass through ONE LDS buffer; the output sweep stores 2 x 16 bytes per lane.
-// X3 = true: the same kernel with SPLIT-bf16 operands on the bf16 matrix cores (precision 'bf16x3': f32 storage, f32 transforms; every
-// fragment quad -- 4 floats per lane -- is split in registers into hi = bf16(x), lo = bf16(x - hi) and one v_mfma_f32_32x32x16_f16-class
-// product becomes hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x8_bf16, whose lane layout (k = 4 lh + i) is exactly a quad).
 // Error against the f64 convolution: ~1e-6 (the transforms' |B^T| row sums of 10 and |A^T| of up to 8 on f32 roundings).
 #include <type_traits>
 
@@ -29,7 +26,6 @@ using namespace fdconv;
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
@@ -84,18 +80,7 @@ __device__ __forceinline__ void glds16s_x2(const void* sbase, unsigned voff, uns
                : "memory");
 }
 
-// one fragment quad (4 floats) -> hi = bf16(x) (round to nearest even), lo = bf16(x - hi): x = hi + lo to 16 mantissa bits
-struct SplitQuad { s16x4 hi, lo; };
-__device__ __forceinline__ SplitQuad split_quad(const u32x4& q) {
-  const unsigned u0 = q[0], u1 = q[1], u2 = q[2], u3 = q[3];   // (vector element -> scalar first: see mma)
-  const float f0 = __builtin_bit_cast(float, u0), f1 = __builtin_bit_cast(float, u1), f2 = __builtin_bit_cast(float, u2), f3 = __builtin_bit_cast(float, u3);
-  const bf16x2 h01 = {(bf16)f0, (bf16)f1}, h23 = {(bf16)f2, (bf16)f3};
-  const bf16x2 l01 = {(bf16)(f0 - (float)h01[0]), (bf16)(f1 - (float)h01[1])}, l23 = {(bf16)(f2 - (float)h23[0]), (bf16)(f3 - (float)h23[1])};
-  const u32x2 hu = {__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)}, lu = {__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
-  return SplitQuad{__builtin_bit_cast(s16x4, hu), __builtin_bit_cast(s16x4, lu)};
-}
-
-template <bool ACT, bool SKIP, bool SC, bool X3>
+template <bool ACT, bool SKIP, bool SC>
 __global__ __launch_bounds__(NTH, 2) void conv_wino4f_kernel(ConvArgs p) {
   static_assert(!(SKIP && SC), "residual input and folded shortcut exclude each other in this kernel");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -295,11 +280,6 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4f_kernel(ConvArgs p) {
       acc[xl][ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, ua), __builtin_bit_cast(float, ub), acc[xl][ct][nt], 0, 0, 0);
     }
   };
-  auto mma3 = [&](int xl, int ct, int nt, const SplitQuad& a, const SplitQuad& bq) {   // X3: hi.hi + hi.lo + lo.hi on the bf16 matrix cores
-    acc[xl][ct][nt] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a.hi, bq.hi, acc[xl][ct][nt], 0, 0, 0);
-    acc[xl][ct][nt] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a.hi, bq.lo, acc[xl][ct][nt], 0, 0, 0);
-    acc[xl][ct][nt] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a.lo, bq.hi, acc[xl][ct][nt], 0, 0, 0);
-  };
   auto rd = [&](int off) { return *reinterpret_cast<const u32x4*>(smem + off); };
   // LDS offsets of the fragments of step k18 (0..17 inside the chunk pair; 18 = step 0 of the next pair)
   auto a_off = [&](int k18, int ct) { return wa_lane + (k18 % NRING) * RSLOT + ct * 1024; };
@@ -365,25 +345,16 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4f_kernel(ConvArgs p) {
       A2 = rd(a_off(k + 1, 0));
       B2 = rd(b_off(k + 1, 0));
       __builtin_amdgcn_sched_barrier(0);
-      SplitQuad sa, sb0, sb1;   // (X3 only) the step's split quads: each fragment is split once and used twice
-      if constexpr (X3) {
-        sa = split_quad(A0); sb0 = split_quad(B0); sb1 = split_quad(B1);
-        mma3(xl, 0, 0, sa, sb0);
-        mma3(xl, 0, 1, sa, sb1);
-      } else {
-        mma(xl, 0, 0, A0, B0);
-        mma(xl, 0, 1, A0, B1);
-      }
+      mma(xl, 0, 0, A0, B0);
+      mma(xl, 0, 1, A0, B1);
       __builtin_amdgcn_sched_barrier(0);
       A0 = rd(a_off(k + 1, 1));
-      if constexpr (X3) { sa = split_quad(A1); mma3(xl, 1, 0, sa, sb0); }
-      else mma(xl, 1, 0, A1, B0);
+      mma(xl, 1, 0, A1, B0);
       __builtin_amdgcn_sched_barrier(0);
       B0 = rd(b_off(k + 1, 1));
       if (s == 3) { next_chunk(); if (half == 0) load_halo(); }   // (after the barrier of this step: every conversion of the previous pair is done)
       dma_step(k + NRING, k % NRING);              // step s + 6 into the slot whose fragments have both arrived
-      if constexpr (X3) mma3(xl, 1, 1, sa, sb1);
-      else mma(xl, 1, 1, A1, B1);
+      mma(xl, 1, 1, A1, B1);
       __builtin_amdgcn_sched_barrier(0);
       // the chunk's vector work, while the quads A1 / B1 are dead
       // (step 8 converts the chunk two ahead: same parity as the current one; steps 0 .. 2 the next chunk: the other parity)
@@ -681,20 +652,13 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino4f_kernel(ConvArgs p) {
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-              if constexpr (X3) {
-                const SplitQuad w0 = split_quad(af[kk][0]), w1 = split_quad(af[kk][1]), xq = split_quad(bq[kk][pl][nt]);
-                mma3(pl, 0, nt, w0, xq);
-                mma3(pl, 1, nt, w1, xq);
-              } else {
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                  const unsigned u0 = af[kk][0][j], u1 = af[kk][1][j], ub = bq[kk][pl][nt][j];   // (element -> scalar first)
-                  acc[pl][0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, u0), __builtin_bit_cast(float, ub), acc[pl][0][nt], 0, 0, 0);
-                  acc[pl][1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, u1), __builtin_bit_cast(float, ub), acc[pl][1][nt], 0, 0, 0);
-                }
+              for (int j = 0; j < 4; ++j) {
+                const unsigned u0 = af[kk][0][j], u1 = af[kk][1][j], ub = bq[kk][pl][nt][j];   // (element -> scalar first)
+                acc[pl][0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, u0), __builtin_bit_cast(float, ub), acc[pl][0][nt], 0, 0, 0);
+                acc[pl][1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, u1), __builtin_bit_cast(float, ub), acc[pl][1][nt], 0, 0, 0);
               }
-            }
         __builtin_amdgcn_sched_barrier(0);
         slot = slot + 1 == SCD ? 0 : slot + 1;
       }
@@ -840,31 +804,28 @@ int fd_wino4f_pack_weights(const float* w, const float* w_sc, void* packed, int 
 }
 
 namespace {
-template <bool ACT, bool X3>
+template <bool ACT>
 int set_attr4() {
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4f_kernel<ACT, false, false, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4f_kernel<ACT, true, false, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4f_kernel<ACT, false, true, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4f_kernel<ACT, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4f_kernel<ACT, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4f_kernel<ACT, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   return FD_OK;
 }
-template <bool ACT, bool X3>
+template <bool ACT>
 void launch4(const ConvArgs& a, bool sc, dim3 grid, dim3 block, hipStream_t st) {
-  if (sc) hipLaunchKernelGGL((conv_wino4f_kernel<ACT, false, true, X3>), grid, block, LDS_BYTES, st, a);
-  else if (a.skip) hipLaunchKernelGGL((conv_wino4f_kernel<ACT, true, false, X3>), grid, block, LDS_BYTES, st, a);
-  else hipLaunchKernelGGL((conv_wino4f_kernel<ACT, false, false, X3>), grid, block, LDS_BYTES, st, a);
+  if (sc) hipLaunchKernelGGL((conv_wino4f_kernel<ACT, false, true>), grid, block, LDS_BYTES, st, a);
+  else if (a.skip) hipLaunchKernelGGL((conv_wino4f_kernel<ACT, true, false>), grid, block, LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((conv_wino4f_kernel<ACT, false, false>), grid, block, LDS_BYTES, st, a);
 }
 }  // namespace
 
 int fd_wino4f_init_attributes() {
-  FD_TRY((set_attr4<false, false>()));
-  FD_TRY((set_attr4<true, false>()));
-  FD_TRY((set_attr4<false, true>()));
-  FD_TRY((set_attr4<true, true>()));
+  FD_TRY(set_attr4<false>());
+  FD_TRY(set_attr4<true>());
   return FD_OK;
 }
 
-// x3: split-bf16 operands (FD_BF16X3_OPERANDS) instead of the exact f32 matrix instruction; same packed weights, same tensors
-int fd_wino4f_launch(ConvArgs a, hipStream_t st, bool x3) {
+int fd_wino4f_launch(ConvArgs a, hipStream_t st) {
   FD_REQUIRE(fd_wino4f_shape_ok(a.H, a.W), "fd_conv2d: FD_WINOGRAD4 (f32) needs H %% 16 == 0 and W %% 16 == 0 (got %d x %d)", a.H, a.W);
   bool sc = false;
   for (int s = 0; s < a.nseg; ++s) sc = sc || a.seg[s].taps == 1;
@@ -878,13 +839,8 @@ int fd_wino4f_launch(ConvArgs a, hipStream_t st, bool x3) {
   const long long nblk = (long long)a.B * a.tiles_h * a.tiles_w;
   FD_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
   const dim3 grid((unsigned)nblk), block(NTH);
-  if (x3) {
-    if (a.affine) launch4<true, true>(a, sc, grid, block, st);
-    else launch4<false, true>(a, sc, grid, block, st);
-  } else {
-    if (a.affine) launch4<true, false>(a, sc, grid, block, st);
-    else launch4<false, false>(a, sc, grid, block, st);
-  }
+  if (a.affine) launch4<true>(a, sc, grid, block, st);
+  else launch4<false>(a, sc, grid, block, st);
   FD_LAUNCH_CHECK();
   return FD_OK;
 }

@@ -355,8 +355,7 @@ struct Fwd {
     // fp32 mode (pure f32: storage, operands, exact f32 MFMA): F(4,3) in float32 (conv_wino4f.hip) wherever its shape rules hold (Cout = 256,
     // whole 16 x 16 tiles, >= 64 input channels) -- the f32 matrix instruction is 16 x slower than the fp16 one, the launch is MFMA-bound at
     // any grid size, and both kernels use one 256-cout workgroup per tile: halving the MFMAs is worth 1.6-1.9 x per launch.  By shape only.
-    // bf16x3 mode (f32 storage, split-bf16 operands): the same kernel with three v_mfma_f32_32x32x8_bf16 per product instead of four f32 ones.
-    const bool autosel_f32 = m && (m->cfg.act_dtype & FD_WINOGRAD_AUTO) && dt == FD_F32 && (opflag == 0 || opflag == FD_BF16X3_OPERANDS);
+    const bool autosel_f32 = m && (m->cfg.act_dtype & FD_WINOGRAD_AUTO) && dt == FD_F32 && opflag == 0;
     if (latency && px_tiles <= 24 && out.C >= 64) tile = FD_TILE_BN32_CHUNK;
     else if (autosel && px_tiles <= 16 && out.C >= 64) tile = FD_TILE_BN64_CHUNK;   // the 96 x 32 level: 18.5 us vs 22.6 (Winograd) at 8 clips, 17.1 vs 21.9 at one
     // (never with a folded 1x1 shortcut: its input is the UN-NORMALISED residual stream, which the Winograd kernel would narrow to
@@ -784,15 +783,14 @@ extern "C" int fd_model_create(const fd_model_config* cfg, fd_model** out) {
   FD_REQUIRE(cfg->num_levels >= 1 && cfg->num_levels <= 8 && cfg->num_res_blocks >= 1, "fd_model_create: bad level / block counts");
   const int act_nos = cfg->act_dtype & ~FD_NO_SIDE_STREAM;
   FD_REQUIRE(((act_nos & 0xff) == FD_BF16 && !(act_nos & (FD_BF16_OPERANDS | FD_BF16X3_OPERANDS))) || act_nos == FD_F32 || act_nos == (FD_F32 | FD_WINOGRAD_AUTO) ||
-                 act_nos == (FD_F32 | FD_BF16_OPERANDS) || act_nos == (FD_F32 | FD_BF16X3_OPERANDS) || act_nos == (FD_F32 | FD_BF16X3_OPERANDS | FD_WINOGRAD_AUTO),
+                 act_nos == (FD_F32 | FD_BF16_OPERANDS) || act_nos == (FD_F32 | FD_BF16X3_OPERANDS),
              "fd_model_create: act_dtype must be FD_BF16 [| FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY], FD_F32 [| FD_WINOGRAD_AUTO], "
-             "FD_F32 | FD_BF16_OPERANDS or FD_F32 | FD_BF16X3_OPERANDS [| FD_WINOGRAD_AUTO]");
+             "FD_F32 | FD_BF16_OPERANDS or FD_F32 | FD_BF16X3_OPERANDS");
   {
     const int algo = cfg->act_dtype & (FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY);
     FD_REQUIRE((algo & (algo - 1)) == 0, "fd_model_create: at most one of FD_WINOGRAD / FD_WINOGRAD_LOWRES / FD_WINOGRAD_AUTO / FD_LOW_LATENCY (got 0x%x)", algo);
-    FD_REQUIRE(algo == 0 || (cfg->act_dtype & 0xff) == FD_BF16 || (algo == FD_WINOGRAD_AUTO && (act_nos == (FD_F32 | FD_WINOGRAD_AUTO) || act_nos == (FD_F32 | FD_BF16X3_OPERANDS | FD_WINOGRAD_AUTO))),
-               "fd_model_create: the convolution-algorithm flags go with FD_BF16 storage (FD_WINOGRAD_AUTO also with FD_F32 and FD_F32 | FD_BF16X3_OPERANDS: "
-               "F(4,3) on f32 storage)");
+    FD_REQUIRE(algo == 0 || (cfg->act_dtype & 0xff) == FD_BF16 || (algo == FD_WINOGRAD_AUTO && act_nos == (FD_F32 | FD_WINOGRAD_AUTO)),
+               "fd_model_create: the convolution-algorithm flags go with FD_BF16 storage (FD_WINOGRAD_AUTO also with pure FD_F32: F(4,3) in float32)");
     FD_REQUIRE((cfg->act_dtype & FD_TILE_MASK) == 0, "fd_model_create: FD_TILE_* selects the workgroup width of ONE fd_conv2d launch, not of a model");
     FD_REQUIRE((cfg->act_dtype & ~(0xff | FD_WINOGRAD | FD_WINOGRAD_LOWRES | FD_WINOGRAD_AUTO | FD_LOW_LATENCY | FD_BF16_OPERANDS | FD_BF16X3_OPERANDS |
                                   FD_NO_SIDE_STREAM)) == 0, "fd_model_create: unknown bits in act_dtype (0x%x)", cfg->act_dtype);

@@ -113,10 +113,9 @@ class NCSNpp(nn.Module):
                              "(f32 storage, two-term bf16 split operands: f32-mode tolerances on the bf16 matrix cores)")
         if conv_algo not in CONV_ALGOS or (conv_algo not in ("direct", "auto") and precision != "bf16"):
             raise ValueError(f"conv_algo must be one of {sorted(CONV_ALGOS)} (precision != 'bf16': 'direct' or 'auto' only)")
-        if precision == "mixed":
-            conv_algo = "direct"   # 'auto' = best available: the mixed operand mode has the direct kernel only
-        # precision='fp32' / 'bf16x3' + 'auto': Winograd F(4,3) on f32 storage (conv_wino4f.hip: exact float32, or split-bf16 operands) for every
-        # 3x3 layer with 256 output channels on whole 16 x 16 tiles
+        if precision in ("mixed", "bf16x3"):
+            conv_algo = "direct"   # 'auto' = best available: the split / mixed operand modes have the direct kernel only
+        # precision='fp32' + 'auto': Winograd F(4,3) in exact float32 (conv_wino4f.hip) for every 3x3 layer with 256 output channels on whole 16 x 16 tiles
         self.nf, self.ch_mult, self.num_res_blocks, self.precision, self.conv_algo = nf, ch_mult, num_res_blocks, precision, conv_algo
         self.num_resolutions = len(ch_mult)
         self.output_layer = nn.Conv2d(num_channels, 2, kernel_size=1, bias=False)
@@ -167,8 +166,7 @@ class NCSNpp(nn.Module):
         cfg.n_fft, cfg.hop = self._stft_cfg["n_fft"], self._stft_cfg["hop"]
         cfg.alpha, cfg.beta = self._stft_cfg["alpha"], self._stft_cfg["beta"]
         cfg.act_dtype = (L.FD_BF16 | CONV_ALGOS[self.conv_algo]) if self.precision == "bf16" else \
-            (L.FD_F32 | {"mixed": L.FD_BF16_OPERANDS, "bf16x3": L.FD_BF16X3_OPERANDS | CONV_ALGOS[self.conv_algo],
-                          "fp32": CONV_ALGOS[self.conv_algo]}[self.precision])
+            (L.FD_F32 | {"mixed": L.FD_BF16_OPERANDS, "bf16x3": L.FD_BF16X3_OPERANDS, "fp32": CONV_ALGOS[self.conv_algo]}[self.precision])
         if not self.side_stream:
             cfg.act_dtype |= L.FD_NO_SIDE_STREAM
         return cfg

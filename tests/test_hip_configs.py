@@ -569,65 +569,6 @@ def test_conv2d_winograd4_f32(case):
     assert rel_err(from_nhwc(out), from_nhwc(outd)) < 5e-6
 
 
-@pytest.mark.parametrize("case", [c for c in WINO4_CASES if c[0] in ("basic", "aff_bias_skip", "deepk", "multi_tile", "cat320", "shortcut", "shortcut_cat")],
-                         ids=lambda c: c[0])
-def test_conv2d_winograd4_bf16x3(case):
-    """The float32-storage F(4,3) kernel with SPLIT-bf16 operands (conv_wino4f.hip, X3: precision 'bf16x3' with conv_algo 'auto'): every
-    fragment quad is split in registers into hi + lo bf16 and a product is hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x8_bf16.  The split
-    happens AFTER the Winograd transforms (|B^T| rows sum to 10, |A^T| up to 8), so its 2^-17 relative error per operand is amplified
-    against the direct split kernel's 2-3e-6: tolerance 1e-4 against the f64 convolution of the same f32 tensors (measured: see the
-    parity report), bit-deterministic, and 1e-4 from the direct split kernel."""
-    from flowdec_amd import ops
-    import zlib
-    name, B, H, W, C0, C1, Cout, use_aff, bias_rows, use_skip, S0, S1 = case
-    rng = np.random.default_rng(zlib.crc32(("w4x3" + name).encode()))
-    Cin = C0 + C1
-    f32 = torch.float32
-    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
-    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
-    aff, xin = None, x.astype(np.float64)
-    if use_aff:
-        a = (1 + 0.2 * rng.standard_normal((B, Cin))).astype(np.float32)
-        d = (0.3 * rng.standard_normal((B, Cin))).astype(np.float32)
-        aff = dev(np.stack([a, d], axis=-1))
-        u = x.astype(np.float64) * a[:, :, None, None] + d[:, :, None, None]
-        xin = u / (1.0 + np.exp(-u))
-    ref = O.conv2d(xin, w.astype(np.float64), None)
-    sc0 = sc1 = w_sc = None
-    if S0:
-        xs = rng.standard_normal((B, S0 + S1, H, W)).astype(np.float32)
-        ws = (rng.standard_normal((Cout, S0 + S1, 1, 1)) / np.sqrt(S0 + S1)).astype(np.float32)
-        ref = ref + O.conv2d(xs.astype(np.float64), ws.astype(np.float64), None)
-        sc0 = nhwc(xs[:, :S0], f32)
-        sc1 = nhwc(xs[:, S0:], f32) if S1 else None
-        w_sc = dev(ws)
-    bias = None
-    if bias_rows:
-        bv = rng.standard_normal((bias_rows, Cout)).astype(np.float32)
-        bias = dev(bv if bias_rows > 1 else bv[0])
-        ref = ref + (bv[:, :, None, None] if bias_rows > 1 else bv[0][None, :, None, None])
-    skip, scale = None, 1.0
-    if use_skip:
-        sk = rng.standard_normal((B, Cout, H, W)).astype(np.float32)
-        skip = nhwc(sk, f32)
-        ref = ref + sk
-        scale = float(1 / np.sqrt(2))
-    ref = ref * scale
-    x0 = nhwc(x[:, :C0], f32)
-    x1 = nhwc(x[:, C0:], f32) if C1 else None
-    pw = ops.pack_conv_weight(dev(w), C0=C0, dtype=f32, w_sc=w_sc, S0=S0 if S0 else None, winograd=4, bf16_operands="x3")
-    kw = dict(x1=x1, affine=aff, bias=bias, skip=skip, scale=scale, sc0=sc0, sc1=sc1, want_stats=True, bf16_operands="x3")
-    out, stats = ops.conv2d(x0, pw, Cout, 3, winograd=4, **kw)
-    torch.cuda.synchronize()
-    check(f"conv2d_winograd4_bf16x3[{name}]", from_nhwc(out), ref, 1e-4)
-    out2, stats2 = ops.conv2d(x0, pw, Cout, 3, winograd=4, **kw)
-    assert torch.equal(out, out2) and torch.equal(stats, stats2)
-    pd = ops.pack_conv_weight(dev(w), C0=C0, dtype=f32, w_sc=w_sc, S0=S0 if S0 else None, bf16_operands="x3")
-    outd, _ = ops.conv2d(x0, pd, Cout, 3, **kw)
-    report(f"conv2d_direct_bf16x3[{name}]", rel_err(from_nhwc(outd), ref), 1e-4)
-    assert rel_err(from_nhwc(out), from_nhwc(outd)) < 1e-4
-
-
 def test_fp32_auto_runs_winograd4_f32_and_matches_direct():
     """precision='fp32' with conv_algo='auto' (the default) sends the 3x3 convolutions with 256 output channels to the float32 F(4,3)
     kernel; 'direct' keeps the direct f32 kernel everywhere.  One full-width forward of each on G10's inputs: both inside the fp32
