@@ -16,6 +16,7 @@ FD_F32, FD_BF16 = 0, 1
 FD_WINOGRAD = 0x100  # algorithm flag OR-ed into a dtype argument (include/flowdec_hip.h)
 FD_WINOGRAD4 = 0x80000  # Winograd F(4,3) along W, 256-cout workgroups (conv_wino4.hip)
 FD_TILE_REVERSED = 0x100000  # with FD_WINOGRAD4: tiles in descending order (same bits)
+FD_WINOGRAD44 = 0x200000  # with FD_F32: 2-D Winograd F(4x4, 3x3) in exact float32 (conv_wino44f.hip)
 FD_WINOGRAD_LOWRES = 0x200
 FD_WINOGRAD_AUTO = 0x400
 FD_LOW_LATENCY = 0x800

@@ -76,6 +76,13 @@ int fd_wino4f_init_attributes();
 bool fd_wino4f_supported(int Cout, int C0, int C1, int S0, int S1, int ksize);
 bool fd_wino4f_shape_ok(int H, int W);
 
+// conv_wino44f.hip (2-D Winograd F(4x4, 3x3) in exact float32: 128-cout workgroups, whole 16 x 16 tiles, channel counts % 8 == 0)
+long long fd_wino44f_packed_bytes(int Cout, int C0, int C1, int S0, int S1);
+int fd_wino44f_pack_weights(const float* w, const float* w_sc, void* packed, int Cout, int C0, int C1, int S0, int S1, hipStream_t st);
+int fd_wino44f_launch(fdconv::ConvArgs a, hipStream_t st);
+bool fd_wino44f_supported(int Cout, int C0, int C1, int S0, int S1, int ksize);
+bool fd_wino44f_shape_ok(int H, int W);
+
 // conv_head.hip (Cout = 4 pyramid heads, bf16)
 bool fd_head_supported(const fdconv::ConvArgs& a, int ksize, int dtype);
 int fd_head_launch(fdconv::ConvArgs a, hipStream_t st);

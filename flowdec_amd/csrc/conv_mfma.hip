@@ -1250,6 +1250,7 @@ extern "C" int fd_conv_cout_pad(int Cout) { return cout_pad(Cout); }
 extern "C" int fd_conv_stats_tiles(int H, int W) { return fd_cdiv(H, 16) * fd_cdiv(W, 16); }
 
 extern "C" long long fd_conv_packed_bytes(int Cout, int C0, int C1, int ksize, int S0, int S1, int wdtype) {
+  if (wdtype == (FD_F32 | FD_WINOGRAD44)) return fd_wino44f_supported(Cout, C0, C1, S0, S1, ksize) ? fd_wino44f_packed_bytes(Cout, C0, C1, S0, S1) : 0;   // 2-D, exact f32
   if (wdtype == (FD_F32 | FD_WINOGRAD4)) return fd_wino4f_supported(Cout, C0, C1, S0, S1, ksize) ? fd_wino4f_packed_bytes(Cout, C0, C1, S0, S1) : 0;   // exact f32
   if (wdtype & FD_WINOGRAD4) return fd_wino4_supported(Cout, C0, C1, S0, S1, ksize) && (wdtype & 0xff) == FD_BF16 ? fd_wino4_packed_bytes(Cout, C0, C1, S0, S1) : 0;
   if (wdtype & FD_WINOGRAD) return fd_wino_supported(Cout, C0, C1, S0, S1, ksize) && (wdtype & 0xff) == FD_BF16 ? fd_wino_packed_bytes(Cout, C0, C1, S0, S1) : 0;
@@ -1266,6 +1267,10 @@ extern "C" int fd_conv_pack_weights(const float* w, const float* w_sc, void* pac
   FD_REQUIRE(w && packed, "fd_conv_pack_weights: null pointer");
   FD_REQUIRE(ksize == 1 || ksize == 3, "fd_conv_pack_weights: ksize must be 1 or 3");
   FD_REQUIRE((S0 + S1 == 0) == (w_sc == nullptr), "fd_conv_pack_weights: shortcut weight / channel mismatch");
+  if (wdtype == (FD_F32 | FD_WINOGRAD44)) {   // 2-D F(4x4, 3x3) in exact float32 (conv_wino44f.hip)
+    FD_REQUIRE(fd_wino44f_supported(Cout, C0, C1, S0, S1, ksize), "fd_conv_pack_weights: FD_F32 | FD_WINOGRAD44 needs ksize 3, Cout %% 128 == 0 and channel counts %% 8 == 0");
+    return fd_wino44f_pack_weights(w, w_sc, packed, Cout, C0, C1, S0, S1, fd_stream(stream));
+  }
   if (wdtype == (FD_F32 | FD_WINOGRAD4)) {   // F(4,3) in exact float32 (conv_wino4f.hip)
     FD_REQUIRE(fd_wino4f_supported(Cout, C0, C1, S0, S1, ksize), "fd_conv_pack_weights: FD_F32 | FD_WINOGRAD4 needs ksize 3, Cout == 256 and channel counts %% 16 == 0");
     return fd_wino4f_pack_weights(w, w_sc, packed, Cout, C0, C1, S0, S1, fd_stream(stream));
@@ -1312,8 +1317,9 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
                          float scale, void* out, int Cout, float* stats, int B, int H, int W, int ksize, int dtype, void* stream) {
   FD_REQUIRE(in0 && packed_w && out, "fd_conv2d: null pointer");
   FD_REQUIRE(ksize == 1 || ksize == 3, "fd_conv2d: ksize must be 1 or 3 (got %d)", ksize);
-  const bool wino = (dtype & FD_WINOGRAD) != 0, wino4 = (dtype & FD_WINOGRAD4) != 0;
-  FD_REQUIRE(!(wino && wino4), "fd_conv2d: FD_WINOGRAD and FD_WINOGRAD4 exclude each other");
+  const bool wino = (dtype & FD_WINOGRAD) != 0, wino4 = (dtype & FD_WINOGRAD4) != 0, wino44 = (dtype & FD_WINOGRAD44) != 0;
+  FD_REQUIRE(!(wino && wino4) && !(wino44 && (wino || wino4)), "fd_conv2d: FD_WINOGRAD, FD_WINOGRAD4 and FD_WINOGRAD44 exclude each other");
+  FD_REQUIRE(!wino44 || dtype == (FD_F32 | FD_WINOGRAD44), "fd_conv2d: FD_WINOGRAD44 goes with pure FD_F32 (no operand / tile flags)");
   const bool mixed = (dtype & FD_BF16_OPERANDS) != 0, split = (dtype & FD_BF16X3_OPERANDS) != 0;
   FD_REQUIRE(!(mixed || split) || dtype == (FD_F32 | FD_BF16_OPERANDS) || dtype == (FD_F32 | FD_BF16X3_OPERANDS),
              "fd_conv2d: FD_BF16_OPERANDS / FD_BF16X3_OPERANDS go with FD_F32 storage and the default direct configuration only");
@@ -1354,12 +1360,17 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   if (S1) a.seg[ns++] = Seg{sc1, S1, -1, 1};
   a.nseg = ns;
   a.affine = affine; a.affC = C0 + C1;
-  a.w = packed_w; a.w_bytes = fd_conv_packed_bytes(Cout, C0, C1, ksize, S0, S1, dtype | (wino ? FD_WINOGRAD : 0) | (wino4 ? FD_WINOGRAD4 : 0) | (mixed ? FD_BF16_OPERANDS : 0) | (split ? FD_BF16X3_OPERANDS : 0));
+  a.w = packed_w; a.w_bytes = fd_conv_packed_bytes(Cout, C0, C1, ksize, S0, S1, dtype | (wino ? FD_WINOGRAD : 0) | (wino4 ? FD_WINOGRAD4 : 0) | (wino44 ? FD_WINOGRAD44 : 0) | (mixed ? FD_BF16_OPERANDS : 0) | (split ? FD_BF16X3_OPERANDS : 0));
   a.bias = bias; a.bias_rows = bias_rows; a.skip = skip; a.scale = scale; a.out = out; a.Cout = Cout; a.CoutPad = cout_pad(Cout);
   a.stats = stats; a.B = B; a.H = H; a.W = W; a.reversed = reversed ? 1 : 0;
   FD_T2(a.dbg = g_dbg;)
   FD_REQUIRE(a.w_bytes < (1ll << 31), "fd_conv2d: packed weights exceed 2 GiB");
   FD_REQUIRE(affine == nullptr || (C0 + C1) * 8 <= AFF_BYTES, "fd_conv2d: at most %d activated input channels", AFF_BYTES / 8);
+  if (wino44) {
+    FD_REQUIRE(fd_wino44f_supported(Cout, C0, C1, S0, S1, ksize) && fd_wino44f_shape_ok(H, W),
+               "fd_conv2d: FD_F32 | FD_WINOGRAD44 needs ksize 3, Cout %% 128 == 0, channel counts %% 8 == 0, H %% 16 == W %% 16 == 0");
+    return fd_wino44f_launch(a, fd_stream(stream));
+  }
   if (wino4f) return fd_wino4f_launch(a, fd_stream(stream));
   if (wino4) return fd_wino4_launch(a, fd_stream(stream));
   if (wino) return fd_wino_launch(a, fd_stream(stream));

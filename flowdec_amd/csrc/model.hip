@@ -30,6 +30,7 @@ struct Mod {
   bool wino0 = false, wino1 = false;   // Conv_0 / Conv_1 (+ folded Conv_2) packed for the Winograd kernel
   void* w0w = nullptr; void* w1w = nullptr;   // FD_WINOGRAD_AUTO: second (Winograd) packing next to the direct one in w0 / w1
   void* w0w4 = nullptr; void* w1w4 = nullptr; // FD_WINOGRAD_AUTO: third packing, for the F(4,3) kernel (conv_wino4.hip), where its shape rules allow
+  void* w0w44 = nullptr; void* w1w44 = nullptr; // FD_F32 | FD_WINOGRAD_AUTO: packing for the 2-D F(4x4, 3x3) float32 kernel (conv_wino44f.hip)
   // device pointers (filled by finalize)
   void* w0 = nullptr; void* w1 = nullptr; void* w2 = nullptr;   // packed conv weights
   float *gn0_g = nullptr, *gn0_b = nullptr, *gn1_g = nullptr, *gn1_b = nullptr;
@@ -344,9 +345,9 @@ struct Fwd {
   // 128-channel workgroups up to 128 tiles; above 128 tiles everything runs the F(4,3) kernel.  By image size only.
   int conv(const Tens& a, const Tens* b, size_t aff, const Tens* s0, const Tens* s1, const void* w, const float* bias, int bias_rows,
            const Tens* skip, float scale, Tens& out, int ks, bool want_stats, bool wino = false, const void* w_wino = nullptr,
-           const void* w_wino4 = nullptr) {
+           const void* w_wino4 = nullptr, const void* w_wino44 = nullptr) {
     int tile = 0;
-    bool wino4 = false;
+    bool wino4 = false, wino44 = false;
     int order = 0;
     const int opflag = m ? (m->cfg.act_dtype & (FD_BF16_OPERANDS | FD_BF16X3_OPERANDS)) : 0;
     const int px_tiles = fd_cdiv(out.H, 16) * fd_cdiv(out.W, 16);
@@ -356,7 +357,10 @@ struct Fwd {
     // whole 16 x 16 tiles, >= 64 input channels) -- the f32 matrix instruction is 16 x slower than the fp16 one, the launch is MFMA-bound at
     // any grid size, and both kernels use one 256-cout workgroup per tile: halving the MFMAs is worth 1.6-1.9 x per launch.  By shape only.
     const bool autosel_f32 = m && (m->cfg.act_dtype & FD_WINOGRAD_AUTO) && dt == FD_F32 && opflag == 0;
-    if (latency && px_tiles <= 24 && out.C >= 64) tile = FD_TILE_BN32_CHUNK;
+    // fp32 mode: 2-D Winograd F(4x4, 3x3) in float32 (conv_wino44f.hip: a quarter of the direct kernel's MFMAs) wherever its shape rules hold
+    // (Cout % 128 == 0, whole 16 x 16 tiles, channel counts % 8 == 0); the matrix pipe bounds the launch at any grid size.  By shape only.
+    if (m && (m->cfg.act_dtype & FD_WINOGRAD_AUTO) && dt == FD_F32 && opflag == 0 && w_wino44 && out.H % 16 == 0 && out.W % 16 == 0) { w = w_wino44; wino44 = true; }
+    else if (latency && px_tiles <= 24 && out.C >= 64) tile = FD_TILE_BN32_CHUNK;
     else if (autosel && px_tiles <= 16 && out.C >= 64) tile = FD_TILE_BN64_CHUNK;   // the 96 x 32 level: 18.5 us vs 22.6 (Winograd) at 8 clips, 17.1 vs 21.9 at one
     // (never with a folded 1x1 shortcut: its input is the UN-NORMALISED residual stream, which the Winograd kernel would narrow to
     // the fp16 range; GroupNorm+SiLU outputs and their FIR-resampled versions are bounded)
@@ -396,7 +400,7 @@ struct Fwd {
     const int rc = fd_conv2d(ptr(a.off), a.C, b ? ptr(b->off) : nullptr, b ? b->C : 0, aff == (size_t)-1 ? nullptr : (const float*)ptr(aff),
                              s0 ? ptr(s0->off) : nullptr, s0 ? s0->C : 0, s1 ? ptr(s1->off) : nullptr, s1 ? s1->C : 0, w, bias, bias_rows,
                              skip ? ptr(skip->off) : nullptr, scale, ptr(out.off), out.C, want_stats ? (float*)ptr(out.sums) : nullptr, B,
-                             out.H, out.W, ks, dt | (wino ? FD_WINOGRAD : 0) | (wino4 ? FD_WINOGRAD4 : 0) | order | tile | opflag, st);
+                             out.H, out.W, ks, dt | (wino ? FD_WINOGRAD : 0) | (wino4 ? FD_WINOGRAD4 : 0) | (wino44 ? FD_WINOGRAD44 : 0) | order | tile | opflag, st);
     if (m && m->profiling) {
       FD_HIP(hipEventRecord(m->ev[m->ev_used].second, st));
       ++m->ev_used;
@@ -404,7 +408,8 @@ struct Fwd {
                        ((a.C + (b ? b->C : 0)) * ks * ks + (s0 ? s0->C : 0) + (s1 ? s1->C : 0));
       const double cin = a.C + (b ? b->C : 0), csc = (s0 ? s0->C : 0) + (s1 ? s1->C : 0);
       // F(4,3): 6 products per 4 outputs and kernel row instead of 12 (the folded shortcut runs as a plain GEMM); F(2,3): 4 instead of 6
-      m->prof_flops_exec += 2.0 * B * out.H * out.W * (double)out.C * (cin * ks * ks * (wino4 ? 0.5 : wino ? 2.0 / 3.0 : 1.0) + csc);
+      // F(4x4, 3x3): 36 products per 16 outputs instead of 144
+      m->prof_flops_exec += 2.0 * B * out.H * out.W * (double)out.C * (cin * ks * ks * (wino44 ? 0.25 : wino4 ? 0.5 : wino ? 2.0 / 3.0 : 1.0) + csc);
       m->prof_bytes += (double)B * out.H * out.W * esz * (cin + csc + (skip ? out.C : 0) + out.C) + (double)esz * out.C * (cin * ks * ks + csc);
     }
     return rc;
@@ -442,10 +447,10 @@ struct Fwd {
     if (md.up || md.down) {
       xr = talloc(md.cin, OH, OW); hr = talloc(md.cin, OH, OW);
       if (!dry) FD_TRY(fir(ptr(x0.off), (const float*)ptr(aff0), ptr(xr.off), ptr(hr.off), H, W, md.cin, md.up ? 1 : -1));
-      FD_TRY(conv(hr, nullptr, (size_t)-1, nullptr, nullptr, md.w0, md.bias0_eff, nt, nullptr, 1.f, h1, 3, true, md.wino0, md.w0w, md.w0w4));
+      FD_TRY(conv(hr, nullptr, (size_t)-1, nullptr, nullptr, md.w0, md.bias0_eff, nt, nullptr, 1.f, h1, 3, true, md.wino0, md.w0w, md.w0w4, md.w0w44));
       tfree(hr);
     } else {
-      FD_TRY(conv(x0, x1, aff0, nullptr, nullptr, md.w0, md.bias0_eff, nt, nullptr, 1.f, h1, 3, true, md.wino0, md.w0w, md.w0w4));
+      FD_TRY(conv(x0, x1, aff0, nullptr, nullptr, md.w0, md.bias0_eff, nt, nullptr, 1.f, h1, 3, true, md.wino0, md.w0w, md.w0w4, md.w0w44));
     }
     arena.release(aff0);
     size_t aff1;
@@ -453,10 +458,10 @@ struct Fwd {
     if (!out_given) out = talloc(md.cout, OH, OW);
     else { out.C = md.cout; out.H = OH; out.W = OW; out.sums = (size_t)-1; }   // fd_resblock: the caller's output tensor
     if (md.has_c2) {  // Conv_1(act(GN1(h))) + Conv_2(x) in one launch (shortcut conv folded in as extra K steps)
-      if (md.up || md.down) FD_TRY(conv(h1, nullptr, aff1, &xr, nullptr, md.w1, md.b1, 1, nullptr, rs2, out, 3, true, md.wino1, md.w1w, md.w1w4));
-      else FD_TRY(conv(h1, nullptr, aff1, &x0, x1, md.w1, md.b1, 1, nullptr, rs2, out, 3, true, md.wino1, md.w1w, md.w1w4));
+      if (md.up || md.down) FD_TRY(conv(h1, nullptr, aff1, &xr, nullptr, md.w1, md.b1, 1, nullptr, rs2, out, 3, true, md.wino1, md.w1w, md.w1w4, md.w1w44));
+      else FD_TRY(conv(h1, nullptr, aff1, &x0, x1, md.w1, md.b1, 1, nullptr, rs2, out, 3, true, md.wino1, md.w1w, md.w1w4, md.w1w44));
     } else {
-      FD_TRY(conv(h1, nullptr, aff1, nullptr, nullptr, md.w1, md.b1, 1, &x0, rs2, out, 3, true, md.wino1, md.w1w, md.w1w4));
+      FD_TRY(conv(h1, nullptr, aff1, nullptr, nullptr, md.w1, md.b1, 1, &x0, rs2, out, 3, true, md.wino1, md.w1w, md.w1w4, md.w1w44));
     }
     if (md.up || md.down) tfree(xr);
     arena.release(aff1);
@@ -937,6 +942,13 @@ extern "C" int fd_model_finalize(fd_model* m, void* stream) {
         if (both4 && fd_conv_packed_bytes(md.cout, md.cout, 0, 3, md.has_c2 ? md.c0 : 0, md.has_c2 ? md.c1 : 0, m->dt | FD_WINOGRAD4) > 0)
           FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, md.has_c2 ? p + "Conv_2.weight" : std::string(), md.has_c2 ? md.c0 : 0,
                            md.has_c2 ? md.c1 : 0, &md.w1w4, st, FD_WINOGRAD4));
+        if (both4 && m->dt == FD_F32 && !(m->cfg.act_dtype & (FD_BF16_OPERANDS | FD_BF16X3_OPERANDS))) {   // fp32 mode: the 2-D float32 kernel's packing
+          if (fd_conv_packed_bytes(md.cout, md.c0, md.c1, 3, 0, 0, FD_F32 | FD_WINOGRAD44) > 0)
+            FD_TRY(pack_conv(m, p + "Conv_0.weight", md.cout, md.c0, md.c1, 3, "", 0, 0, &md.w0w44, st, FD_WINOGRAD44));
+          if (fd_conv_packed_bytes(md.cout, md.cout, 0, 3, md.has_c2 ? md.c0 : 0, md.has_c2 ? md.c1 : 0, FD_F32 | FD_WINOGRAD44) > 0)
+            FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, md.has_c2 ? p + "Conv_2.weight" : std::string(), md.has_c2 ? md.c0 : 0,
+                             md.has_c2 ? md.c1 : 0, &md.w1w44, st, FD_WINOGRAD44));
+        }
         FD_TRY(pack_conv(m, p + "Conv_0.weight", md.cout, md.c0, md.c1, 3, "", 0, 0, &md.w0, st, md.wino0 ? FD_WINOGRAD : 0));
         if (md.has_c2) {  // fold the 1x1 shortcut into Conv_1's K loop; biases add
           FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, p + "Conv_2.weight", md.c0, md.c1, &md.w1, st, md.wino1 ? FD_WINOGRAD : 0));

@@ -76,13 +76,14 @@ def conv_in(in8, w, bias):
     return out, stats
 
 
-_WINO = {False: 0, 0: 0, True: L.FD_WINOGRAD, 4: L.FD_WINOGRAD4}   # (True == 1: the F(2,3) kernel)
+_WINO = {False: 0, 0: 0, True: L.FD_WINOGRAD, 4: L.FD_WINOGRAD4, 44: L.FD_WINOGRAD44}   # (True == 1: the F(2,3) kernel; 44: 2-D F(4x4,3x3), float32 only)
 
 
 def pack_conv_weight(w, C0=None, dtype=torch.bfloat16, w_sc=None, S0=None, winograd=False, bf16_operands=False):
     """w: [Cout, Cin, k, k] float32 (GPU); C0 = channels of the first concat segment (default: all).
     w_sc: optional 1x1 shortcut weight [Cout, S, 1, 1] folded behind the main K loop (S0 = first segment).
-    winograd: True = pack for the F(2,3) kernel (FD_WINOGRAD), 4 = for the F(4,3) kernel (FD_WINOGRAD4); pass the same value to conv2d.
+    winograd: True = pack for the F(2,3) kernel (FD_WINOGRAD), 4 = for the F(4,3) kernel (FD_WINOGRAD4; bf16 or float32 storage), 44 = for the
+    2-D F(4x4, 3x3) kernel (FD_WINOGRAD44; float32 storage only); pass the same value to conv2d.
     bf16_operands (with dtype=float32): True = FD_BF16_OPERANDS (f32 activations, bf16 weights / MFMA operands), "x3" =
     FD_BF16X3_OPERANDS (two-term bf16 split, three MFMAs per product); pass the same value to conv2d."""
     L.require_cuda(w, w_sc)

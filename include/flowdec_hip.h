@@ -59,6 +59,10 @@ extern "C" {
 /* fd_conv2d with FD_WINOGRAD4 only: walk the pixel tiles in DESCENDING order.  Same result, bit for bit; a consumer that starts where
  * its producer stopped finds the producer's last output lines still in the memory-side cache (the model alternates the direction from
  * one F(4,3) launch to the next: 0.5 % of a cfg 2 step). */
+/* fd_conv_pack_weights / fd_conv2d with FD_F32 storage: 2-D Winograd F(4x4, 3x3) in exact float32 (conv_wino44f.hip: 2.25 multiply-adds per
+ * output and input channel instead of 9; Cout % 128 == 0, channel counts % 8 == 0, H % 16 == W % 16 == 0; folded shortcut and residual
+ * input allowed together).  The fp32 mode's kernel (`FD_F32 | FD_WINOGRAD_AUTO`). */
+#define FD_WINOGRAD44 0x200000
 #define FD_TILE_REVERSED 0x100000
 /* fd_model_config.act_dtype only: Winograd for the blocks of resolution level >= 2 (small grids, where its 128-cout workgroups
  * fill the chip better), direct MFMA convolution elsewhere. */

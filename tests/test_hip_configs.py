@@ -503,16 +503,23 @@ def test_conv2d_winograd4(case):
     assert rel_err(from_nhwc(out), from_nhwc(outd)) < 5e-3
 
 
-@pytest.mark.parametrize("case", WINO4_CASES + [("f32_c16", 1, 16, 32, 16, 0, 256, True, 1, False, 0, 0), ("f32_sc48", 1, 16, 16, 48, 16, 256, True, 1, False, 32, 16)],
-                         ids=[c[0] for c in WINO4_CASES] + ["f32_c16", "f32_sc48"])
+W4F_CASES = WINO4_CASES + [("f32_c16", 1, 16, 32, 16, 0, 256, True, 1, False, 0, 0), ("f32_sc48", 1, 16, 16, 48, 16, 256, True, 1, False, 32, 16)]
+# the 2-D kernel: Cout multiples of 128, channel counts multiples of 8, folded shortcut AND residual input together
+W44F_CASES = W4F_CASES + [("c128_cat", 2, 32, 16, 24, 8, 128, True, 1, True, 0, 0), ("c128_sc", 1, 16, 32, 128, 0, 128, True, 1, False, 64, 8),
+                          ("sc_and_skip", 1, 16, 16, 64, 0, 256, True, 1, True, 64, 0), ("c8", 1, 16, 16, 8, 0, 128, False, 0, False, 0, 0)]
+
+
+@pytest.mark.parametrize("case", [(4, c) for c in W4F_CASES] + [(44, c) for c in W44F_CASES], ids=lambda ac: f"w{ac[0]}-{ac[1][0]}")
 def test_conv2d_winograd4_f32(case):
-    """Winograd F(4,3) in EXACT FLOAT32 (conv_wino4f.hip; round 6): f32 storage, f32 transforms, v_mfma_f32_32x32x2_f32 -- the fp32 mode's
-    kernel for every 3x3 layer with 256 output channels (half the MFMAs of the direct f32 kernel).  Same operator cases as the fp16-operand kernel plus
+    """The two float32 Winograd kernels of the fp32 mode (round 6): algo 44 = 2-D F(4x4, 3x3) (conv_wino44f.hip: a quarter of the direct f32
+    kernel's MFMAs; Cout % 128 == 0, channel counts % 8 == 0, shortcut and residual together) and algo 4 = F(4,3) along W x direct along H
+    (conv_wino4f.hip: half; Cout = 256, channel counts % 16 == 0) -- f32 storage, f32 transforms, f32 matrix instructions.  Same operator cases as the fp16-operand kernel plus
     channel counts that are multiples of 16 only; reference = the f64 convolution of the SAME f32 tensors: 5e-6 (measured 2.3e-7 ... 9.0e-7:
     the transforms' row sums of 10 / 8 on f32 roundings; the direct f32 kernel: 3e-7), GroupNorm partial sums 5e-6 (measured <= 2.2e-7),
     bit-deterministic in both tile orders, and within 5e-6 of the direct f32 kernel."""
     from flowdec_amd import ops
     import zlib
+    algo, case = case
     name, B, H, W, C0, C1, Cout, use_aff, bias_rows, use_skip, S0, S1 = case
     rng = np.random.default_rng(zlib.crc32(("w4f" + name).encode()))
     Cin = C0 + C1
@@ -549,29 +556,30 @@ def test_conv2d_winograd4_f32(case):
     ref = ref * scale
     x0 = nhwc(x[:, :C0], f32)
     x1 = nhwc(x[:, C0:], f32) if C1 else None
-    pw = ops.pack_conv_weight(dev(w), C0=C0, dtype=f32, w_sc=w_sc, S0=S0 if S0 else None, winograd=4)
+    pw = ops.pack_conv_weight(dev(w), C0=C0, dtype=f32, w_sc=w_sc, S0=S0 if S0 else None, winograd=algo)
     kw = dict(x1=x1, affine=aff, bias=bias, skip=skip, scale=scale, sc0=sc0, sc1=sc1, want_stats=True)
-    out, stats = ops.conv2d(x0, pw, Cout, 3, winograd=4, **kw)
+    out, stats = ops.conv2d(x0, pw, Cout, 3, winograd=algo, **kw)
     torch.cuda.synchronize()
     assert out.dtype == f32
-    check(f"conv2d_winograd4_f32[{name}]", from_nhwc(out), ref, 5e-6)
+    check(f"conv2d_winograd{algo}_f32[{name}]", from_nhwc(out), ref, 5e-6)
     st = stats.double().sum(dim=1).cpu().numpy()[:, :Cout]
     ref_s = np.stack([ref.sum(axis=(2, 3)), (ref ** 2).sum(axis=(2, 3))], axis=-1)
     e = float(np.abs(st - ref_s).max() / np.abs(ref_s).max())
-    report(f"conv2d_winograd4_f32_stats[{name}]", e, 5e-6)
+    report(f"conv2d_winograd{algo}_f32_stats[{name}]", e, 5e-6)
     assert e < 5e-6
-    out2, stats2 = ops.conv2d(x0, pw, Cout, 3, winograd=4, **kw)
+    out2, stats2 = ops.conv2d(x0, pw, Cout, 3, winograd=algo, **kw)
     assert torch.equal(out, out2) and torch.equal(stats, stats2)
-    out3, stats3 = ops.conv2d(x0, pw, Cout, 3, winograd=4, reversed_tiles=True, **kw)
-    assert torch.equal(out, out3) and torch.equal(stats, stats3)
+    if algo == 4:
+        out3, stats3 = ops.conv2d(x0, pw, Cout, 3, winograd=4, reversed_tiles=True, **kw)
+        assert torch.equal(out, out3) and torch.equal(stats, stats3)
     pd = ops.pack_conv_weight(dev(w), C0=C0, dtype=f32, w_sc=w_sc, S0=S0 if S0 else None)
     outd, _ = ops.conv2d(x0, pd, Cout, 3, **kw)
     assert rel_err(from_nhwc(out), from_nhwc(outd)) < 5e-6
 
 
 def test_fp32_auto_runs_winograd4_f32_and_matches_direct():
-    """precision='fp32' with conv_algo='auto' (the default) sends the 3x3 convolutions with 256 output channels to the float32 F(4,3)
-    kernel; 'direct' keeps the direct f32 kernel everywhere.  One full-width forward of each on G10's inputs: both inside the fp32
+    """precision='fp32' with conv_algo='auto' (the default) sends the 3x3 convolutions of every ResBlock to the float32 Winograd kernels
+    (2-D F(4x4, 3x3)); 'direct' keeps the direct f32 kernel everywhere.  One full-width forward of each on G10's inputs: both inside the fp32
     tolerance against the reference, and within 2e-5 of each other (different summation orders of exact f32 products)."""
     import flowdec_amd
     g = load_golden("g10_ncsnpp_nf64.npz")
