@@ -80,6 +80,7 @@ bool fd_wino4f_shape_ok(int H, int W);
 long long fd_wino44f_packed_bytes(int Cout, int C0, int C1, int S0, int S1);
 int fd_wino44f_pack_weights(const float* w, const float* w_sc, void* packed, int Cout, int C0, int C1, int S0, int S1, hipStream_t st);
 int fd_wino44f_launch(fdconv::ConvArgs a, hipStream_t st);
+int fd_wino44f_init_attributes();
 bool fd_wino44f_supported(int Cout, int C0, int C1, int S0, int S1, int ksize);
 bool fd_wino44f_shape_ok(int H, int W);
 

@@ -1239,6 +1239,7 @@ int fd_conv_init_attributes() {
   FD_TRY(fd_wino_init_attributes());
   FD_TRY(fd_wino4_init_attributes());
   FD_TRY(fd_wino4f_init_attributes());
+  FD_TRY(fd_wino44f_init_attributes());
   FD_TRY(fd_head_init_attributes());
   if (known) done_dev[dev] = true;
   return FD_OK;

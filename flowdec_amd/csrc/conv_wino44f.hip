@@ -7,14 +7,15 @@
 // i.e. 2.25 multiply-adds per output and input channel instead of 9 (direct) or 4.5 (conv_wino4f.hip: F(4,3) along W only) -- a quarter /
 // half of the MFMAs.  In float32 this pays in full: v_mfma_f32_16x16x4_f32 runs at the f32 VECTOR rate (1/16 of the fp16 matrix rate), so
 // the launch is bound by the matrix pipe and nothing else matters much -- which is why this kernel, unlike the fp16 kernels of this
-// library, is deliberately SIMPLE: no LDS-DMA rings, no counted waits, two barriers per chunk.  (In fp16 the 2-D form is neither accurate
+// library, is deliberately SIMPLE: no weight rings, no counted waits, two barriers per chunk.  (In fp16 the 2-D form is neither accurate
 // -- the transforms amplify an operand rounding ~100 x -- nor affordable: 2.25 accumulator planes per output.)
 //
 //   * one workgroup = 16 x 16 output pixels (16 tiles of 4 x 4) x 128 output channels, 8 waves; wave w owns couts 16 w .. 16 w + 15 for ALL
 //     36 positions and all 16 tiles: 36 accumulator tiles of 16 x 16 (v_mfma_f32_16x16x4_f32) = 144 registers, the whole output
 //     transform stays inside a lane (no exchange between waves);
-//   * K walks 8-channel chunks: halo (18 x 18 x 8, global -> registers one chunk ahead) -> [silu(a x + d)] -> z (LDS) -> 2-D input
-//     transform -> V (LDS, double-buffered, [position group of 4][tile][channel slot][4 positions]: one ds_read_b128 feeds 4 MFMAs);
+//   * K walks 8-channel chunks: halo (18 x 18 x 8) by LDS-DMA one chunk ahead, converted IN PLACE by the lanes that requested it
+//     ([silu(a x + d)], zero padding; a raw input needs no conversion at all) -> 2-D input transform -> V (LDS, double-buffered,
+//     [position group of 4][tile][channel slot][4 positions]: one ds_read_b128 feeds 4 MFMAs);
 //   * weights: transformed at pack time, laid out so that a lane's operand of 4 consecutive positions is one aligned 16-byte piece of
 //     a contiguous 1-KiB wave load: they go from L2 straight into registers, 6 loads ahead (32 B / clk and CU: half the L1 rate);
 //   * the folded 1x1 shortcut (Conv_2, layerspp.py:276-284) is more K chunks on the raw shortcut input: a centre-tap kernel transforms
@@ -31,13 +32,20 @@ using namespace fdconv;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int NTH = 512, TH = 16, TW = 16, HH = TH + 2, HW = TW + 2, BN = 128, CK = 8;
-constexpr int ZROW = HW * CK + 4;                    // floats per halo row: 148 (16-byte aligned; four rows apart = 16 banks: the transform's reads are 2-way conflicted at worst)
-constexpr int Z_FLOATS = HH * ZROW;                  // 2664
-constexpr int V_FLOATS = 9 * 16 * CK * 4;            // [group of 4 positions][tile][channel slot][4] = 4608
-constexpr int NPIECE = HH * HW * 2;                  // 648 halo pieces of 4 channels per chunk
-constexpr int WDEPTH = 4;                            // weight loads in flight per wave (1 KiB each; registers: 36 x 4 accumulators leave ~100)
-constexpr int WSTEP = 18;                            // weight loads per chunk and wave: 9 position groups x 2 channel quads
+constexpr int NTH = 512, TH = 16, TW = 16, BN = 128, CK = 8;
+constexpr int WR = 6, WC = 10, WPIX = WR * WC;       // a wave's halo window: 2 horizontally adjacent tiles of 4 x 4 outputs = 6 x 10 pixels
+constexpr int ZHALF = (WPIX + 1) * 4;                // floats between the two channel halves of a window: [half][pixel 60 (+1 pad)][4 channels]
+                                                     // (244 = 20 mod 32: the transform's reads of a (channel, tile) lane group hit 32 different banks)
+constexpr int ZWAVE = 128 * 4;                       // floats of z per window (2 KiB; 121 slots used)
+constexpr int V_FLOATS = 9 * 16 * CK * 4;            // [group of 4 positions][tile][channel slot][4] = 4608 floats (18 KiB)
+constexpr int WSTEP = 18;                            // weight pieces (1 KiB) per chunk and wave: 9 position groups x 2 channel quads
+constexpr int RD = 9;                                // per-wave weight ring: 9 slots of 1 KiB; 18 % RD == 0: a step's slot is a compile-time constant
+static_assert(WSTEP % RD == 0 && WPIX <= 64, "ring / window layout");
+constexpr int Z_OFF = 0, V_OFF = 8 * 2 * ZWAVE * 4, RING_OFF = V_OFF + 3 * V_FLOATS * 4,
+              LDS_BYTES = RING_OFF + 8 * RD * 1024;  // 32 (two z windows per wave) + 54 + 72 KiB = 158 KiB
+static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // B^T (6 x 6) of F(4,3): rows applied to a column of 6 values
 __device__ __forceinline__ void bt6(const float (&d)[6], float (&o)[6]) {
@@ -64,11 +72,37 @@ __device__ __forceinline__ bool inner_pos(int xi) {   // positions (i, j) with 1
   return i >= 1 && i <= 4 && j >= 1 && j <= 4;
 }
 
+// LDS-DMA (as in conv_wino4.hip): each lane's 16 bytes come from (wave-uniform base + per-lane byte offset) and land at LDS byte
+// (M0 + lane * 16).  EVERY vector-memory load of this kernel's loop is one of these, so the s_waitcnt vmcnt(N) below are exact counts
+// (vector-memory operations of a wave complete in order).
+// a pointer that is wave-uniform by construction, said so where the compiler's divergence analysis cannot see it ("s" asm operands)
+template <typename T>
+__device__ __forceinline__ const T* uniform_ptr(const T* q) {
+  const unsigned long long ub = reinterpret_cast<unsigned long long>(q);
+  return reinterpret_cast<const T*>(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(ub >> 32)) << 32) |
+                                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)ub));
+}
+__device__ __forceinline__ void glds16(const void* sbase_, unsigned voff, unsigned lds_dst) {
+  const char* sbase = uniform_ptr(reinterpret_cast<const char*>(sbase_));
+  lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Schedule.  The matrix pipe is the bound (v_mfma_f32_16x16x4_f32: 32 cycles per instruction and SIMD), so it must never wait for the
+// producer.  The 8 waves form two groups (waves 0-3 / 4-7: one wave of each group per SIMD) that alternate in HALF-PHASES separated by
+// one workgroup barrier each:          half-phase 2c: group 0 multiplies chunk c, group 1 produces its part of chunk c + 1
+//                                      half-phase 2c + 1: group 0 produces its part of chunk c + 2, group 1 multiplies chunk c
+// -- while one wave of a SIMD issues its 72 MFMAs, the other one converts and transforms.  Both groups run the SAME loop (multiply c;
+// barrier; produce c + 2; barrier); group 1 enters it one producer step and one barrier later.  PRODUCE is wave-private: wave w owns
+// the two tiles (row w >> 1, columns 2 (w & 1), + 1), requests their 6 x 10-pixel window by DMA into its own 2 KiB of z one chunk
+// ahead, converts it in place and transforms it -- no barrier inside.  V has three buffers (chunk k in V[k % 3]).
 template <bool ACT, bool SKIP>
 __global__ __launch_bounds__(NTH, 2) void conv_wino44f_kernel(ConvArgs p) {
-  __shared__ __attribute__((aligned(16))) float zbuf[Z_FLOATS];
-  __shared__ __attribute__((aligned(16))) float vbuf[2][V_FLOATS];
-  FD_T2(const unsigned long long t2_entry = __builtin_amdgcn_s_memtime();)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const vbuf0 = reinterpret_cast<float*>(smem + V_OFF);
+  FD_T2(const unsigned long long t2_entry = __builtin_amdgcn_s_memtime(); unsigned long long t2_mfma = 0, t2_prod = 0, t2_pwait = 0, t2_pwork = 0;)
 
   // ---- tile decode with XCD-aware remap (as conv_mfma.hip); the cout blocks of a pixel tile are neighbours (they share the halo in L2)
   const int bid = blockIdx.x, nblk = gridDim.x;
@@ -88,171 +122,234 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino44f_kernel(ConvArgs p) {
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = wave >> 2;
   const int n16 = lane & 15, kq = lane >> 4;
 
-  // ---- chunk list: the 3x3 segments first, the folded-shortcut segments (taps == 1) behind them
+  // ---- chunk list: the 3x3 segments first, the folded-shortcut segments (taps == 1) behind them (wave-uniform scalar code)
   int n3 = 0, n1 = 0;
   for (int s = 0; s < p.nseg; ++s) (p.seg[s].taps == 9 ? n3 : n1) += p.seg[s].C / CK;
   const int nchunk = n3 + n1;
-  auto chunk_src = [&](int c, const float*& src, int& C, int& c0, int& aff_off) {   // chunk c -> tensor, channels, first channel, affine offset
-    int s = 0, cc = c;
-    while (s + 1 < p.nseg && cc >= p.seg[s].C / CK) { cc -= p.seg[s].C / CK; ++s; }
-    src = reinterpret_cast<const float*>(p.seg[s].src) + (size_t)b * img_elems * p.seg[s].C;
-    C = p.seg[s].C; c0 = cc * CK; aff_off = p.seg[s].aff_off;
+  // A cursor walks the chunk list (segment by segment, CK channels at a time) in scalar registers: the kernel arguments of a segment are
+  // read when the cursor enters it, never per chunk.  Past the last chunk it stays there (a request then re-reads that chunk: harmless).
+  struct Cursor { int s, left; const float* src; int C, c0, aoff; };
+  auto cur_enter = [&](Cursor& q, int sidx) {
+    q.s = sidx; q.C = p.seg[sidx].C; q.aoff = p.seg[sidx].aff_off; q.c0 = 0; q.left = q.C / CK - 1;
+    q.src = reinterpret_cast<const float*>(p.seg[sidx].src) + (size_t)b * img_elems * q.C;
   };
+  auto cur_next = [&](Cursor& q) {
+    if (q.left > 0) { --q.left; q.c0 += CK; }
+    else if (q.s + 1 < p.nseg) cur_enter(q, q.s + 1);
+  };
+  Cursor qd, qc;        // the chunk the next halo request fetches / the chunk the next producer step converts
+  cur_enter(qd, 0);
+  cur_enter(qc, 0);
+  int kd = 0;           // chunks requested so far (window kd & 1)
 
-  // ---- halo: piece q = 2 * pixel + half (4 channels = 16 bytes); thread t takes q = t and, for t < 136, q = t + 512
-  int hpix[2], zoff[2];
-  bool hok[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int q = t + i * NTH;
-    const int px = q < NPIECE ? q >> 1 : 0;
-    const int hr = px / HW, hc = px - hr * HW;
-    const int gh = h0 - 1 + hr, gw = w0 - 1 + hc;
-    hok[i] = q < NPIECE && gh >= 0 && gh < H && gw >= 0 && gw < W;
-    hpix[i] = hok[i] ? gh * W + gw : 0;
-    zoff[i] = hr * ZROW + hc * CK + 4 * (q & 1);
+  // ---- this wave's halo window: tiles (ty, 2 tp), (ty, 2 tp + 1); lane l < 60 owns pixel (l / 10, l % 10): both 16-byte channel halves
+  // (the half is uniform per request and per conversion pass: the GroupNorm affine stays in scalar registers)
+  const int ty_w = wave >> 1, tp_w = wave & 1;
+  float* const zw = reinterpret_cast<float*>(smem + Z_OFF) + wave * 2 * ZWAVE;   // two windows: chunk k in window k & 1
+  const bool hreal = lane < WPIX;
+  int hpix;
+  bool hok;
+  {
+    const int hr = hreal ? lane / WC : 0, hc = hreal ? lane - hr * WC : 0;
+    const int gh = h0 - 1 + 4 * ty_w + hr, gw = w0 - 1 + 8 * tp_w + hc;
+    hok = hreal && gh >= 0 && gh < H && gw >= 0 && gw < W;
+    hpix = hok ? gh * W + gw : 0;
   }
-  const bool has2 = t + NTH < NPIECE;
-  f32x4 hreg[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  f32x4 areg[2];      // (a, d) pairs of the 4 channels of BOTH pieces (t and t + 512 have the same parity: the same channel half; ACT only)
-  auto load_halo = [&](int c) {        // global -> registers (chunk c; past the end: nothing)
-    if (c >= nchunk) return;
-    const float* src; int C, c0, aoff;
-    chunk_src(c, src, C, c0, aoff);
+  const unsigned zlds = (unsigned)(Z_OFF + wave * 2 * ZWAVE * 4);
+  auto dma_halo = [&]() {              // the next chunk -> z window kd & 1 (always 2 operations: the counted waits rely on it)
+    if (hreal) {                       // (lanes 60 .. 63 masked off: their slots belong to the other half)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (i == 1 && !has2) continue;
-      const int ch = c0 + 4 * ((t + i * NTH) & 1);
-      hreg[i] = hok[i] ? *reinterpret_cast<const f32x4*>(src + (size_t)hpix[i] * C + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (ACT && aoff >= 0 && i == 0) {
-        const float* ap = p.affine + ((size_t)b * p.affC + aoff + ch) * 2;
-        areg[0] = *reinterpret_cast<const f32x4*>(ap);
-        areg[1] = *reinterpret_cast<const f32x4*>(ap + 4);
+      for (int i = 0; i < 2; ++i) glds16(qd.src, (unsigned)((hpix * qd.C + qd.c0) * 4 + i * 16), zlds + (unsigned)((kd & 1) * ZWAVE * 4 + i * ZHALF * 4));
+    }
+    ++kd;
+    cur_next(qd);
+  };
+  // the GroupNorm affine (a, d) of the 8 channels of chunk qc: 16 scalar registers, requested one producer step ahead (the scalar load is
+  // invisible to hipcc: aff_wait re-defines the registers before their first use)
+  f32x16 af;
+  auto aff_request = [&]() {
+    if constexpr (ACT) {
+      if (qc.aoff >= 0) {
+        const float* ap = uniform_ptr(p.affine + ((size_t)b * p.affC + qc.aoff + qc.c0) * 2);
+        asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(af) : "s"(ap) : "memory");
       }
     }
   };
-  auto store_halo = [&](int c) {       // registers -> [silu(a x + d)] -> z; zero padding AFTER the activation
-    const float* src; int C, c0, aoff;
-    chunk_src(c, src, C, c0, aoff);
-    const bool act = ACT && aoff >= 0;
+  auto aff_wait = [&]() {
+    if constexpr (ACT) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(af)::"memory");
+  };
+  auto convert_halo = [&](int c) {     // own slots: [silu(a x + d)], zeros outside the image (AFTER the activation); in place
+    const bool act = ACT && qc.aoff >= 0;
+    aff_wait();
+    if (!hreal || (!act && hok)) return;               // raw input inside the image: the slot is already what the transform reads
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (i == 1 && !has2) continue;
-      f32x4 v = hreg[i];
+      float* zp = zw + (c & 1) * ZWAVE + i * ZHALF + lane * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(zp);
       if (act) {
-        v[0] = fd_silu(fmaf(v[0], areg[0][0], areg[0][1]));
-        v[1] = fd_silu(fmaf(v[1], areg[0][2], areg[0][3]));
-        v[2] = fd_silu(fmaf(v[2], areg[1][0], areg[1][1]));
-        v[3] = fd_silu(fmaf(v[3], areg[1][2], areg[1][3]));
-        if (!hok[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fd_silu(fmaf(v[e], af[8 * i + 2 * e], af[8 * i + 2 * e + 1]));
       }
-      *reinterpret_cast<f32x4*>(zbuf + zoff[i]) = v;
+      if (!hok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(zp) = v;
     }
   };
 
-  // ---- 2-D input transform z -> V[buf]: threads 0 .. 255 = (channel 8, tile row 4, tile column 4, half 2); a thread transforms the
-  // 6 x 6 tile of its channel (columns first), keeps the three output rows 3 half .. 3 half + 2 and stores them as 16-byte groups of
-  // four consecutive positions: V[g][tile][slot = ch ^ (tile >> 1)][4] (the XOR keeps the MFMA's ds_read_b128 free of bank conflicts)
-  const int tr_ch = t & 7, tr_ty = (t >> 3) & 3, tr_tx = (t >> 5) & 3;
-  auto transform_half = [&](int buf, auto hf_tag) {   // hf: output rows 3 hf .. 3 hf + 2 (wave-uniform: waves 0, 1 / 2, 3)
-    constexpr int HF = decltype(hf_tag)::value;
-    const float* zp = zbuf + (4 * tr_ty) * ZROW + (4 * tr_tx) * CK + tr_ch;
-    float trow[3][6];   // trow[ii][j] = (B^T d)[3 HF + ii][j]
+  // ---- 2-D input transform of the wave's two tiles: lanes 0 .. 47 = (channel 8, tile 2, third 3); a lane transforms the columns of its
+  // channel's 6 x 6 tile, keeps the output rows 2 third, 2 third + 1 = positions 12 third .. 12 third + 11 and stores them as three
+  // 16-byte groups of four consecutive positions: V[g][tile][slot = ch ^ (tile >> 1)][4] (the XOR keeps the MFMA's ds_read_b128 free of
+  // bank conflicts).  LDS operations of one wave complete in order: the reads see the in-place conversion of the other lanes.
+  const int tr_ch = lane & 7, tr_tl = (lane >> 3) & 1, tr_th = lane >> 4;
+  auto transform = [&](int k) {        // (all 48 lanes run the same instructions: the third only selects rows and the store address)
+    const int buf = k % 3;
+    const float* zp = zw + (k & 1) * ZWAVE + (tr_ch >> 2) * ZHALF + (4 * tr_tl) * 4 + (tr_ch & 3);
+    float dd[6][6];     // all 36 values requested at once: one LDS latency per producer step, not one per column
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int r = 0; r < 6; ++r) dd[j][r] = zp[(r * WC + j) * 4];
+    __builtin_amdgcn_sched_barrier(0);
+    float trow[2][6];   // trow[ii][j] = (B^T d)[2 third + ii][j]
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      float d[6], o6[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) d[r] = zp[r * ZROW + j * CK];
-      bt6(d, o6);
-#pragma unroll
-      for (int ii = 0; ii < 3; ++ii) trow[ii][j] = o6[3 * HF + ii];
+      float o6[6];
+      bt6(dd[j], o6);
+      trow[0][j] = tr_th == 0 ? o6[0] : tr_th == 1 ? o6[2] : o6[4];
+      trow[1][j] = tr_th == 0 ? o6[1] : tr_th == 1 ? o6[3] : o6[5];
     }
-    const int tile = tr_ty * 4 + tr_tx;
-    float* vb = vbuf[buf] + (tile * CK + (tr_ch ^ (tile >> 1))) * 4;
-    float lin[18];      // positions xi = 6 i + j of this half: 18 consecutive values starting at 18 HF
+    const int tile = ty_w * 4 + 2 * tp_w + tr_tl;
+    float* vb = vbuf0 + buf * V_FLOATS + (tile * CK + (tr_ch ^ (tile >> 1))) * 4 + 3 * tr_th * 16 * CK * 4;
+    float lin[12];
 #pragma unroll
-    for (int ii = 0; ii < 3; ++ii) {
+    for (int ii = 0; ii < 2; ++ii) {
       float o6[6];
       bt6(trow[ii], o6);
 #pragma unroll
       for (int j = 0; j < 6; ++j) lin[6 * ii + j] = o6[j];
     }
-    if constexpr (HF == 0) {   // xi 0 .. 17: groups 0 .. 3 whole, the first two positions of group 4
 #pragma unroll
-      for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(vb + g * 16 * CK * 4) = f32x4{lin[4 * g], lin[4 * g + 1], lin[4 * g + 2], lin[4 * g + 3]};
-      *reinterpret_cast<f32x2*>(vb + 4 * 16 * CK * 4) = f32x2{lin[16], lin[17]};
-    } else {                   // xi 18 .. 35: the last two positions of group 4, groups 5 .. 8 whole
-      *reinterpret_cast<f32x2*>(vb + 4 * 16 * CK * 4 + 2) = f32x2{lin[0], lin[1]};
-#pragma unroll
-      for (int g = 5; g < 9; ++g) *reinterpret_cast<f32x4*>(vb + g * 16 * CK * 4) = f32x4{lin[4 * g - 18], lin[4 * g - 17], lin[4 * g - 16], lin[4 * g - 15]};
+    for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4*>(vb + g * 16 * CK * 4) = f32x4{lin[4 * g], lin[4 * g + 1], lin[4 * g + 2], lin[4 * g + 3]};
+  };
+  // PRODUCE chunk k (this wave's two tiles) into V[k % 3], then request chunk k + 2 into the window just consumed (the request flies for a
+  // whole period: activations come from HBM).  FIRST: prologue form of the wait; steady state: younger than the request of chunk k are the
+  // 2 operations of the request of chunk k + 1 and of the weight pieces at most the RD of the ring.
+  auto produce = [&](int k, auto first_tag) {
+    FD_T2(const unsigned long long tp0 = __builtin_amdgcn_s_memtime();)
+    if constexpr (decltype(first_tag)::value) vm_wait<0>(); else vm_wait<RD + 2>();
+    FD_T2(const unsigned long long tp1 = __builtin_amdgcn_s_memtime(); t2_pwait += tp1 - tp0;)
+    // the producer's vector instructions go in front of the other wave's MFMAs (which leave 7 of 8 issue slots free); at equal priority
+    // the multiplying wave wins the arbitration and the producer step takes twice as long
+    __builtin_amdgcn_s_setprio(3);
+    if (k < nchunk) {
+#ifndef FD_ABL_NOPROD     // (timing-only ablation: the multiply phase without a producing wave next to it)
+      convert_halo(k);
+      if (tr_th < 3) transform(k);
+#endif
+      cur_next(qc);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the transform's reads of z are done before the next request overwrites it
+    dma_halo();             // chunk k + 2
+    if (k + 1 < nchunk) aff_request();
+    __builtin_amdgcn_s_setprio(0);
+    FD_T2(t2_pwork += __builtin_amdgcn_s_memtime() - tp1;)
   };
-  auto transform = [&](int buf) {
-    if (wave < 2) transform_half(buf, std::integral_constant<int, 0>{});
-    else if (wave < 4) transform_half(buf, std::integral_constant<int, 1>{});
-  };
+  using TFIRST = std::integral_constant<bool, true>;
+  using TSTEADY = std::integral_constant<bool, false>;
 
-  // ---- weights: [cout block][chunk][wave][18 = group x channel quad][64 lanes][4 positions] f32, 1 KiB per load
-  const float* wgt = reinterpret_cast<const float*>(p.w) + ((size_t)cb * (nchunk + 1) * 8 + wave) * (WSTEP * 256) + lane * 4;
-  const size_t wchunk = (size_t)8 * WSTEP * 256;   // floats per chunk (all 8 waves)
-  f32x4 wq[WDEPTH];
-#pragma unroll
-  for (int i = 0; i < WDEPTH; ++i) wq[i] = *reinterpret_cast<const f32x4*>(wgt + i * 256);
+  // ---- weights: [cout block][chunk][wave][18 = group x channel quad][64 lanes][4 positions] f32: 1 KiB per piece, straight into this
+  // wave's ring of RD slots by DMA; piece s (counted over all chunks) lives in slot s % RD = (s % 18) % RD
+  const char* wgt = reinterpret_cast<const char*>(reinterpret_cast<const float*>(p.w) + ((size_t)cb * (nchunk + 1) * 8 + wave) * (WSTEP * 256));
+  asm volatile("" : "+s"(wgt));
+  const size_t wchunk = (size_t)8 * WSTEP * 1024;   // bytes per chunk (all 8 waves)
+  const unsigned lane16 = (unsigned)(lane * 16);
+  const unsigned ring = (unsigned)(RING_OFF + wave * RD * 1024);
+  const float* const ringp = reinterpret_cast<const float*>(smem + RING_OFF) + wave * RD * 256 + lane * 4;
+  // piece idx + RD relative to the current chunk (the buffer is padded by one zero chunk: the stream runs RD pieces past the last one)
+  auto dma_w = [&](int idx) { glds16(idx < WSTEP ? wgt + idx * 1024 : wgt + wchunk + (idx - WSTEP) * 1024, lane16, ring + (unsigned)((idx % RD) * 1024)); };
 
   f32x4 acc[36];
 #pragma unroll
   for (int i = 0; i < 36; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: chunk 0 through the producer, chunk 1 into the registers
-  load_halo(0);
-  store_halo(0);
+  // ---- prologue: the first ring of weights, chunk 0 (everybody) and chunk 1 (group 0) through the producer
+#pragma unroll
+  for (int i = 0; i < RD; ++i) dma_w(i);
+  dma_halo();
+  dma_halo();
+  aff_request();
+  produce(0, TFIRST{});
+#ifdef FD_W44_SKEWED
+  if (grp == 0) produce(1, TFIRST{});
   __syncthreads();
-  transform(0);
-  load_halo(1);
+  if (grp == 1) { produce(1, TFIRST{}); __syncthreads(); }   // group 1: one producer step and one barrier behind
+#else
+  produce(1, TFIRST{});
   __syncthreads();
+#endif
   FD_T2(const unsigned long long t2_first = __builtin_amdgcn_s_memtime();)
 
-  // one chunk of MFMAs on V[buf]; ALL = every position (3x3 chunk) or the 16 inner ones (shortcut chunk).  B operand of (g, kk): lane
-  // (tile n16, channel 4 kk + kq) reads 16 bytes = 4 positions; A operand from the weight registers (loaded WDEPTH steps ahead; the
-  // buffer is padded by one chunk, so the loads past the last chunk read zeros that are never used)
+  // one chunk of MFMAs on V[buf]; ALL = every position (3x3 chunk) or the 16 inner ones (shortcut chunk).  Step idx = (g, kk): A operand =
+  // 16 bytes of ring slot idx % RD (4 positions of this lane's cout / channel), B operand = 16 bytes of V (lane = tile n16, channel
+  // 4 kk + kq); both for step idx + 1 are requested before the MFMAs of step idx.  In flight on the vector-memory counter when step idx
+  // waits for piece idx + 1, oldest first: the pieces idx + 1 .. idx + RD - 1 and -- for the pieces requested before this phase, idx + 1 < RD
+  // -- the 2 halo requests of the producer step in front of this phase: vmcnt(RD - 2 + 2) resp. vmcnt(RD - 2).
   auto mfma_chunk = [&](int buf, auto all_tag) {
     constexpr bool ALL = decltype(all_tag)::value;
-    const float* vb = vbuf[buf] + n16 * CK * 4;
+    const float* vb = vbuf0 + buf * V_FLOATS + n16 * CK * 4;
+    auto b_of = [&](int idx) { const int g = idx >> 1, kk = idx & 1; return *reinterpret_cast<const f32x4*>(vb + g * 16 * CK * 4 + (((4 * kk + kq) ^ (n16 >> 1)) * 4)); };
+    auto a_of = [&](int idx) { return *reinterpret_cast<const f32x4*>(ringp + (idx % RD) * 256); };
+#ifndef FD_ABL_NOWAIT
+    vm_wait<RD + 1>();      // piece 0: pieces 1 .. RD - 1 and the 2 halo requests may stay in flight
+#endif
+    f32x4 av = a_of(0), bv = b_of(0);
 #pragma unroll
     for (int idx = 0; idx < WSTEP; ++idx) {
-      const int g = idx >> 1, kk = idx & 1;
-      const f32x4 av = wq[idx % WDEPTH];
-      // the load WDEPTH steps ahead: this chunk's, or -- past its 18 -- the first ones of the NEXT chunk (layout [chunk][wave][18])
-      wq[idx % WDEPTH] = *reinterpret_cast<const f32x4*>(idx + WDEPTH < WSTEP ? wgt + (idx + WDEPTH) * 256 : wgt + wchunk + (idx + WDEPTH - WSTEP) * 256);
-      bool any = ALL;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) any = any || inner_pos(4 * g + e);
-      if (!any) continue;
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(vb + g * 16 * CK * 4 + (((4 * kk + kq) ^ (n16 >> 1)) * 4));
+      const int g = idx >> 1;
+      f32x4 an = av, bn = bv;
+      if (idx + 1 < WSTEP) {
+#ifndef FD_ABL_NOWAIT     // (timing-only ablation: how much of the phase is waiting for weights)
+        if (idx + 1 < RD) vm_wait<RD>(); else vm_wait<RD - 2>();
+#endif
+        an = a_of(idx + 1);
+        bn = b_of(idx + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // the requests of step idx + 1 stay IN FRONT of the MFMAs of step idx (a whole step of LDS latency hidden)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
+#ifdef FD_ABL_NOMFMA   // (timing-only ablation: the producer without a multiplying wave next to it)
+        if (ALL || inner_pos(4 * g + e)) acc[4 * g + e][0] += av[e] * bv[e];
+#else
         if (ALL || inner_pos(4 * g + e)) acc[4 * g + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc[4 * g + e], 0, 0, 0);
+#endif
+      dma_w(idx + RD);      // into the slot of step idx: its operand was read one step ago
+      av = an; bv = bn;
     }
     wgt += wchunk;
+    asm volatile("" : "+s"(wgt));
   };
   using TALL = std::integral_constant<bool, true>;
   using TINNER = std::integral_constant<bool, false>;
 
-  // ---- K loop: MFMAs of chunk c on V[c & 1]; then chunk c + 1 (in registers since the previous iteration) -> z -> V[(c + 1) & 1], and the
-  // halo of chunk c + 2 is requested.  Two barriers per chunk; the two waves of a SIMD overlap each other's producer with their MFMAs.
+  // ---- K loop (both groups; group 1 is one half-phase behind)
   for (int c = 0; c < nchunk; ++c) {
-    if (c < n3) mfma_chunk(c & 1, TALL{});
-    else mfma_chunk(c & 1, TINNER{});
-    if (c + 1 < nchunk) {
-      store_halo(c + 1);
-      load_halo(c + 2);
-      __syncthreads();
-      transform((c + 1) & 1);
-      __syncthreads();
-    }
+    FD_T2(const unsigned long long ta = __builtin_amdgcn_s_memtime();)
+    if (c < n3) mfma_chunk(c % 3, TALL{});
+    else mfma_chunk(c % 3, TINNER{});
+    FD_T2(const unsigned long long tb = __builtin_amdgcn_s_memtime(); t2_mfma += tb - ta;)
+#ifdef FD_W44_SKEWED
+    __syncthreads();
+#endif
+    produce(c + 2, TSTEADY{});
+    __syncthreads();
+    FD_T2(t2_prod += __builtin_amdgcn_s_memtime() - tb;)
   }
+#ifdef FD_W44_SKEWED
+  if (grp == 0) __syncthreads();   // (group 1 passed one more barrier in front of the loop)
+#endif
+  vm_wait<0>();                    // the weight stream's run-off and the last halo request land before the workgroup may retire
   FD_T2(const unsigned long long t2_loop = __builtin_amdgcn_s_memtime();)
 
   // ---- epilogue.  acc[6 i + j][r]: cout cb * 128 + 16 wave + 4 kq + r, tile n16 = (ty, tx), position (i, j).  Per output row a: T_j =
@@ -264,8 +361,20 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino44f_kernel(ConvArgs p) {
   if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + (size_t)(p.bias_rows > 1 ? b : 0) * p.Cout + cout);
   const int ty = n16 >> 2, tx = n16 & 3;
   f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+  auto row_off = [&](int a) { return ((size_t)(h0 + 4 * ty + a) * W + w0 + 4 * tx) * p.Cout; };
+  f32x4 sk[2][4];   // the residual input of output row a is requested while row a - 1 is transformed
+  if constexpr (SKIP) {
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) sk[0][bb] = *reinterpret_cast<const f32x4*>(skip + row_off(0) + (size_t)bb * p.Cout);
+  }
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
+    if constexpr (SKIP) {
+      if (a < 3) {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) sk[(a + 1) & 1][bb] = *reinterpret_cast<const f32x4*>(skip + row_off(a + 1) + (size_t)bb * p.Cout);
+      }
+    }
     f32x4 tj[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -275,12 +384,12 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino44f_kernel(ConvArgs p) {
     }
     f32x4 y[4];
     at4(tj, y);
-    const size_t rowoff = ((size_t)(h0 + 4 * ty + a) * W + w0 + 4 * tx) * p.Cout;
+    const size_t rowoff = row_off(a);
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
 #pragma clang fp contract(off)
       f32x4 v = y[bb] + bias4;
-      if constexpr (SKIP) v = v + *reinterpret_cast<const f32x4*>(skip + rowoff + (size_t)bb * p.Cout);
+      if constexpr (SKIP) v = v + sk[a & 1][bb];
       v = v * p.scale;
       ssum += v;
       ssq += v * v;
@@ -307,8 +416,9 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino44f_kernel(ConvArgs p) {
   if (p.dbg && t == 0 && bid < 8192) {
     const unsigned long long t2_end = __builtin_amdgcn_s_memtime();
     unsigned long long* d = p.dbg + (size_t)bid * 8;
-    d[0] = t2_first - t2_entry; d[1] = t2_loop - t2_first; d[2] = t2_end - t2_loop;
+    d[0] = t2_first - t2_entry; d[1] = t2_loop - t2_first; d[2] = t2_end - t2_loop; d[3] = t2_mfma; d[4] = t2_prod; d[5] = t2_pwait; d[6] = t2_pwork;
   }
+  if (p.dbg && t == 256 && bid < 8192) p.dbg[(size_t)bid * 8 + 7] = t2_mfma;   // a wave of group 1
   )
 }
 
@@ -348,12 +458,24 @@ __global__ void wino44f_pack_kernel(const float* __restrict__ w, const float* __
 }
 
 template <bool ACT>
+int set_attr44() {
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino44f_kernel<ACT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino44f_kernel<ACT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  return FD_OK;
+}
+template <bool ACT>
 void launch44(const ConvArgs& a, dim3 grid, hipStream_t st) {
-  if (a.skip) hipLaunchKernelGGL((conv_wino44f_kernel<ACT, true>), grid, dim3(NTH), 0, st, a);
-  else hipLaunchKernelGGL((conv_wino44f_kernel<ACT, false>), grid, dim3(NTH), 0, st, a);
+  if (a.skip) hipLaunchKernelGGL((conv_wino44f_kernel<ACT, true>), grid, dim3(NTH), LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((conv_wino44f_kernel<ACT, false>), grid, dim3(NTH), LDS_BYTES, st, a);
 }
 
 }  // namespace
+
+int fd_wino44f_init_attributes() {
+  FD_TRY(set_attr44<false>());
+  FD_TRY(set_attr44<true>());
+  return FD_OK;
+}
 
 bool fd_wino44f_supported(int Cout, int C0, int C1, int S0, int S1, int ksize) {
   return ksize == 3 && Cout > 0 && Cout % BN == 0 && C0 > 0 && C0 % CK == 0 && C1 % CK == 0 && S0 % CK == 0 && S1 % CK == 0 && (S1 == 0 || S0 > 0);
