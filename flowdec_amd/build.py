@@ -31,7 +31,7 @@ def needs_build():
 
 
 def check_wino4_isa(hipcc=None, extra=()):
-    """conv_wino4.hip (and its float32 twin conv_wino4f.hip) writes M0 from inline asm without saving it (the LDS-DMA destination; hipcc refuses M0 on a clobber list) and counts
+    """conv_wino4.hip (and the float32 kernels conv_wino4f.hip, conv_wino44f.hip) writes M0 from inline asm without saving it (the LDS-DMA destination; hipcc refuses M0 on a clobber list) and counts
     its own s_waitcnt vmcnt by hand.  Both rest on properties of the GENERATED code, so the build checks them and fails otherwise: no M0
     use outside the kernel's own `s_mov_b32 m0` statements, no scratch (a spill inside the K loop would break the counted waits), and the
     expected number of MFMA sites (one loop body per instantiation).  ~6 s, runs beside the object compiles.
@@ -44,8 +44,10 @@ def check_wino4_isa(hipcc=None, extra=()):
     hipcc = hipcc or _hipcc()
     ok = True
     # file -> (MFMA mnemonic, expected sites): conv_wino4.hip six instantiations x 18 steps x 4; conv_wino4f.hip (float32) six x 18 x 16 in the
-    # K loop + 64 per folded-shortcut stage body of the two shortcut instantiations
-    for src, (mnem, want) in {"conv_wino4.hip": ("v_mfma_f32_32x32x16_f16", 6 * 72), "conv_wino4f.hip": ("v_mfma_f32_32x32x2_f32", 6 * 288 + 2 * 64)}.items():
+    # K loop + 64 per folded-shortcut stage body of the two shortcut instantiations; conv_wino44f.hip (2-D float32) four x (72 per 3x3 chunk
+    # body + 32 per shortcut chunk body)
+    for src, (mnem, want) in {"conv_wino4.hip": ("v_mfma_f32_32x32x16_f16", 6 * 72), "conv_wino4f.hip": ("v_mfma_f32_32x32x2_f32", 6 * 288 + 2 * 64),
+                              "conv_wino44f.hip": ("v_mfma_f32_16x16x4_f32", 4 * (72 + 32))}.items():
         with tempfile.TemporaryDirectory() as d:
             out = os.path.join(d, "w4.s")
             r = subprocess.run([hipcc, *FLAGS, *extra, "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out], capture_output=True, text=True)
@@ -59,7 +61,7 @@ def check_wino4_isa(hipcc=None, extra=()):
             raise RuntimeError("%s: a kernel spills to scratch (breaks the hand-counted s_waitcnt vmcnt)" % src)
         n = sum(mnem in l for l in code)
         if n != want:
-            print("flowdec_amd.build: WARNING %s has %d F(4,3) MFMA sites, expected %d (the K loop was duplicated or unswitched by "
+            print("flowdec_amd.build: WARNING %s has %d Winograd MFMA sites, expected %d (the K loop was duplicated or unswitched by "
                   "this hipcc: slower, still correct)" % (src, n, want), file=sys.stderr)
             ok = False
     return ok

@@ -5,23 +5,29 @@
 // shortcut conv, residual, 1/sqrt(2), statistics of the output for the next GroupNorm, virtual channel concat) for the fp32 mode:
 //   V = B^T d B (6 x 6 input tile d, stride 4),  U = G g G^T,  M_(i,j) = sum_c U_(i,j) V_(i,j) (36 products per 16 outputs),  Y = A^T M A
 // i.e. 2.25 multiply-adds per output and input channel instead of 9 (direct) or 4.5 (conv_wino4f.hip: F(4,3) along W only) -- a quarter /
-// half of the MFMAs.  In float32 this pays in full: v_mfma_f32_16x16x4_f32 runs at the f32 VECTOR rate (1/16 of the fp16 matrix rate), so
-// the launch is bound by the matrix pipe and nothing else matters much -- which is why this kernel, unlike the fp16 kernels of this
-// library, is deliberately SIMPLE: no weight rings, no counted waits, two barriers per chunk.  (In fp16 the 2-D form is neither accurate
-// -- the transforms amplify an operand rounding ~100 x -- nor affordable: 2.25 accumulator planes per output.)
+// half of the MFMAs.  In float32 this pays: v_mfma_f32_16x16x4_f32 runs at the f32 VECTOR rate (1/16 of the fp16 matrix rate), the launch
+// is bound by the matrix pipe at any grid size.  (In fp16 the 2-D form is neither accurate -- the transforms amplify an operand rounding
+// ~100 x -- nor affordable: 2.25 accumulator planes per output.)
 //
 //   * one workgroup = 16 x 16 output pixels (16 tiles of 4 x 4) x 128 output channels, 8 waves; wave w owns couts 16 w .. 16 w + 15 for ALL
 //     36 positions and all 16 tiles: 36 accumulator tiles of 16 x 16 (v_mfma_f32_16x16x4_f32) = 144 registers, the whole output
 //     transform stays inside a lane (no exchange between waves);
-//   * K walks 8-channel chunks: halo (18 x 18 x 8) by LDS-DMA one chunk ahead, converted IN PLACE by the lanes that requested it
-//     ([silu(a x + d)], zero padding; a raw input needs no conversion at all) -> 2-D input transform -> V (LDS, double-buffered,
-//     [position group of 4][tile][channel slot][4 positions]: one ds_read_b128 feeds 4 MFMAs);
+//   * K walks 8-channel chunks.  PRODUCER, wave-private: wave w owns the tiles (row w >> 1, columns 2 (w & 1), + 1), requests their
+//     6 x 10-pixel window by LDS-DMA two chunks ahead into one of its two z windows ([channel half][pixel][4 channels]: the half is uniform
+//     per request, so the GroupNorm affine of a chunk is 16 scalar registers, loaded one step ahead), converts it IN PLACE ([silu(a x + d)],
+//     zero padding; a raw input inside the image needs no conversion at all) and transforms it: lanes = (channel 8, tile 2, third 3), all 36
+//     inputs of a lane's 6 x 6 tile in one round of LDS reads -> V (LDS, three buffers, [position group of 4][tile][channel slot][4
+//     positions]: one ds_read_b128 feeds 4 MFMAs);
 //   * weights: transformed at pack time, laid out so that a lane's operand of 4 consecutive positions is one aligned 16-byte piece of
-//     a contiguous 1-KiB wave load: they go from L2 straight into registers, 6 loads ahead (32 B / clk and CU: half the L1 rate);
+//     a contiguous 1-KiB wave piece; the pieces go from L2 into a 9-slot per-wave LDS ring by DMA, 9 steps ahead (18 pieces per chunk:
+//     a step's slot is a compile-time constant); every vector-memory operation of the loop is a DMA, the s_waitcnt vmcnt(N) are exact;
 //   * the folded 1x1 shortcut (Conv_2, layerspp.py:276-284) is more K chunks on the raw shortcut input: a centre-tap kernel transforms
 //     to the 16 inner positions only, so a shortcut chunk costs 16 of the 36 MFMAs -- exactly the 1x1 convolution's multiply-adds;
-//   * epilogue: Y = A^T M A on 4-cout vectors in registers, bias / residual / scale, statistics by cross-lane adds, 16-byte stores.
-// Error against the f64 convolution: ~1e-6 (tests/test_hip_configs.py test_conv2d_winograd44_f32).
+//   * epilogue: Y = A^T M A on 4-cout vectors in registers, bias / residual (rows requested one ahead) / scale, statistics by cross-lane
+//     adds, 16-byte stores.
+// Error against the f64 convolution: ~1e-6 (tests/test_hip_configs.py test_conv2d_winograd4_f32[44-*]).  Per launch 1.1-1.4 x the F(4,3)
+// float32 kernel and 1.8-2.2 x the direct one (profiles/r06_wino44f.txt); the K loop runs at ~60 % of its MFMA floor (2 x 72 MFMAs x 32
+// cycles per chunk and SIMD) -- the rest is the producer's vector instructions, which cannot overlap float32 MFMAs on this chip.
 #include <type_traits>
 
 #include "conv_common.h"
@@ -90,14 +96,16 @@ __device__ __forceinline__ void glds16(const void* sbase_, unsigned voff, unsign
 template <int N>
 __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// Schedule.  The matrix pipe is the bound (v_mfma_f32_16x16x4_f32: 32 cycles per instruction and SIMD), so it must never wait for the
-// producer.  The 8 waves form two groups (waves 0-3 / 4-7: one wave of each group per SIMD) that alternate in HALF-PHASES separated by
-// one workgroup barrier each:          half-phase 2c: group 0 multiplies chunk c, group 1 produces its part of chunk c + 1
-//                                      half-phase 2c + 1: group 0 produces its part of chunk c + 2, group 1 multiplies chunk c
-// -- while one wave of a SIMD issues its 72 MFMAs, the other one converts and transforms.  Both groups run the SAME loop (multiply c;
-// barrier; produce c + 2; barrier); group 1 enters it one producer step and one barrier later.  PRODUCE is wave-private: wave w owns
-// the two tiles (row w >> 1, columns 2 (w & 1), + 1), requests their 6 x 10-pixel window by DMA into its own 2 KiB of z one chunk
-// ahead, converts it in place and transforms it -- no barrier inside.  V has three buffers (chunk k in V[k % 3]).
+// Schedule.  On gfx950 the float32 MFMA runs on the vector ALU's own multipliers: v_mfma_f32_16x16x4_f32 (32 cycles) and v_fma_f32 never
+// overlap, neither inside a wave nor between the two waves of a SIMD -- another wave's vector instructions next to MFMAs take LONGER than
+// the two one after the other (scripts/mfma_valu_coissue.hip, profiles/r06_mfma_valu_coissue.txt) -- so a chunk costs its 2 x 72 MFMAs per
+// SIMD plus the producer's vector instructions whatever the schedule, and the schedule is the simple one: all eight waves run
+//     the MFMAs of chunk c on V[c % 3]   |   the producer step of chunk c + 2 into V[(c + 2) % 3]   |   one barrier
+// (three V buffers: chunk c + 1 was finished before the previous barrier, nobody reads V[(c + 2) % 3] any more).  The producer is
+// wave-private: wave w owns the two tiles (row w >> 1, columns 2 (w & 1), + 1), requests their 6 x 10-pixel window by DMA into one of its
+// two z windows two chunks ahead (activations come from HBM), converts it in place and transforms it -- no barrier inside.  Variants measured
+// and not adopted (profiles/r06_wino44f.txt): the two halves of the workgroup half a chunk apart (one multiplies while its SIMD partner
+// produces), and the producer step woven into the MFMA steps (scripts/conv_wino44f_fused.patch): same ticks.
 template <bool ACT, bool SKIP>
 __global__ __launch_bounds__(NTH, 2) void conv_wino44f_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -122,7 +130,6 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino44f_kernel(ConvArgs p) {
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int grp = wave >> 2;
   const int n16 = lane & 15, kq = lane >> 4;
 
   // ---- chunk list: the 3x3 segments first, the folded-shortcut segments (taps == 1) behind them (wave-uniform scalar code)
@@ -240,20 +247,14 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino44f_kernel(ConvArgs p) {
     FD_T2(const unsigned long long tp0 = __builtin_amdgcn_s_memtime();)
     if constexpr (decltype(first_tag)::value) vm_wait<0>(); else vm_wait<RD + 2>();
     FD_T2(const unsigned long long tp1 = __builtin_amdgcn_s_memtime(); t2_pwait += tp1 - tp0;)
-    // the producer's vector instructions go in front of the other wave's MFMAs (which leave 7 of 8 issue slots free); at equal priority
-    // the multiplying wave wins the arbitration and the producer step takes twice as long
-    __builtin_amdgcn_s_setprio(3);
     if (k < nchunk) {
-#ifndef FD_ABL_NOPROD     // (timing-only ablation: the multiply phase without a producing wave next to it)
       convert_halo(k);
       if (tr_th < 3) transform(k);
-#endif
       cur_next(qc);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the transform's reads of z are done before the next request overwrites it
     dma_halo();             // chunk k + 2
     if (k + 1 < nchunk) aff_request();
-    __builtin_amdgcn_s_setprio(0);
     FD_T2(t2_pwork += __builtin_amdgcn_s_memtime() - tp1;)
   };
   using TFIRST = std::integral_constant<bool, true>;
@@ -274,21 +275,15 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino44f_kernel(ConvArgs p) {
 #pragma unroll
   for (int i = 0; i < 36; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: the first ring of weights, chunk 0 (everybody) and chunk 1 (group 0) through the producer
+  // ---- prologue: the first ring of weights, chunks 0 and 1 through the producer
 #pragma unroll
   for (int i = 0; i < RD; ++i) dma_w(i);
   dma_halo();
   dma_halo();
   aff_request();
   produce(0, TFIRST{});
-#ifdef FD_W44_SKEWED
-  if (grp == 0) produce(1, TFIRST{});
-  __syncthreads();
-  if (grp == 1) { produce(1, TFIRST{}); __syncthreads(); }   // group 1: one producer step and one barrier behind
-#else
   produce(1, TFIRST{});
   __syncthreads();
-#endif
   FD_T2(const unsigned long long t2_first = __builtin_amdgcn_s_memtime();)
 
   // one chunk of MFMAs on V[buf]; ALL = every position (3x3 chunk) or the 16 inner ones (shortcut chunk).  Step idx = (g, kk): A operand =
@@ -301,29 +296,21 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino44f_kernel(ConvArgs p) {
     const float* vb = vbuf0 + buf * V_FLOATS + n16 * CK * 4;
     auto b_of = [&](int idx) { const int g = idx >> 1, kk = idx & 1; return *reinterpret_cast<const f32x4*>(vb + g * 16 * CK * 4 + (((4 * kk + kq) ^ (n16 >> 1)) * 4)); };
     auto a_of = [&](int idx) { return *reinterpret_cast<const f32x4*>(ringp + (idx % RD) * 256); };
-#ifndef FD_ABL_NOWAIT
     vm_wait<RD + 1>();      // piece 0: pieces 1 .. RD - 1 and the 2 halo requests may stay in flight
-#endif
     f32x4 av = a_of(0), bv = b_of(0);
 #pragma unroll
     for (int idx = 0; idx < WSTEP; ++idx) {
       const int g = idx >> 1;
       f32x4 an = av, bn = bv;
       if (idx + 1 < WSTEP) {
-#ifndef FD_ABL_NOWAIT     // (timing-only ablation: how much of the phase is waiting for weights)
         if (idx + 1 < RD) vm_wait<RD>(); else vm_wait<RD - 2>();
-#endif
         an = a_of(idx + 1);
         bn = b_of(idx + 1);
       }
       __builtin_amdgcn_sched_barrier(0);   // the requests of step idx + 1 stay IN FRONT of the MFMAs of step idx (a whole step of LDS latency hidden)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-#ifdef FD_ABL_NOMFMA   // (timing-only ablation: the producer without a multiplying wave next to it)
-        if (ALL || inner_pos(4 * g + e)) acc[4 * g + e][0] += av[e] * bv[e];
-#else
         if (ALL || inner_pos(4 * g + e)) acc[4 * g + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc[4 * g + e], 0, 0, 0);
-#endif
       dma_w(idx + RD);      // into the slot of step idx: its operand was read one step ago
       av = an; bv = bn;
     }
@@ -333,22 +320,16 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino44f_kernel(ConvArgs p) {
   using TALL = std::integral_constant<bool, true>;
   using TINNER = std::integral_constant<bool, false>;
 
-  // ---- K loop (both groups; group 1 is one half-phase behind)
+  // ---- K loop: the MFMAs of chunk c, the producer step of chunk c + 2, one barrier
   for (int c = 0; c < nchunk; ++c) {
     FD_T2(const unsigned long long ta = __builtin_amdgcn_s_memtime();)
     if (c < n3) mfma_chunk(c % 3, TALL{});
     else mfma_chunk(c % 3, TINNER{});
     FD_T2(const unsigned long long tb = __builtin_amdgcn_s_memtime(); t2_mfma += tb - ta;)
-#ifdef FD_W44_SKEWED
-    __syncthreads();
-#endif
     produce(c + 2, TSTEADY{});
     __syncthreads();
     FD_T2(t2_prod += __builtin_amdgcn_s_memtime() - tb;)
   }
-#ifdef FD_W44_SKEWED
-  if (grp == 0) __syncthreads();   // (group 1 passed one more barrier in front of the loop)
-#endif
   vm_wait<0>();                    // the weight stream's run-off and the last halo request land before the workgroup may retire
   FD_T2(const unsigned long long t2_loop = __builtin_amdgcn_s_memtime();)
 

@@ -358,7 +358,8 @@ struct Fwd {
     // any grid size, and both kernels use one 256-cout workgroup per tile: halving the MFMAs is worth 1.6-1.9 x per launch.  By shape only.
     const bool autosel_f32 = m && (m->cfg.act_dtype & FD_WINOGRAD_AUTO) && dt == FD_F32 && opflag == 0;
     // fp32 mode: 2-D Winograd F(4x4, 3x3) in float32 (conv_wino44f.hip: a quarter of the direct kernel's MFMAs) wherever its shape rules hold
-    // (Cout % 128 == 0, whole 16 x 16 tiles, channel counts % 8 == 0); the matrix pipe bounds the launch at any grid size.  By shape only.
+    // (Cout % 128 == 0, whole 16 x 16 tiles, channel counts % 8 == 0): 1.1-1.4 x the F(4,3) float32 kernel per launch at 256 couts and
+    // 1.8-2.2 x the direct kernel at 128 (profiles/r06_wino44f.txt); the matrix pipe bounds the launch at any grid size.  By shape only.
     if (m && (m->cfg.act_dtype & FD_WINOGRAD_AUTO) && dt == FD_F32 && opflag == 0 && w_wino44 && out.H % 16 == 0 && out.W % 16 == 0) { w = w_wino44; wino44 = true; }
     else if (latency && px_tiles <= 24 && out.C >= 64) tile = FD_TILE_BN32_CHUNK;
     else if (autosel && px_tiles <= 16 && out.C >= 64) tile = FD_TILE_BN64_CHUNK;   // the 96 x 32 level: 18.5 us vs 22.6 (Winograd) at 8 clips, 17.1 vs 21.9 at one
@@ -937,18 +938,20 @@ extern "C" int fd_model_finalize(fd_model* m, void* stream) {
           FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, md.has_c2 ? p + "Conv_2.weight" : std::string(), md.has_c2 ? md.c0 : 0,
                            md.has_c2 ? md.c1 : 0, &md.w1w, st, FD_WINOGRAD));
         const bool both4 = (m->cfg.act_dtype & (FD_WINOGRAD_AUTO | FD_LOW_LATENCY)) != 0;
-        if (both4 && fd_conv_packed_bytes(md.cout, md.c0, md.c1, 3, 0, 0, m->dt | FD_WINOGRAD4) > 0)
-          FD_TRY(pack_conv(m, p + "Conv_0.weight", md.cout, md.c0, md.c1, 3, "", 0, 0, &md.w0w4, st, FD_WINOGRAD4));
-        if (both4 && fd_conv_packed_bytes(md.cout, md.cout, 0, 3, md.has_c2 ? md.c0 : 0, md.has_c2 ? md.c1 : 0, m->dt | FD_WINOGRAD4) > 0)
-          FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, md.has_c2 ? p + "Conv_2.weight" : std::string(), md.has_c2 ? md.c0 : 0,
-                           md.has_c2 ? md.c1 : 0, &md.w1w4, st, FD_WINOGRAD4));
-        if (both4 && m->dt == FD_F32 && !(m->cfg.act_dtype & (FD_BF16_OPERANDS | FD_BF16X3_OPERANDS))) {   // fp32 mode: the 2-D float32 kernel's packing
+        // fp32 mode: the 2-D float32 kernel's packing wherever its shape rules hold; the F(4,3) float32 packing (whose rules are a subset:
+        // Cout = 256, channels % 16) only where they do not -- Fwd::conv prefers the 2-D kernel, a second copy would be dead memory
+        if (both4 && m->dt == FD_F32 && !(m->cfg.act_dtype & (FD_BF16_OPERANDS | FD_BF16X3_OPERANDS))) {
           if (fd_conv_packed_bytes(md.cout, md.c0, md.c1, 3, 0, 0, FD_F32 | FD_WINOGRAD44) > 0)
             FD_TRY(pack_conv(m, p + "Conv_0.weight", md.cout, md.c0, md.c1, 3, "", 0, 0, &md.w0w44, st, FD_WINOGRAD44));
           if (fd_conv_packed_bytes(md.cout, md.cout, 0, 3, md.has_c2 ? md.c0 : 0, md.has_c2 ? md.c1 : 0, FD_F32 | FD_WINOGRAD44) > 0)
             FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, md.has_c2 ? p + "Conv_2.weight" : std::string(), md.has_c2 ? md.c0 : 0,
                              md.has_c2 ? md.c1 : 0, &md.w1w44, st, FD_WINOGRAD44));
         }
+        if (both4 && !md.w0w44 && fd_conv_packed_bytes(md.cout, md.c0, md.c1, 3, 0, 0, m->dt | FD_WINOGRAD4) > 0)
+          FD_TRY(pack_conv(m, p + "Conv_0.weight", md.cout, md.c0, md.c1, 3, "", 0, 0, &md.w0w4, st, FD_WINOGRAD4));
+        if (both4 && !md.w1w44 && fd_conv_packed_bytes(md.cout, md.cout, 0, 3, md.has_c2 ? md.c0 : 0, md.has_c2 ? md.c1 : 0, m->dt | FD_WINOGRAD4) > 0)
+          FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, md.has_c2 ? p + "Conv_2.weight" : std::string(), md.has_c2 ? md.c0 : 0,
+                           md.has_c2 ? md.c1 : 0, &md.w1w4, st, FD_WINOGRAD4));
         FD_TRY(pack_conv(m, p + "Conv_0.weight", md.cout, md.c0, md.c1, 3, "", 0, 0, &md.w0, st, md.wino0 ? FD_WINOGRAD : 0));
         if (md.has_c2) {  // fold the 1x1 shortcut into Conv_1's K loop; biases add
           FD_TRY(pack_conv(m, p + "Conv_1.weight", md.cout, md.cout, 0, 3, p + "Conv_2.weight", md.c0, md.c1, &md.w1, st, md.wino1 ? FD_WINOGRAD : 0));

@@ -29,4 +29,4 @@ for name, C0, C1, aff, skip, Cout in [("plain 256", 256, 0, 0, 0, 256), ("aff 25
         ms = e0.elapsed_time(e1)
         pro, loop, epi, mf, pr, pwait, pwork, mf1 = [d[:, k].mean().item() for k in range(8)]
         tag = {False: "direct f32", 4: "F(4,3) f32 ", 44: "F(4x4) f32 "}[algo]
-        print(f"{name:14s} {tag} {ms:8.3f} ms | ticks: prologue {pro:8.0f} loop {loop:9.0f} epilogue {epi:8.0f}" + (f" | loop = MFMA phases {mf:9.0f} (a wave of group 1: {mf1:.0f}) + producer phases {pr:9.0f}; inside the producer steps of wave 0: waiting for the halo {pwait:.0f}, working {pwork:.0f}" if algo == 44 else ""), flush=True)
+        print(f"{name:14s} {tag} {ms:8.3f} ms | ticks: prologue {pro:8.0f} loop {loop:9.0f} epilogue {epi:8.0f}" + (f" | loop = MFMA phases {mf:9.0f} (wave 4, the SIMD partner of wave 0: {mf1:.0f}) + producer phases {pr:9.0f}; inside the producer steps of wave 0: waiting for the halo {pwait:.0f}, working {pwork:.0f}" if algo == 44 else ""), flush=True)

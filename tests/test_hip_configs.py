@@ -594,7 +594,7 @@ def test_fp32_auto_runs_winograd4_f32_and_matches_direct():
         check(f"ncsnpp_nf64[fp32,{algo}]", outs[algo], g["out"], TOL_FWD_FULL["fp32"])
         del m
     e = rel_err(outs["auto"], outs["direct"])
-    report("fp32_forward[auto (F(4,3) f32) vs direct]", e, 2e-5)
+    report("fp32_forward[auto (2-D F(4x4,3x3) f32) vs direct]", e, 2e-5)
     assert 0 < e < 2e-5, e            # (0 would mean the F(4,3) kernel did not run: G10's image is 768 x 64 = 192 tiles)
     with pytest.raises(ValueError):
         flowdec_amd.from_preset("flowdec_75m", precision="fp32", conv_algo="winograd")
