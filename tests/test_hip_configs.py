@@ -506,7 +506,9 @@ def test_conv2d_winograd4(case):
 W4F_CASES = WINO4_CASES + [("f32_c16", 1, 16, 32, 16, 0, 256, True, 1, False, 0, 0), ("f32_sc48", 1, 16, 16, 48, 16, 256, True, 1, False, 32, 16)]
 # the 2-D kernel: Cout multiples of 128, channel counts multiples of 8, folded shortcut AND residual input together
 W44F_CASES = W4F_CASES + [("c128_cat", 2, 32, 16, 24, 8, 128, True, 1, True, 0, 0), ("c128_sc", 1, 16, 32, 128, 0, 128, True, 1, False, 64, 8),
-                          ("sc_and_skip", 1, 16, 16, 64, 0, 256, True, 1, True, 64, 0), ("c8", 1, 16, 16, 8, 0, 128, False, 0, False, 0, 0)]
+                          ("sc_and_skip", 1, 16, 16, 64, 0, 256, True, 1, True, 64, 0), ("c8", 1, 16, 16, 8, 0, 128, False, 0, False, 0, 0),
+                          # three cout blocks (the tile decode's modulo is not a power of two), per-clip bias rows, concat + residual
+                          ("c384_b3", 3, 16, 48, 40, 24, 384, True, 3, True, 0, 0)]
 
 
 @pytest.mark.parametrize("case", [(4, c) for c in W4F_CASES] + [(44, c) for c in W44F_CASES], ids=lambda ac: f"w{ac[0]}-{ac[1][0]}")
