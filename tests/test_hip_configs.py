@@ -579,6 +579,46 @@ def test_conv2d_winograd4_f32(case):
     assert rel_err(from_nhwc(out), from_nhwc(outd)) < 5e-6
 
 
+def test_conv2d_winograd44_f32_random_shapes():
+    """Randomised sweep of the 2-D float32 Winograd kernel against the DIRECT float32 kernel on the same tensors (both exact-f32 products:
+    5e-6): 48 seeded draws over batch, image size in whole tiles, channel counts (multiples of 8: 1 .. 9 chunks per segment, one or two
+    3x3 segments, none / one / two shortcut segments), Cout in {128, 256, 384}, and every combination of affine / per-clip bias / residual.
+    The chunk cursors, the padded last requests and the run-off of the weight ring see every segment layout the model does not use."""
+    from flowdec_amd import ops
+    rng = np.random.default_rng(20260)
+    f32 = torch.float32
+    worst = 0.0
+    for it in range(48):
+        B = int(rng.integers(1, 4)); H = 16 * int(rng.integers(1, 4)); W = 16 * int(rng.integers(1, 4))
+        C0 = 8 * int(rng.integers(1, 10)); C1 = 8 * int(rng.integers(0, 6)) * int(rng.integers(0, 2))
+        S0 = 8 * int(rng.integers(1, 6)) * int(rng.integers(0, 2)); S1 = 8 * int(rng.integers(1, 4)) * int(rng.integers(0, 2)) if S0 else 0
+        Cout = int(rng.choice([128, 256, 384]))
+        use_aff, use_skip, bias_rows = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), int(rng.choice([0, 1, B]))
+        Cin = C0 + C1
+        x = torch.from_numpy(rng.standard_normal((B, H, W, Cin)).astype(np.float32)).cuda()
+        w = dev((rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32))
+        aff = dev(np.stack([1 + 0.2 * rng.standard_normal((B, Cin)), 0.3 * rng.standard_normal((B, Cin))], axis=-1).astype(np.float32)) if use_aff else None
+        sc0 = sc1 = w_sc = None
+        if S0:
+            xs = torch.from_numpy(rng.standard_normal((B, H, W, S0 + S1)).astype(np.float32)).cuda()
+            sc0 = xs[..., :S0].contiguous(); sc1 = xs[..., S0:].contiguous() if S1 else None
+            w_sc = dev((rng.standard_normal((Cout, S0 + S1, 1, 1)) / np.sqrt(S0 + S1)).astype(np.float32))
+        bias = dev(rng.standard_normal((bias_rows, Cout)).astype(np.float32) if bias_rows > 1 else rng.standard_normal(Cout).astype(np.float32)) if bias_rows else None
+        skip = torch.from_numpy(rng.standard_normal((B, H, W, Cout)).astype(np.float32)).cuda() if use_skip else None
+        kw = dict(x1=x[..., C0:].contiguous() if C1 else None, affine=aff, bias=bias, skip=skip, scale=0.7 if use_skip else 1.0, sc0=sc0, sc1=sc1, want_stats=True)
+        x0 = x[..., :C0].contiguous()
+        outs = []
+        for algo in (44, False):
+            pw = ops.pack_conv_weight(w, C0=C0, dtype=f32, w_sc=w_sc, S0=S0 if S0 else None, winograd=algo)
+            outs.append(ops.conv2d(x0, pw, Cout, 3, winograd=algo, **kw))
+        torch.cuda.synchronize()
+        e = rel_err(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy())
+        es = rel_err(outs[0][1].double().sum(dim=1).cpu().numpy()[:, :Cout], outs[1][1].double().sum(dim=1).cpu().numpy()[:, :Cout])
+        assert e < 5e-6 and es < 5e-6, (it, B, H, W, C0, C1, S0, S1, Cout, use_aff, use_skip, bias_rows, e, es)
+        worst = max(worst, e)
+    report("conv2d_winograd44_f32[48 random shapes vs direct f32]", worst, 5e-6)
+
+
 def test_fp32_auto_runs_winograd4_f32_and_matches_direct():
     """precision='fp32' with conv_algo='auto' (the default) sends the 3x3 convolutions of every ResBlock to the float32 Winograd kernels
     (2-D F(4x4, 3x3)); 'direct' keeps the direct f32 kernel everywhere.  One full-width forward of each on G10's inputs: both inside the fp32
