@@ -26,7 +26,7 @@
 //   * epilogue: Y = A^T M A on 4-cout vectors in registers, bias / residual (rows requested one ahead) / scale, statistics by cross-lane
 //     adds, 16-byte stores.
 // Error against the f64 convolution: ~1e-6 (tests/test_hip_configs.py test_conv2d_winograd4_f32[44-*]).  Per launch 1.1-1.4 x the F(4,3)
-// float32 kernel and 1.8-2.2 x the direct one (profiles/r06_wino44f.txt); the K loop runs at ~60 % of its MFMA floor (2 x 72 MFMAs x 32
+// float32 kernel and 1.8-2.2 x the direct one (profiles/r06_wino44f.txt); the K loop runs at 58-65 % of its MFMA floor (2 x 72 MFMAs x 32
 // cycles per chunk and SIMD) -- the rest is the producer's vector instructions, which cannot overlap float32 MFMAs on this chip.
 #include <type_traits>
 
@@ -73,8 +73,14 @@ __device__ __forceinline__ void at4(const f32x4 (&m)[6], f32x4 (&y)[4]) {
   y[3] = d12 + 8.f * d34 + m[5];
 }
 
+// Position order.  The 36 positions (i, j) of the transformed tile are numbered so that the two rows a transform lane produces are 12
+// consecutive numbers = three aligned groups of four: rows {1, 2}, {3, 4}, {0, 5} (the pairs share their column arithmetic: row 1 / 2 =
+// u +- v etc.), xi = 12 * pair + 6 * (second row of the pair) + j.  Weights (pack kernel), V, accumulators and epilogue all use xi.
+__host__ __device__ constexpr int pos_row(int xi) { return xi < 12 ? 1 + xi / 6 : xi < 24 ? 3 + (xi - 12) / 6 : xi < 30 ? 0 : 5; }
+__host__ __device__ constexpr int pos_col(int xi) { return xi % 6; }
+__host__ __device__ constexpr int pos_of(int i, int j) { return (i == 1 ? 0 : i == 2 ? 6 : i == 3 ? 12 : i == 4 ? 18 : i == 0 ? 24 : 30) + j; }
 __device__ __forceinline__ bool inner_pos(int xi) {   // positions (i, j) with 1 <= i, j <= 4: where a centre-tap (1x1) kernel lives
-  const int i = xi / 6, j = xi - 6 * i;
+  const int i = pos_row(xi), j = pos_col(xi);
   return i >= 1 && i <= 4 && j >= 1 && j <= 4;
 }
 
@@ -205,12 +211,18 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino44f_kernel(ConvArgs p) {
     }
   };
 
-  // ---- 2-D input transform of the wave's two tiles: lanes 0 .. 47 = (channel 8, tile 2, third 3); a lane transforms the columns of its
-  // channel's 6 x 6 tile, keeps the output rows 2 third, 2 third + 1 = positions 12 third .. 12 third + 11 and stores them as three
-  // 16-byte groups of four consecutive positions: V[g][tile][slot = ch ^ (tile >> 1)][4] (the XOR keeps the MFMA's ds_read_b128 free of
+  // ---- 2-D input transform of the wave's two tiles: lanes 0 .. 47 = (channel 8, tile 2, third 3); a lane computes the two rows of its
+  // third's pair (rows {1, 2} / {3, 4} / {0, 5}) of B^T d for the six columns, transforms them along the row and stores its positions
+  // 12 third .. 12 third + 11 (see "Position order") as three 16-byte groups of four consecutive positions: V[g][tile][slot = ch ^ (tile >> 1)][4] (the XOR keeps the MFMA's ds_read_b128 free of
   // bank conflicts).  LDS operations of one wave complete in order: the reads see the in-place conversion of the other lanes.
   const int tr_ch = lane & 7, tr_tl = (lane >> 3) & 1, tr_th = lane >> 4;
-  auto transform = [&](int k) {        // (all 48 lanes run the same instructions: the third only selects rows and the store address)
+  // per-lane coefficients of the column pass: the lane's two rows a, b of B^T d as  u = d4 + k1 d2,  v = k2 d3 + k3 d1,
+  //   a = u + ta v + e0 d0,  b = sb u + tb v + e5 d5      (rows 1, 2: u +- v with (k1, k2, k3) = (-4, 1, -4); rows 3, 4: (-1, 2, -2);
+  //   rows 0, 5: a = 4 d0 - 5 d2 + d4, b = 4 d1 - 5 d3 + d5 with (-5, -5, 4))  -- 8 operations per column instead of the full B^T (14) + selects
+  const float ck1 = tr_th == 0 ? -4.f : tr_th == 1 ? -1.f : -5.f, ck2 = tr_th == 0 ? 1.f : tr_th == 1 ? 2.f : -5.f,
+              ck3 = tr_th == 0 ? -4.f : tr_th == 1 ? -2.f : 4.f, cta = tr_th == 2 ? 0.f : 1.f, ce0 = tr_th == 2 ? 4.f : 0.f,
+              csb = tr_th == 2 ? 0.f : 1.f, ctb = tr_th == 2 ? 1.f : -1.f, ce5 = tr_th == 2 ? 1.f : 0.f;
+  auto transform = [&](int k) {        // (all 48 lanes run the same instructions: the third only sets coefficients and the store address)
     const int buf = k % 3;
     const float* zp = zw + (k & 1) * ZWAVE + (tr_ch >> 2) * ZHALF + (4 * tr_tl) * 4 + (tr_ch & 3);
     float dd[6][6];     // all 36 values requested at once: one LDS latency per producer step, not one per column
@@ -219,13 +231,13 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino44f_kernel(ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 6; ++r) dd[j][r] = zp[(r * WC + j) * 4];
     __builtin_amdgcn_sched_barrier(0);
-    float trow[2][6];   // trow[ii][j] = (B^T d)[2 third + ii][j]
+    float trow[2][6];   // trow[ii][j] = (B^T d)[row ii of the lane's pair][j]
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      float o6[6];
-      bt6(dd[j], o6);
-      trow[0][j] = tr_th == 0 ? o6[0] : tr_th == 1 ? o6[2] : o6[4];
-      trow[1][j] = tr_th == 0 ? o6[1] : tr_th == 1 ? o6[3] : o6[5];
+      const float u = fmaf(ck1, dd[j][2], dd[j][4]);
+      const float v = fmaf(ck2, dd[j][3], ck3 * dd[j][1]);
+      trow[0][j] = fmaf(ce0, dd[j][0], fmaf(cta, v, u));
+      trow[1][j] = fmaf(ce5, dd[j][5], fmaf(ctb, v, csb * u));
     }
     const int tile = ty_w * 4 + 2 * tp_w + tr_tl;
     float* vb = vbuf0 + buf * V_FLOATS + (tile * CK + (tr_ch ^ (tile >> 1))) * 4 + 3 * tr_th * 16 * CK * 4;
@@ -359,7 +371,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino44f_kernel(ConvArgs p) {
     f32x4 tj[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      const f32x4 m0 = acc[j], m1 = acc[6 + j], m2 = acc[12 + j], m3 = acc[18 + j], m4 = acc[24 + j], m5 = acc[30 + j];
+      const f32x4 m0 = acc[pos_of(0, j)], m1 = acc[pos_of(1, j)], m2 = acc[pos_of(2, j)], m3 = acc[pos_of(3, j)], m4 = acc[pos_of(4, j)], m5 = acc[pos_of(5, j)];
       const f32x4 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
       tj[j] = a == 0 ? m0 + s12 + s34 : a == 1 ? d12 + 2.f * d34 : a == 2 ? s12 + 4.f * s34 : d12 + 8.f * d34 + m5;
     }
@@ -422,7 +434,7 @@ __global__ void wino44f_pack_kernel(const float* __restrict__ w, const float* __
     const int chunk = (int)(r % (nchunk + 1));
     const int cb = (int)(r / (nchunk + 1));
     const int g = idx >> 1, kk = idx & 1;
-    const int xi = 4 * g + e, i = xi / 6, j = xi - 6 * i;
+    const int xi = 4 * g + e, i = pos_row(xi), j = pos_col(xi);
     const int co = cb * BN + 16 * wave + (lane & 15), k = 4 * kk + (lane >> 4);
     float v = 0.f;
     if (chunk < n3) {
