@@ -115,7 +115,8 @@ class NCSNpp(nn.Module):
             raise ValueError(f"conv_algo must be one of {sorted(CONV_ALGOS)} (precision != 'bf16': 'direct' or 'auto' only)")
         if precision in ("mixed", "bf16x3"):
             conv_algo = "direct"   # 'auto' = best available: the split / mixed operand modes have the direct kernel only
-        # precision='fp32' + 'auto': Winograd F(4,3) in exact float32 (conv_wino4f.hip) for every 3x3 layer with 256 output channels on whole 16 x 16 tiles
+        # precision='fp32' + 'auto': 2-D Winograd F(4x4, 3x3) in exact float32 (conv_wino44f.hip) for every 3x3 layer with a multiple of 128 output
+        # channels on whole 16 x 16 tiles
         self.nf, self.ch_mult, self.num_res_blocks, self.precision, self.conv_algo = nf, ch_mult, num_res_blocks, precision, conv_algo
         self.num_resolutions = len(ch_mult)
         self.output_layer = nn.Conv2d(num_channels, 2, kernel_size=1, bias=False)
