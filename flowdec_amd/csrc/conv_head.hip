@@ -9,7 +9,7 @@
 //     zero row (an LDS broadcast): no weight ring, no DMA waits, 2 barriers per chunk, both only for the halo buffer;
 //   * keeps TWO chunks of halo in flight in registers (the loads of chunk c+3 are issued when chunk c+1 is stored), so that a
 //     chunk's global loads have two chunk times to land;
-//   * ONE halo buffer -> 76 KiB of LDS, two workgroups per CU;
+//   * ONE halo buffer -> 47 KiB (128 input channels: three workgroups per CU) / 56 KiB (256: two) of LDS;
 //   * stores straight from registers: the 4 output channels of a pixel are accumulator registers 0..3 of one lane.
 // Contract = fd_conv2d with Cout = 4, ksize 3, an even number of 32-channel chunks, no folded shortcut, no statistics output.
 #include <type_traits>
@@ -23,10 +23,11 @@ using namespace fdconv;
 constexpr int NTH = 256, TH = 16, TW = 16, HH = TH + 2, HW = TW + 2;
 constexpr int HALO_BYTES = HH * PITCH * ROWB;      // one buffer, the direct kernel's geometry (PITCH 24, ROWB 80)
 constexpr int MAX_STEPS = 9 * 16;                  // up to 512 input channels
-constexpr int W_OFF = HALO_BYTES;                  // [step][4 rows][64 B]
-constexpr int ZERO_OFF = W_OFF + MAX_STEPS * 256;  // 64 B of zeros: rows 4..31 of the A operand
+constexpr int ZERO_OFF = HALO_BYTES;               // 64 B of zeros: rows 4..31 of the A operand
 constexpr int AFFH_OFF = ZERO_OFF + 64;
-constexpr int LDS_BYTES = AFFH_OFF + AFF_BYTES;    // 34560 + 36864 + 64 + 4096 = 75584 -> 2 workgroups per CU
+constexpr int W_OFF = AFFH_OFF + AFF_BYTES;        // [step][4 rows][64 B], LAST: a launch allocates what its layer needs
+constexpr int LDS_MAX = W_OFF + MAX_STEPS * 256;   // 34560 + 64 + 4096 + 36864 = 75584 (512 input channels)
+__host__ __device__ constexpr int lds_bytes(int nsteps) { return W_OFF + nsteps * 256; }   // 256 channels: 57152 -> 2 workgroups per CU; 128: 47936 -> 3
 constexpr int PPP = NTH / 4;
 constexpr int HITER = (HH * HW + PPP - 1) / PPP;   // 6
 constexpr int CK = 32, EPS = 8;
@@ -259,10 +260,10 @@ bool fd_head_supported(const ConvArgs& a, int ksize, int dtype) {
 }
 
 int fd_head_init_attributes() {
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_head_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_head_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_head_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_head_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_head_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_head_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_head_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+  FD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_head_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
   return FD_OK;
 }
 
@@ -273,6 +274,9 @@ int fd_head_launch(ConvArgs a, hipStream_t st) {
   const long long nblk = (long long)a.B * a.tiles_h * a.tiles_w;
   FD_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv grid out of range");
   const dim3 grid((unsigned)nblk), block(NTH);
+  int chunks = 0;
+  for (int s = 0; s < a.nseg; ++s) chunks += (a.seg[s].C + CK - 1) / CK;
+  const int LDS_BYTES = lds_bytes(chunks * 9);
   if (a.affine) {
     if (a.skip) hipLaunchKernelGGL((conv_head_kernel<true, true>), grid, block, LDS_BYTES, st, a);
     else hipLaunchKernelGGL((conv_head_kernel<true, false>), grid, block, LDS_BYTES, st, a);
