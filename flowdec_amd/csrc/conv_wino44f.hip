@@ -26,7 +26,7 @@
 //   * epilogue: Y = A^T M A on 4-cout vectors in registers, bias / residual (rows requested one ahead) / scale, statistics by cross-lane
 //     adds, 16-byte stores.
 // Error against the f64 convolution: ~1e-6 (tests/test_hip_configs.py test_conv2d_winograd4_f32[44-*]).  Per launch 1.1-1.4 x the F(4,3)
-// float32 kernel and 1.8-2.2 x the direct one (profiles/r06_wino44f.txt); the K loop runs at 58-65 % of its MFMA floor (2 x 72 MFMAs x 32
+// float32 kernel and 1.8-2.2 x the direct one (profiles/r06_wino44f.txt); the K loop runs at 60-67 % of its MFMA floor (2 x 72 MFMAs x 32
 // cycles per chunk and SIMD) -- the rest is the producer's vector instructions, which cannot overlap float32 MFMAs on this chip.
 #include <type_traits>
 
@@ -332,16 +332,18 @@ __global__ __launch_bounds__(NTH, 2) void conv_wino44f_kernel(ConvArgs p) {
   using TALL = std::integral_constant<bool, true>;
   using TINNER = std::integral_constant<bool, false>;
 
-  // ---- K loop: the MFMAs of chunk c, the producer step of chunk c + 2, one barrier
-  for (int c = 0; c < nchunk; ++c) {
+  // ---- K loop: the MFMAs of chunk c, the producer step of chunk c + 2, one barrier.  TWO loops, one per chunk kind: with both MFMA bodies in
+  // one loop hipcc keeps a second copy of the 16 accumulator tiles the shortcut body touches and moves 64 registers per iteration
+  auto k_iteration = [&](int c, auto all_tag) {
     FD_T2(const unsigned long long ta = __builtin_amdgcn_s_memtime();)
-    if (c < n3) mfma_chunk(c % 3, TALL{});
-    else mfma_chunk(c % 3, TINNER{});
+    mfma_chunk(c % 3, all_tag);
     FD_T2(const unsigned long long tb = __builtin_amdgcn_s_memtime(); t2_mfma += tb - ta;)
     produce(c + 2, TSTEADY{});
     __syncthreads();
     FD_T2(t2_prod += __builtin_amdgcn_s_memtime() - tb;)
-  }
+  };
+  for (int c = 0; c < n3; ++c) k_iteration(c, TALL{});
+  for (int c = n3; c < nchunk; ++c) k_iteration(c, TINNER{});
   vm_wait<0>();                    // the weight stream's run-off and the last halo request land before the workgroup may retire
   FD_T2(const unsigned long long t2_loop = __builtin_amdgcn_s_memtime();)
 
