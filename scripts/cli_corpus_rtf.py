@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--N", type=int, default=6)
     ap.add_argument("--solver", default="euler")
     ap.add_argument("--batches", type=int, nargs="+", default=[1, 8, 16])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "mixed"])
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r06_cli_corpus_rtf.json"))
     args = ap.parse_args()
     import flowdec_amd
@@ -38,7 +39,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix="fd_corpus_")
     try:
         # full-width FlowDec-75m with seeded random weights, saved in the Lightning layout the reference's checkpoints have
-        m = flowdec_amd.from_preset("flowdec_75m", precision="bf16")
+        m = flowdec_amd.from_preset("flowdec_75m", precision=args.precision)
         g = torch.Generator().manual_seed(1234)
         sd = {}
         for k, v in m.state_dict().items():
@@ -66,9 +67,9 @@ def main():
             buckets[padded_frames_of(int(n))] = buckets.get(padded_frames_of(int(n)), 0) + 1
         audio = float(lens.sum()) / 48000
         fill = float(sum(lens)) / sum(384.0 * padded_frames_of(int(n)) for n in lens)
-        model = enhance_cli.load_from_checkpoint(ckpt, map_location="cuda:0", precision="bf16")
+        model = enhance_cli.load_from_checkpoint(ckpt, map_location="cuda:0", precision=args.precision)
         res = {"files": int(args.files), "audio_seconds": audio, "lengths_s": [float(args.min_s), float(args.max_s)], "N": args.N, "solver": args.solver,
-               "precision": "bf16", "files_per_T_pad_bucket": {str(k): v for k, v in sorted(buckets.items())},
+               "precision": args.precision, "files_per_T_pad_bucket": {str(k): v for k, v in sorted(buckets.items())},
                "samples_over_padded_frames": fill, "runs": {}}
         ref_dir = None
         for bf in args.batches:
