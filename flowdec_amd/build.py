@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libflowdec_hip.so")
-SOURCES = ["api.hip", "calib.hip", "conv_mfma.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wino4f.hip", "conv_wino44f.hip", "conv_head.hip", "elementwise.hip", "stft.hip", "model.hip", "ndac.hip", "ndac_mfma.hip"]
+SOURCES = ["api.hip", "calib.hip", "conv_mfma.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wino4f.hip", "conv_wino44f.hip", "conv_head.hip", "conv_headf.hip", "elementwise.hip", "stft.hip", "model.hip", "ndac.hip", "ndac_mfma.hip"]
 # -fno-slp-vectorize: hipcc (ROCm 7.2) otherwise packs adjacent f32 FMAs into v_pk_fma_f32; beside MFMAs that is slower
 # (guide: MI355X_MICROARCH "price of one filler beside MFMAs") and one such packing of the fused GroupNorm affine
 # produced wrong lanes (op_sel_hi broadcast) in the f32 conv path.

@@ -88,3 +88,8 @@ bool fd_wino44f_shape_ok(int H, int W);
 bool fd_head_supported(const fdconv::ConvArgs& a, int ksize, int dtype);
 int fd_head_launch(fdconv::ConvArgs a, hipStream_t st);
 int fd_head_init_attributes();
+
+// conv_headf.hip (Cout = 4 pyramid heads, exact float32: v_mfma_f32_4x4x1_16B_f32)
+bool fd_headf_supported(const fdconv::ConvArgs& a, int ksize, int dtype);
+int fd_headf_launch(fdconv::ConvArgs a, hipStream_t st);
+int fd_headf_init_attributes();

@@ -1241,6 +1241,7 @@ int fd_conv_init_attributes() {
   FD_TRY(fd_wino4f_init_attributes());
   FD_TRY(fd_wino44f_init_attributes());
   FD_TRY(fd_head_init_attributes());
+  FD_TRY(fd_headf_init_attributes());
   if (known) done_dev[dev] = true;
   return FD_OK;
 }
@@ -1378,6 +1379,7 @@ extern "C" int fd_conv2d(const void* in0, int C0, const void* in1, int C1, const
   if (mixed) return dispatch_conv_mixed(a, fd_stream(stream));
   if (split) return dispatch_conv_split(a, fd_stream(stream));
   if (bn_hint == 0 && fd_head_supported(a, ksize, dtype)) return fd_head_launch(a, fd_stream(stream));
+  if (bn_hint == 0 && tile == 0 && fd_headf_supported(a, ksize, dtype)) return fd_headf_launch(a, fd_stream(stream));
   if (dtype == FD_BF16) return dispatch_conv<bf16>(a, fd_stream(stream), bn_hint, tile == FD_TILE_BN64_CHUNK || tile == FD_TILE_BN32_CHUNK, tile == FD_TILE_PERSIST);
   return dispatch_conv<float>(a, fd_stream(stream), bn_hint, false);
 }
